@@ -1,0 +1,267 @@
+/*
+ * niagara_vis.h — C ABI of the MI355X-native visibility front-end.
+ *
+ * Drop-in replacement for the compute passes niagara records between its scene
+ * upload and its indirect draws:
+ *
+ *     drawcull -> tasksubmit -> clustercull -> clustersubmit      (+ depthreduce)
+ *
+ * Every struct below keeps the byte layout of the reference (citations are
+ * relative to the reference tree, file:line).  Every entry point names the
+ * reference interface it replaces.  All pointers named d_* are DEVICE pointers
+ * owned by the caller; the library only owns scratch inside nv_context.
+ *
+ * Conventions (mirrors SURVEY.md §8b):
+ *   - all functions return 0 on success, a negative NV_E* code or a positive
+ *     hipError_t otherwise; nothing throws across this boundary;
+ *   - work is enqueued asynchronously on the caller's hipStream_t (passed as
+ *     void* so this header needs no HIP include);
+ *   - the caller zeroes count words before each pass (src/niagara.cpp:1541,1586)
+ *     and zeroes drawVisibility / meshletVisibility once (src/niagara.cpp:1450-1468);
+ *   - stage ordering == stream order (replaces the Vulkan barriers at
+ *     src/niagara.cpp:1561,1571,1601,1610,1725);
+ *   - overflow past NV_TASK_WGLIMIT / NV_CLUSTER_LIMIT is dropped silently,
+ *     exactly as drawcull.comp.glsl:128 and clustercull.comp.glsl:137 do.
+ *
+ * Output order.  The reference appends with unordered global atomics; this
+ * library appends in ascending invocation order (draw index; command index then
+ * lane), which is one valid serialisation of the reference and makes the lists
+ * bit-reproducible.
+ */
+#ifndef NIAGARA_VIS_H
+#define NIAGARA_VIS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- compile-time contract (src/config.h:2-28) ---- */
+#define NV_TASK_WGSIZE 64u           /* src/config.h:2  */
+#define NV_CLUSTER_TILE 16u          /* src/config.h:22 */
+#define NV_TASK_WGLIMIT (1u << 22)   /* src/config.h:25 */
+#define NV_CLUSTER_LIMIT (1u << 24)  /* src/config.h:28 */
+#define NV_MAX_LODS 8u               /* src/scene.h:92  */
+#define NV_MAX_MIPS 16u              /* sampler maxLod 16: src/resources.cpp:305 */
+
+/* ---- status codes ---- */
+#define NV_OK 0
+#define NV_EINVAL (-1)   /* bad argument */
+#define NV_ENOMEM (-2)   /* scratch allocation failed */
+#define NV_ESTATE (-3)   /* device-side protocol error (look-back spin bound hit) */
+#define NV_ENODEV (-4)   /* no HIP device */
+
+/* ---- layouts ---- */
+
+/* src/scene.h:10-23, src/shaders/mesh.h:11-24; 24 B, align 8. cull reads bytes 0-11 only */
+typedef struct NvMeshlet
+{
+	uint16_t center[3]; /* fp16 bits */
+	uint16_t radius;    /* fp16 bits */
+	int8_t cone_axis[3];
+	int8_t cone_cutoff;
+	uint32_t dataOffset;
+	uint32_t baseVertex;
+	uint8_t vertexCount;
+	uint8_t triangleCount;
+	uint8_t shortRefs;
+	uint8_t padding;
+} NvMeshlet;
+
+/* src/scene.h:39-49, src/shaders/mesh.h:92-102; 48 B, align 16; orientation is (x,y,z,w) */
+typedef struct NvMeshDraw
+{
+	float position[3];
+	float scale;
+	float orientation[4];
+	uint32_t meshIndex;
+	uint32_t meshletVisibilityOffset;
+	uint32_t postPass;
+	uint32_t materialIndex;
+} NvMeshDraw;
+
+/* src/scene.h:68-75, src/shaders/mesh.h:53-60; 20 B */
+typedef struct NvMeshLod
+{
+	uint32_t indexOffset;
+	uint32_t indexCount;
+	uint32_t meshletOffset;
+	uint32_t meshletCount;
+	float error;
+} NvMeshLod;
+
+/* src/scene.h:77-93, src/shaders/mesh.h:62-78; 208 B, align 16 */
+typedef struct NvMesh
+{
+	float center[3];
+	float radius;
+	uint32_t vertexOffset;
+	uint32_t vertexCount;
+	uint32_t ommIndexData;
+	uint32_t ommIndexBase;
+	uint32_t lodCount;
+	uint32_t lodRT;
+	uint32_t padding[2];
+	NvMeshLod lods[NV_MAX_LODS];
+} NvMesh;
+
+/* src/niagara.cpp:227-231, src/shaders/mesh.h:104-114; 24 B */
+typedef struct NvMeshDrawCommand
+{
+	uint32_t drawId;
+	uint32_t indexCount;
+	uint32_t instanceCount;
+	uint32_t firstIndex;
+	uint32_t vertexOffset;
+	uint32_t firstInstance;
+} NvMeshDrawCommand;
+
+/* src/niagara.cpp:233-240, src/shaders/mesh.h:116-123; 20 B */
+typedef struct NvMeshTaskCommand
+{
+	uint32_t drawId;
+	uint32_t taskOffset;
+	uint32_t taskCount;
+	uint32_t lateDrawVisibility;
+	uint32_t meshletVisibilityOffset;
+} NvMeshTaskCommand;
+
+/* src/niagara.cpp:242-260, src/shaders/mesh.h:26-44; 144 B (136 used), align 16.
+ * view is column-major: view[4*col + row]. */
+typedef struct NvCullData
+{
+	float view[16];
+	float P00, P11, znear, zfar;
+	float frustum[4];
+	float lodTarget;
+	float pyramidWidth, pyramidHeight;
+	uint32_t drawCount;
+	int32_t cullingEnabled;
+	int32_t lodEnabled;
+	int32_t occlusionEnabled;
+	int32_t clusterOcclusionEnabled;
+	int32_t clusterBackfaceEnabled;
+	uint32_t postPass;
+	uint32_t _pad[2];
+} NvCullData;
+
+/* Replaces the (depthPyramid image, depthSampler) descriptor pair
+ * (src/niagara.cpp:1339-1350 image + per-mip views; src/niagara.cpp:629 sampler =
+ * LINEAR filter, NEAREST mip, CLAMP_TO_EDGE, MIN reduction).  The mip chain is one
+ * linear fp32 buffer; level i is max(1,width>>i) x max(1,height>>i), row-major, at
+ * d_base + mipOffset[i] (offsets in floats). */
+typedef struct NvPyramidDesc
+{
+	float* d_base;
+	uint32_t width;   /* level-0 width  = previousPow2(depth target width)  */
+	uint32_t height;  /* level-0 height = previousPow2(depth target height) */
+	uint32_t levels;  /* getImageMipLevels(width, height), src/resources.cpp:280-292 */
+	uint32_t mipOffset[NV_MAX_MIPS];
+	uint32_t totalTexels;
+} NvPyramidDesc;
+
+typedef struct nv_context nv_context;
+
+/* ---- lifetime (replaces createProgram/createComputePipeline, src/niagara.cpp:652-762) ---- */
+int nv_create(nv_context** out_ctx, int device);
+void nv_destroy(nv_context* ctx);
+const char* nv_version(void);
+/* reads and clears the device-side error word; NV_OK or NV_ESTATE. Synchronises the stream. */
+int nv_status(nv_context* ctx, void* stream);
+
+/* ---- scene upload hook (next to uploadBuffer(mlb), src/niagara.cpp:1055) ----
+ * Builds the library-owned SoA mirror of the 12 cull bytes of every meshlet
+ * (bounds: 4 x fp16 = 8 B, cone: 4 x s8 = 4 B).  nv_clustercull uses the mirror when
+ * its d_meshlets argument equals the pointer registered here, and reads the 24-B AoS
+ * records directly otherwise. */
+int nv_upload_meshlets(nv_context* ctx, void* stream, const NvMeshlet* d_meshlets, uint32_t meshletCount);
+
+/* ---- the passes ---- */
+
+/* drawcull.comp.glsl:54-156; dispatch at src/niagara.cpp:1548-1556.
+ * late/task are the LATE/TASK specialisation constants (src/niagara.cpp:724-727).
+ * d_commands: NvMeshTaskCommand[NV_TASK_WGLIMIT] if task else NvMeshDrawCommand[drawCount].
+ * d_count4: {commandCount, groupCountX, groupCountY, groupCountZ} (dccb).
+ * pyramid may be NULL unless late && occlusionEnabled. */
+int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late, int task,
+                const NvMeshDraw* d_draws, const NvMesh* d_meshes, void* d_commands, uint32_t* d_count4,
+                uint32_t* d_drawVisibility, const NvPyramidDesc* pyramid);
+
+/* tasksubmit.comp.glsl:27-47; dispatch at src/niagara.cpp:1563-1568 */
+int nv_tasksubmit(nv_context* ctx, void* stream, uint32_t* d_count4, NvMeshTaskCommand* d_commands);
+
+/* clustercull.comp.glsl:56-149; indirect dispatch at src/niagara.cpp:1590-1599.
+ * The grid is taken on-device from d_count4[1] (groupCountX written by nv_tasksubmit):
+ * commands [0, groupCountX*64) are processed, like vkCmdDispatchIndirect(dccb, 4). */
+int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
+                   const NvMeshTaskCommand* d_commands, const uint32_t* d_count4, const NvMeshDraw* d_draws,
+                   const NvMeshlet* d_meshlets, uint32_t* d_meshletVisibility, const NvPyramidDesc* pyramid,
+                   uint32_t* d_clusterIndices, uint32_t* d_clusterCount4);
+
+/* clustersubmit.comp.glsl:25-45; dispatch at src/niagara.cpp:1603-1608 */
+int nv_clustersubmit(nv_context* ctx, void* stream, uint32_t* d_clusterCount4, uint32_t* d_clusterIndices);
+
+/* meshlet.task.glsl:53-149 (cull half): same tests as nv_clustercull but compacted per
+ * task command into a 64-entry payload, d_payloadCounts[c] = EmitMeshTasksEXT count. */
+int nv_taskcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
+                const NvMeshTaskCommand* d_commands, const uint32_t* d_count4, const NvMeshDraw* d_draws,
+                const NvMeshlet* d_meshlets, uint32_t* d_meshletVisibility, const NvPyramidDesc* pyramid,
+                uint32_t* d_payloads, uint32_t* d_payloadCounts);
+
+/* depthreduce.comp.glsl:14-22 + the level loop at src/niagara.cpp:1703-1733.
+ * d_depth is the width x height fp32 depth target (reverse-Z, far = 0). */
+int nv_depthreduce(nv_context* ctx, void* stream, const float* d_depth, uint32_t width, uint32_t height,
+                   const NvPyramidDesc* pyramid);
+
+/* ---- host helpers mirroring src/niagara.cpp / src/resources.cpp (no device work) ---- */
+uint32_t nv_previous_pow2(uint32_t v);                        /* src/niagara.cpp:439-447 */
+uint32_t nv_image_mip_levels(uint32_t width, uint32_t height); /* src/resources.cpp:280-292 */
+/* fills width/height/levels/mipOffset/totalTexels from the depth target size; d_base untouched */
+int nv_pyramid_desc_init(NvPyramidDesc* desc, uint32_t depthWidth, uint32_t depthHeight);
+/* src/niagara.cpp:424-437,1487-1516: CullData from a camera (position, orientation quat xyzw, fovY,
+ * znear), viewport, draw distance and pyramid size; flags are left 0 for the caller to set. */
+int nv_build_cull_data(NvCullData* out, const float cameraPosition[3], const float cameraOrientation[4],
+                       float fovY, float znear, float drawDistance, uint32_t viewportWidth,
+                       uint32_t viewportHeight, uint32_t pyramidWidth, uint32_t pyramidHeight,
+                       uint32_t drawCount, int debugLodStep);
+/* src/niagara.cpp:1002-1020: per-draw meshletVisibilityOffset prefix; returns the slot count
+ * through out_slots (meshletVisibility bytes = (slots+31)/32*4) and the postPass mask. */
+int nv_assign_visibility_offsets(NvMeshDraw* draws, uint32_t drawCount, const NvMesh* meshes,
+                                 uint32_t meshCount, uint32_t* out_slots, uint32_t* out_postPassMask);
+/* src/niagara.cpp:449-481,969-998: PCG32-seeded synthetic scene (state 0x42) */
+int nv_synth_draws(NvMeshDraw* draws, uint32_t drawCount, uint32_t meshCount, float sceneRadius);
+
+/* ---- multi-GPU helper: contiguous shard of `total` units for `rank` ---- */
+void nv_shard_range(uint64_t total, uint32_t rank, uint32_t world, uint64_t* begin, uint64_t* end);
+/* packs {count4a[0], count4b[0], count4c[0]} (any may be NULL -> 0) into d_out[3] as u64,
+ * the payload of the one ncclAllReduce(sum) per phase */
+int nv_pack_counts(nv_context* ctx, void* stream, const uint32_t* d_countA, const uint32_t* d_countB,
+                   const uint32_t* d_countC, uint64_t* d_out3);
+
+/* ---- verification probe (tests only): per-meshlet scalar intermediates of the cluster cull
+ * (view-space centre xyz, radius, cone lhs, cone rhs, aabb[4], mip level, sampled depth,
+ * depthSphere, flags) = 16 floats per lane, for the <=1-ULP scalar parity tests. */
+int nv_probe_cluster_scalars(nv_context* ctx, void* stream, const NvCullData* cull,
+                             const NvMeshTaskCommand* d_commands, uint32_t commandCount,
+                             const NvMeshDraw* d_draws, const NvMeshlet* d_meshlets,
+                             const NvPyramidDesc* pyramid, float* d_out16);
+
+#ifdef __cplusplus
+}
+
+static_assert(sizeof(NvMeshlet) == 24, "Meshlet layout (src/scene.h:10-23)");
+static_assert(sizeof(NvMeshDraw) == 48, "MeshDraw layout (src/scene.h:39-49)");
+static_assert(sizeof(NvMeshLod) == 20, "MeshLod layout (src/scene.h:68-75)");
+static_assert(sizeof(NvMesh) == 208, "Mesh layout (src/scene.h:77-93)");
+static_assert(offsetof(NvMesh, lods) == 48, "Mesh.lods offset");
+static_assert(sizeof(NvMeshDrawCommand) == 24, "MeshDrawCommand layout (src/niagara.cpp:227-231)");
+static_assert(sizeof(NvMeshTaskCommand) == 20, "MeshTaskCommand layout (src/niagara.cpp:233-240)");
+static_assert(sizeof(NvCullData) == 144, "CullData layout (src/niagara.cpp:242-260)");
+static_assert(offsetof(NvCullData, P00) == 64 && offsetof(NvCullData, frustum) == 80, "CullData offsets");
+static_assert(offsetof(NvCullData, lodTarget) == 96 && offsetof(NvCullData, drawCount) == 108, "CullData offsets");
+static_assert(offsetof(NvCullData, cullingEnabled) == 112 && offsetof(NvCullData, postPass) == 132, "CullData offsets");
+#endif
+
+#endif /* NIAGARA_VIS_H */

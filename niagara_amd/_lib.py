@@ -1,0 +1,61 @@
+"""ctypes binding of the C ABI in include/niagara_vis.h (niagara_amd/libniagara_vis.so).
+
+The library is the product: there is no Python or CPU fallback.  If the shared object is missing this module raises
+at import time, and every device entry point raises NvError on a non-zero status.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libniagara_vis.so")
+
+
+class NvError(RuntimeError):
+    pass
+
+
+class PyramidDesc(C.Structure):
+    _fields_ = [("d_base", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("levels", C.c_uint32),
+                ("mipOffset", C.c_uint32 * 16), ("totalTexels", C.c_uint32)]
+
+
+if not os.path.exists(SO_PATH):
+    raise ImportError("niagara_amd: %s is missing — build it with `make -C niagara_amd/csrc` (or __graft_entry__.build()); "
+                      "there is no fallback path" % SO_PATH)
+
+lib = C.CDLL(SO_PATH)
+
+_vp, _u32, _i, _f = C.c_void_p, C.c_uint32, C.c_int, C.c_float
+_SIGS = {
+    "nv_create": (_i, [C.POINTER(_vp), _i]),
+    "nv_destroy": (None, [_vp]),
+    "nv_version": (C.c_char_p, []),
+    "nv_status": (_i, [_vp, _vp]),
+    "nv_upload_meshlets": (_i, [_vp, _vp, _vp, _u32]),
+    "nv_drawcull": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(PyramidDesc)]),
+    "nv_tasksubmit": (_i, [_vp, _vp, _vp, _vp]),
+    "nv_clustercull": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(PyramidDesc), _vp, _vp]),
+    "nv_clustersubmit": (_i, [_vp, _vp, _vp, _vp]),
+    "nv_taskcull": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(PyramidDesc), _vp, _vp]),
+    "nv_depthreduce": (_i, [_vp, _vp, _vp, _u32, _u32, C.POINTER(PyramidDesc)]),
+    "nv_previous_pow2": (_u32, [_u32]),
+    "nv_image_mip_levels": (_u32, [_u32, _u32]),
+    "nv_pyramid_desc_init": (_i, [C.POINTER(PyramidDesc), _u32, _u32]),
+    "nv_build_cull_data": (_i, [_vp, _vp, _vp, _f, _f, _f, _u32, _u32, _u32, _u32, _u32, _i]),
+    "nv_assign_visibility_offsets": (_i, [_vp, _u32, _vp, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
+    "nv_synth_draws": (_i, [_vp, _u32, _u32, _f]),
+    "nv_shard_range": (None, [C.c_uint64, _u32, _u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "nv_pack_counts": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "nv_probe_cluster_scalars": (_i, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, C.POINTER(PyramidDesc), _vp]),
+}
+EXPORTS = sorted(_SIGS)
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header/library mismatch, fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(rc, what):
+    if rc != 0:
+        names = {-1: "NV_EINVAL", -2: "NV_ENOMEM", -3: "NV_ESTATE", -4: "NV_ENODEV"}
+        raise NvError("%s failed: %s" % (what, names.get(rc, "hipError %d" % rc)))

@@ -1,0 +1,390 @@
+// context.hip — the extern "C" boundary declared in include/niagara_vis.h: context lifetime, argument packing and
+// kernel launches.  No torch types, no exceptions across the ABI; every entry point only enqueues on the caller's
+// stream (nv_status and scratch growth are the only synchronising calls).
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/niagara_vis.h"
+#include "cullmath.cuh"
+#include "ordered.cuh"
+#include "args.cuh"
+
+namespace nv
+{
+
+int launch_clustercull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t gridBlocks);
+int launch_taskcull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t gridBlocks);
+int launch_probe(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
+int launch_soa_split(hipStream_t, const NvMeshlet*, uint32_t count, uint32_t padded, uint2* bounds, uint32_t* cones);
+uint32_t clustercull_tile_commands();
+int launch_drawcull(hipStream_t, const DrawArgs&, int late, int task, uint32_t gridBlocks);
+uint32_t drawcull_tile_draws();
+int launch_tasksubmit(hipStream_t, uint32_t* count4, NvMeshTaskCommand* commands);
+int launch_clustersubmit(hipStream_t, uint32_t* cc4, uint32_t* clusterIndices);
+int launch_pack_counts(hipStream_t, const uint32_t*, const uint32_t*, const uint32_t*, uint64_t*);
+int launch_depthreduce(hipStream_t, const float* depth, uint32_t w, uint32_t h, const NvPyramidDesc& pyr);
+
+} // namespace nv
+
+struct nv_context
+{
+	int device;
+	int numCUs;
+	nv::OrderCtl* ctl;
+	uint64_t* state;
+	uint32_t stateCapacity;
+	// SoA mirror of the meshlet cull bytes
+	const NvMeshlet* mirroredFrom;
+	uint32_t mirroredCount;
+	uint2* soaBounds;
+	uint32_t* soaCones;
+	uint32_t soaCapacity;
+};
+
+namespace
+{
+
+struct DeviceGuard
+{
+	int prev;
+	bool switched;
+	explicit DeviceGuard(int dev) : prev(-1), switched(false)
+	{
+		if (hipGetDevice(&prev) == hipSuccess && prev != dev)
+			switched = hipSetDevice(dev) == hipSuccess;
+	}
+	~DeviceGuard()
+	{
+		if (switched)
+			(void)hipSetDevice(prev);
+	}
+};
+
+uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+NvPyramidDesc null_pyramid()
+{
+	NvPyramidDesc p;
+	memset(&p, 0, sizeof(p));
+	return p;
+}
+
+int ensure_state(nv_context* ctx, uint32_t tiles)
+{
+	if (tiles <= ctx->stateCapacity)
+		return NV_OK;
+	// growth is rare (only for > 2^28 draws); it synchronises the device
+	hipError_t e = hipDeviceSynchronize();
+	if (e != hipSuccess)
+		return (int)e;
+	if (ctx->state)
+		(void)hipFree(ctx->state);
+	ctx->state = nullptr;
+	ctx->stateCapacity = 0;
+	e = hipMalloc(&ctx->state, (size_t)tiles * sizeof(uint64_t));
+	if (e != hipSuccess)
+		return NV_ENOMEM;
+	e = hipMemset(ctx->state, 0, (size_t)tiles * sizeof(uint64_t));
+	if (e != hipSuccess)
+		return (int)e;
+	ctx->stateCapacity = tiles;
+	return NV_OK;
+}
+
+uint32_t persistent_grid(const nv_context* ctx, uint32_t blocksPerCU, uint32_t tilesKnown)
+{
+	uint32_t grid = (uint32_t)ctx->numCUs * blocksPerCU;
+	if (tilesKnown && tilesKnown < grid)
+		grid = tilesKnown;
+	// every ticket shard needs at least one workgroup (ordered.cuh)
+	return round_up(grid < NV_SHARDS ? NV_SHARDS : grid, NV_SHARDS);
+}
+
+} // namespace
+
+extern "C" {
+
+const char* nv_version(void) { return "niagara_vis 0.1 (gfx950)"; }
+
+int nv_create(nv_context** out_ctx, int device)
+{
+	if (!out_ctx)
+		return NV_EINVAL;
+	*out_ctx = nullptr;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+		return NV_ENODEV;
+	if (device < 0 || device >= count)
+		return NV_EINVAL;
+	DeviceGuard guard(device);
+
+	nv_context* ctx = new (std::nothrow) nv_context();
+	if (!ctx)
+		return NV_ENOMEM;
+	memset(ctx, 0, sizeof(*ctx));
+	ctx->device = device;
+
+	hipDeviceProp_t prop;
+	hipError_t e = hipGetDeviceProperties(&prop, device);
+	if (e != hipSuccess)
+	{
+		delete ctx;
+		return (int)e;
+	}
+	ctx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+	e = hipMalloc(&ctx->ctl, sizeof(nv::OrderCtl));
+	if (e == hipSuccess)
+	{
+		nv::OrderCtl init;
+		memset(&init, 0, sizeof(init));
+		init.epoch = 1;
+		e = hipMemcpy(ctx->ctl, &init, sizeof(init), hipMemcpyHostToDevice);
+	}
+	if (e != hipSuccess)
+	{
+		nv_destroy(ctx);
+		return e == hipErrorOutOfMemory ? NV_ENOMEM : (int)e;
+	}
+
+	// enough tiles for NV_TASK_WGLIMIT commands and for 2^28 draws
+	uint32_t tiles = NV_TASK_WGLIMIT / nv::clustercull_tile_commands() + 1;
+	int rc = ensure_state(ctx, tiles < (1u << 18) ? (1u << 18) : tiles);
+	if (rc != NV_OK)
+	{
+		nv_destroy(ctx);
+		return rc;
+	}
+
+	*out_ctx = ctx;
+	return NV_OK;
+}
+
+void nv_destroy(nv_context* ctx)
+{
+	if (!ctx)
+		return;
+	DeviceGuard guard(ctx->device);
+	if (ctx->ctl)
+		(void)hipFree(ctx->ctl);
+	if (ctx->state)
+		(void)hipFree(ctx->state);
+	if (ctx->soaBounds)
+		(void)hipFree(ctx->soaBounds);
+	if (ctx->soaCones)
+		(void)hipFree(ctx->soaCones);
+	delete ctx;
+}
+
+int nv_status(nv_context* ctx, void* stream)
+{
+	if (!ctx)
+		return NV_EINVAL;
+	DeviceGuard guard(ctx->device);
+	hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+	if (e != hipSuccess)
+		return (int)e;
+	uint32_t err = 0;
+	e = hipMemcpy(&err, &ctx->ctl->error, sizeof(err), hipMemcpyDeviceToHost);
+	if (e != hipSuccess)
+		return (int)e;
+	if (err)
+	{
+		// a timed-out chain leaves tickets/epoch in an undefined state: re-arm everything
+		nv::OrderCtl init;
+		memset(&init, 0, sizeof(init));
+		init.epoch = 1;
+		(void)hipMemcpy(ctx->ctl, &init, sizeof(init), hipMemcpyHostToDevice);
+		(void)hipMemset(ctx->state, 0, (size_t)ctx->stateCapacity * sizeof(uint64_t));
+		return NV_ESTATE;
+	}
+	return NV_OK;
+}
+
+int nv_upload_meshlets(nv_context* ctx, void* stream, const NvMeshlet* d_meshlets, uint32_t meshletCount)
+{
+	if (!ctx || (!d_meshlets && meshletCount))
+		return NV_EINVAL;
+	DeviceGuard guard(ctx->device);
+	// one extra 64-entry block so that a command's 64-lane window never leaves the mirror
+	uint32_t padded = round_up(meshletCount, 64) + 64;
+	if (padded > ctx->soaCapacity)
+	{
+		hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+		if (e != hipSuccess)
+			return (int)e;
+		if (ctx->soaBounds)
+			(void)hipFree(ctx->soaBounds);
+		if (ctx->soaCones)
+			(void)hipFree(ctx->soaCones);
+		ctx->soaBounds = nullptr;
+		ctx->soaCones = nullptr;
+		ctx->soaCapacity = 0;
+		ctx->mirroredFrom = nullptr;
+		if (hipMalloc(&ctx->soaBounds, (size_t)padded * sizeof(uint2)) != hipSuccess ||
+		    hipMalloc(&ctx->soaCones, (size_t)padded * sizeof(uint32_t)) != hipSuccess)
+			return NV_ENOMEM;
+		ctx->soaCapacity = padded;
+	}
+	int rc = nv::launch_soa_split((hipStream_t)stream, d_meshlets, meshletCount, padded, ctx->soaBounds, ctx->soaCones);
+	if (rc)
+		return rc;
+	ctx->mirroredFrom = d_meshlets;
+	ctx->mirroredCount = meshletCount;
+	return NV_OK;
+}
+
+int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late, int task, const NvMeshDraw* d_draws,
+                const NvMesh* d_meshes, void* d_commands, uint32_t* d_count4, uint32_t* d_drawVisibility,
+                const NvPyramidDesc* pyramid)
+{
+	if (!ctx || !cull || !d_count4 || !d_drawVisibility || (cull->drawCount && (!d_draws || !d_meshes || !d_commands)))
+		return NV_EINVAL;
+	if (late && cull->occlusionEnabled == 1 && !(pyramid && pyramid->d_base))
+		return NV_EINVAL;
+	DeviceGuard guard(ctx->device);
+
+	const uint32_t tiles = (cull->drawCount + nv::drawcull_tile_draws() - 1) / nv::drawcull_tile_draws();
+	int rc = ensure_state(ctx, tiles);
+	if (rc)
+		return rc;
+
+	nv::DrawArgs a;
+	a.cd = *cull;
+	a.pyr = pyramid ? *pyramid : null_pyramid();
+	a.draws = d_draws;
+	a.meshes = d_meshes;
+	a.commands = d_commands;
+	a.count4 = d_count4;
+	a.dvb = d_drawVisibility;
+	a.state = ctx->state;
+	a.ctl = ctx->ctl;
+	a.stateCapacity = ctx->stateCapacity;
+	return nv::launch_drawcull((hipStream_t)stream, a, late, task, persistent_grid(ctx, 3, tiles ? tiles : 1));
+}
+
+int nv_tasksubmit(nv_context* ctx, void* stream, uint32_t* d_count4, NvMeshTaskCommand* d_commands)
+{
+	if (!ctx || !d_count4 || !d_commands)
+		return NV_EINVAL;
+	DeviceGuard guard(ctx->device);
+	return nv::launch_tasksubmit((hipStream_t)stream, d_count4, d_commands);
+}
+
+static int fill_cluster_args(nv_context* ctx, nv::ClusterArgs& a, const NvCullData* cull, int late,
+                             const NvMeshTaskCommand* d_commands, const uint32_t* d_count4, const NvMeshDraw* d_draws,
+                             const NvMeshlet* d_meshlets, uint32_t* d_meshletVisibility, const NvPyramidDesc* pyramid)
+{
+	if (!ctx || !cull || !d_commands || !d_draws || !d_meshlets)
+		return NV_EINVAL;
+	if (cull->clusterOcclusionEnabled == 1 && !d_meshletVisibility)
+		return NV_EINVAL;
+	if (late && cull->clusterOcclusionEnabled == 1 && !(pyramid && pyramid->d_base))
+		return NV_EINVAL;
+	memset(&a, 0, sizeof(a));
+	a.cd = *cull;
+	a.pyr = pyramid ? *pyramid : null_pyramid();
+	a.commands = d_commands;
+	a.count4 = d_count4;
+	a.draws = d_draws;
+	a.meshlets = d_meshlets;
+	const bool soa = ctx->mirroredFrom == d_meshlets && ctx->soaBounds;
+	a.soaBounds = soa ? ctx->soaBounds : nullptr;
+	a.soaCones = soa ? ctx->soaCones : nullptr;
+	a.mvb = d_meshletVisibility;
+	a.state = ctx->state;
+	a.ctl = ctx->ctl;
+	a.stateCapacity = ctx->stateCapacity;
+	return NV_OK;
+}
+
+int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int late, const NvMeshTaskCommand* d_commands,
+                   const uint32_t* d_count4, const NvMeshDraw* d_draws, const NvMeshlet* d_meshlets,
+                   uint32_t* d_meshletVisibility, const NvPyramidDesc* pyramid, uint32_t* d_clusterIndices,
+                   uint32_t* d_clusterCount4)
+{
+	if (!d_count4 || !d_clusterIndices || !d_clusterCount4)
+		return NV_EINVAL;
+	nv::ClusterArgs a;
+	int rc = fill_cluster_args(ctx, a, cull, late, d_commands, d_count4, d_draws, d_meshlets, d_meshletVisibility, pyramid);
+	if (rc)
+		return rc;
+	DeviceGuard guard(ctx->device);
+	a.clusterIndices = d_clusterIndices;
+	a.clusterCount4 = d_clusterCount4;
+	return nv::launch_clustercull((hipStream_t)stream, a, late, a.soaBounds != nullptr, persistent_grid(ctx, 8, 0));
+}
+
+int nv_clustersubmit(nv_context* ctx, void* stream, uint32_t* d_clusterCount4, uint32_t* d_clusterIndices)
+{
+	if (!ctx || !d_clusterCount4 || !d_clusterIndices)
+		return NV_EINVAL;
+	DeviceGuard guard(ctx->device);
+	return nv::launch_clustersubmit((hipStream_t)stream, d_clusterCount4, d_clusterIndices);
+}
+
+int nv_taskcull(nv_context* ctx, void* stream, const NvCullData* cull, int late, const NvMeshTaskCommand* d_commands,
+                const uint32_t* d_count4, const NvMeshDraw* d_draws, const NvMeshlet* d_meshlets,
+                uint32_t* d_meshletVisibility, const NvPyramidDesc* pyramid, uint32_t* d_payloads, uint32_t* d_payloadCounts)
+{
+	if (!d_count4 || !d_payloads || !d_payloadCounts)
+		return NV_EINVAL;
+	nv::ClusterArgs a;
+	int rc = fill_cluster_args(ctx, a, cull, late, d_commands, d_count4, d_draws, d_meshlets, d_meshletVisibility, pyramid);
+	if (rc)
+		return rc;
+	DeviceGuard guard(ctx->device);
+	a.clusterIndices = d_payloads;
+	a.payloadCounts = d_payloadCounts;
+	return nv::launch_taskcull((hipStream_t)stream, a, late, a.soaBounds != nullptr, (uint32_t)ctx->numCUs * 8);
+}
+
+int nv_depthreduce(nv_context* ctx, void* stream, const float* d_depth, uint32_t width, uint32_t height,
+                   const NvPyramidDesc* pyramid)
+{
+	if (!ctx || !d_depth || !pyramid || !pyramid->d_base || !width || !height || !pyramid->levels || pyramid->levels > NV_MAX_MIPS)
+		return NV_EINVAL;
+	DeviceGuard guard(ctx->device);
+	return nv::launch_depthreduce((hipStream_t)stream, d_depth, width, height, *pyramid);
+}
+
+int nv_pack_counts(nv_context* ctx, void* stream, const uint32_t* d_countA, const uint32_t* d_countB,
+                   const uint32_t* d_countC, uint64_t* d_out3)
+{
+	if (!ctx || !d_out3)
+		return NV_EINVAL;
+	DeviceGuard guard(ctx->device);
+	return nv::launch_pack_counts((hipStream_t)stream, d_countA, d_countB, d_countC, d_out3);
+}
+
+int nv_probe_cluster_scalars(nv_context* ctx, void* stream, const NvCullData* cull, const NvMeshTaskCommand* d_commands,
+                             uint32_t commandCount, const NvMeshDraw* d_draws, const NvMeshlet* d_meshlets,
+                             const NvPyramidDesc* pyramid, float* d_out16)
+{
+	if (!d_out16 || !commandCount)
+		return NV_EINVAL;
+	nv::ClusterArgs a;
+	int rc = fill_cluster_args(ctx, a, cull, 0, d_commands, nullptr, d_draws, d_meshlets, nullptr, pyramid);
+	if (rc == NV_EINVAL && cull && cull->clusterOcclusionEnabled == 1)
+	{
+		// the probe never touches visibility bits
+		NvCullData c2 = *cull;
+		c2.clusterOcclusionEnabled = 0;
+		rc = fill_cluster_args(ctx, a, &c2, 0, d_commands, nullptr, d_draws, d_meshlets, nullptr, pyramid);
+		if (rc == NV_OK)
+			a.cd = *cull;
+	}
+	if (rc)
+		return rc;
+	DeviceGuard guard(ctx->device);
+	a.commandCountOverride = commandCount;
+	a.probeOut = d_out16;
+	uint32_t blocks = (commandCount + 3) / 4;
+	uint32_t cap = (uint32_t)ctx->numCUs * 8;
+	return nv::launch_probe((hipStream_t)stream, a, a.soaBounds != nullptr, blocks < cap ? blocks : cap);
+}
+
+} // extern "C"

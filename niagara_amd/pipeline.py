@@ -1,0 +1,162 @@
+"""Host-side mirror of niagara's cull/render/pyramid lambdas (src/niagara.cpp:1530-1611,1703-1733,1765-1788)
+driving the HIP passes through the C ABI.  torch is plumbing only: device memory, streams, torch.distributed.
+
+Buffer names follow the reference (src/niagara.cpp:1027-1093):
+    mb meshes · mlb meshlets · db draws · dvb drawVisibility · dcb draw/task commands · dccb command count + indirect
+    args · mvb meshletVisibility · cib clusterIndices · ccb cluster count + indirect args
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import host
+from . import layouts as L
+from ._lib import NvError, PyramidDesc, check, lib
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_device(arr, device):
+    """numpy (structured) array -> flat uint8 device tensor with the same bytes"""
+    a = np.ascontiguousarray(arr)
+    return torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(device)
+
+
+def from_device(t, dtype, count=None):
+    a = t.detach().cpu().numpy().view(np.uint8).reshape(-1)
+    out = a.view(dtype)
+    return out[:count] if count is not None else out
+
+
+class Context:
+    """one nv_context per device; not re-entrant (one stream at a time)"""
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise NvError("niagara_amd needs a HIP device: torch.cuda.is_available() is False and there is no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        h = C.c_void_p()
+        check(lib.nv_create(C.byref(h), self.device.index), "nv_create")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.nv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def status(self):
+        check(lib.nv_status(self.h, _stream()), "nv_status")
+
+    # ---- passes (argument order = descriptor order of the reference dispatches)
+    def upload_meshlets(self, mlb, count):
+        check(lib.nv_upload_meshlets(self.h, _stream(), _ptr(mlb), count), "nv_upload_meshlets")
+
+    def drawcull(self, cull, late, task, db, mb, dcb, dccb, dvb, pyramid=None):
+        check(lib.nv_drawcull(self.h, _stream(), C.c_void_p(cull.ctypes.data), int(late), int(task), _ptr(db), _ptr(mb), _ptr(dcb),
+                              _ptr(dccb), _ptr(dvb), None if pyramid is None else C.byref(pyramid)), "nv_drawcull")
+
+    def tasksubmit(self, dccb, dcb):
+        check(lib.nv_tasksubmit(self.h, _stream(), _ptr(dccb), _ptr(dcb)), "nv_tasksubmit")
+
+    def clustercull(self, cull, late, dcb, dccb, db, mlb, mvb, pyramid, cib, ccb):
+        check(lib.nv_clustercull(self.h, _stream(), C.c_void_p(cull.ctypes.data), int(late), _ptr(dcb), _ptr(dccb), _ptr(db), _ptr(mlb),
+                                 _ptr(mvb), None if pyramid is None else C.byref(pyramid), _ptr(cib), _ptr(ccb)), "nv_clustercull")
+
+    def clustersubmit(self, ccb, cib):
+        check(lib.nv_clustersubmit(self.h, _stream(), _ptr(ccb), _ptr(cib)), "nv_clustersubmit")
+
+    def taskcull(self, cull, late, dcb, dccb, db, mlb, mvb, pyramid, payloads, payload_counts):
+        check(lib.nv_taskcull(self.h, _stream(), C.c_void_p(cull.ctypes.data), int(late), _ptr(dcb), _ptr(dccb), _ptr(db), _ptr(mlb),
+                              _ptr(mvb), None if pyramid is None else C.byref(pyramid), _ptr(payloads), _ptr(payload_counts)), "nv_taskcull")
+
+    def depthreduce(self, depth, width, height, pyramid):
+        check(lib.nv_depthreduce(self.h, _stream(), _ptr(depth), width, height, C.byref(pyramid)), "nv_depthreduce")
+
+    def pack_counts(self, a, b, c, out3):
+        check(lib.nv_pack_counts(self.h, _stream(), _ptr(a), _ptr(b), _ptr(c), _ptr(out3)), "nv_pack_counts")
+
+    def probe_cluster_scalars(self, cull, dcb, command_count, db, mlb, pyramid=None):
+        out = torch.zeros((command_count, 64, 16), dtype=torch.float32, device=self.device)
+        check(lib.nv_probe_cluster_scalars(self.h, _stream(), C.c_void_p(cull.ctypes.data), _ptr(dcb), command_count, _ptr(db), _ptr(mlb),
+                                           None if pyramid is None else C.byref(pyramid), _ptr(out)), "nv_probe_cluster_scalars")
+        return out
+
+
+class DepthPyramid:
+    """replaces the R32F mip-chain image + MIN sampler (src/niagara.cpp:629,1339-1350)"""
+
+    def __init__(self, device, depth_w, depth_h):
+        self.desc = host.pyramid_desc(depth_w, depth_h)
+        self.data = torch.zeros(self.desc.totalTexels, dtype=torch.float32, device=device)
+        self.desc.d_base = self.data.data_ptr()
+        self.width, self.height, self.levels = self.desc.width, self.desc.height, self.desc.levels
+        self.mip_offset = [int(x) for x in self.desc.mipOffset]
+
+    def level(self, i):
+        w, h = max(1, self.width >> i), max(1, self.height >> i)
+        return self.data[self.mip_offset[i]:self.mip_offset[i] + w * h].view(h, w)
+
+
+class VisibilityPipeline:
+    """niagara's GPU-driven visibility front-end for one scene on one device."""
+
+    def __init__(self, meshes, meshlets, draws, depth_size, ctx=None, task_capacity=None, cluster_capacity=None, use_soa=True):
+        self.ctx = ctx or Context()
+        dev = self.ctx.device
+        self.mesh_count, self.meshlet_count, self.draw_count = len(meshes), len(meshlets), len(draws)
+        self.draws_host = draws.copy()
+        self.slots, self.post_mask = host.assign_visibility_offsets(self.draws_host, meshes)  # src/niagara.cpp:1002-1020
+        self.mb = to_device(meshes, dev)
+        self.mlb = to_device(meshlets, dev)
+        self.db = to_device(self.draws_host, dev)
+        self.dvb = torch.zeros(max(1, self.draw_count), dtype=torch.int32, device=dev)         # zeroed once (:1450-1457)
+        self.mvb = torch.zeros(max(1, (self.slots + 31) // 32 + 2), dtype=torch.int32, device=dev)  # (:1459-1468)
+        tcap = task_capacity or L.TASK_WGLIMIT
+        ccap = cluster_capacity or L.CLUSTER_LIMIT
+        self.dcb = torch.zeros(tcap * L.TASKCMD.itemsize + 64 * L.TASKCMD.itemsize, dtype=torch.uint8, device=dev)
+        self.dccb = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.cib = torch.zeros(ccap + 256, dtype=torch.int32, device=dev)
+        self.ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.depth_w, self.depth_h = depth_size
+        self.pyramid = DepthPyramid(dev, *depth_size)
+        if use_soa and self.meshlet_count:
+            self.ctx.upload_meshlets(self.mlb, self.meshlet_count)
+
+    # src/niagara.cpp:1530-1574
+    def cull(self, cull_data, late, task=True, post_pass=0):
+        self.dccb[0:1].zero_()                                      # vkCmdFillBuffer(dccb, 0, 4, 0)  (:1541)
+        pass_data = cull_data.copy()
+        pass_data["clusterBackfaceEnabled"] = 1 if post_pass == 0 else 0   # (:1549)
+        pass_data["postPass"] = post_pass
+        self.ctx.drawcull(pass_data, late, task, self.db, self.mb, self.dcb, self.dccb, self.dvb, self.pyramid.desc)
+        if task:
+            self.ctx.tasksubmit(self.dccb, self.dcb)                # (:1563-1568)
+
+    # src/niagara.cpp:1582-1611 (cluster branch of render())
+    def render_clusters(self, cull_data, late, post_pass=0):
+        self.ccb[0:1].zero_()                                       # vkCmdFillBuffer(ccb, 0, 4, 0)  (:1586)
+        pass_data = cull_data.copy()
+        pass_data["postPass"] = post_pass                           # (:1595-1596)
+        self.ctx.clustercull(pass_data, late, self.dcb, self.dccb, self.db, self.mlb, self.mvb, self.pyramid.desc, self.cib, self.ccb)
+        self.ctx.clustersubmit(self.ccb, self.cib)
+
+    # src/niagara.cpp:1703-1733
+    def build_pyramid(self, depth):
+        self.ctx.depthreduce(depth, self.depth_w, self.depth_h, self.pyramid.desc)
+
+    def visible_clusters(self):
+        n = int(self.ccb[0].item())
+        return self.cib[:min(n, L.CLUSTER_LIMIT)].cpu().numpy().view(np.uint32), n

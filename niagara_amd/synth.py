@@ -1,0 +1,90 @@
+"""Synthetic scenes of the BASELINE.json configs (numpy, host side).
+
+The reference generates its stress scene in main() (src/niagara.cpp:969-998); meshlet bounds come from meshoptimizer
+there (src/scene.cpp:69-85), which is not vendored, so meshlet pools are drawn from a seeded generator with the
+distributions SURVEY.md §8(d) fixes.
+"""
+import numpy as np
+
+from . import host
+from . import layouts as L
+
+
+def make_meshlets(count, seed=2):
+    """centre ~U[-1,1]^3 and radius ~U[0.02,0.1] as fp16; cone axis = random unit vector -> round(127 x) s8;
+    cutoff ~U{0..127}"""
+    rng = np.random.default_rng(seed)
+    m = np.zeros(count, dtype=L.MESHLET)
+    m["center"] = rng.uniform(-1, 1, (count, 3)).astype(np.float16).view(np.uint16)
+    m["radius"] = rng.uniform(0.02, 0.1, count).astype(np.float16).view(np.uint16)
+    axis = rng.normal(size=(count, 3))
+    axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    m["cone_axis"] = np.rint(axis * 127).astype(np.int8)
+    m["cone_cutoff"] = rng.integers(0, 128, count).astype(np.int8)
+    m["vertexCount"] = 64
+    m["triangleCount"] = 96
+    return m
+
+
+def make_meshes(mesh_count, lod_count, meshlets_lod0, center=(0.0, 0.0, 0.0), radius=1.8, seed=3):
+    """meshes with `lod_count` LODs; LOD i has ceil(meshlets_lod0 / 2^i) meshlets, error 0.002*2^i (error 0 for LOD 0),
+    indexCount 86832>>i.  Returns (meshes, total_meshlets); meshlet ranges are packed back to back."""
+    rng = np.random.default_rng(seed)
+    meshes = np.zeros(mesh_count, dtype=L.MESH)
+    offset = 0
+    index_offset = 0
+    for i in range(mesh_count):
+        meshes[i]["center"] = np.asarray(center, np.float32) + rng.uniform(-0.05, 0.05, 3).astype(np.float32) * (mesh_count > 1)
+        meshes[i]["radius"] = radius
+        meshes[i]["vertexOffset"] = i * 1000
+        meshes[i]["vertexCount"] = 1000
+        meshes[i]["lodCount"] = lod_count
+        for l in range(lod_count):
+            mc = max(1, -(-meshlets_lod0 // (1 << l))) if meshlets_lod0 else 0
+            lod = meshes[i]["lods"][l]
+            lod["indexOffset"] = index_offset
+            lod["indexCount"] = 86832 >> l
+            lod["meshletOffset"] = offset
+            lod["meshletCount"] = mc
+            lod["error"] = 0.0 if l == 0 else 0.002 * (1 << l)
+            offset += mc
+            index_offset += 86832 >> l
+    return meshes, offset
+
+
+def make_task_commands(draw_count, commands_per_draw, late_draw_visibility=None):
+    """config 3A: full commands (taskCount 64), command k covers meshlets [64k, 64k+64) and visibility slots alike"""
+    n = draw_count * commands_per_draw
+    c = np.zeros(n, dtype=L.TASKCMD)
+    k = np.arange(n, dtype=np.uint32)
+    c["drawId"] = k // commands_per_draw
+    c["taskOffset"] = k * 64
+    c["taskCount"] = 64
+    c["meshletVisibilityOffset"] = k * 64
+    if late_draw_visibility is not None:
+        c["lateDrawVisibility"] = late_draw_visibility[c["drawId"]]
+    return c
+
+
+def make_depth(width, height, znear=0.1, rects=64, seed=4):
+    """reverse-Z depth target: background 0 (far), `rects` axis-aligned rectangles with depth = znear / z, z~U[5,100]"""
+    rng = np.random.default_rng(seed)
+    depth = np.zeros((height, width), dtype=np.float32)
+    for _ in range(rects):
+        w = int(rng.integers(max(2, width // 64), max(3, width // 4)))
+        h = int(rng.integers(max(2, height // 64), max(3, height // 4)))
+        x = int(rng.integers(0, max(1, width - w)))
+        y = int(rng.integers(0, max(1, height - h)))
+        z = np.float32(rng.uniform(5, 100))
+        depth[y:y + h, x:x + w] = np.maximum(depth[y:y + h, x:x + w], np.float32(znear) / z)
+    return depth
+
+
+def cluster_scene(draw_count, commands_per_draw=10, seed=2, scene_radius=300.0):
+    """config 3A / 5 inputs: draws (niagara generator), meshlet pool, full task commands"""
+    draws = host.synth_draws(draw_count, 1, scene_radius)
+    n_cmd = draw_count * commands_per_draw
+    meshlets = make_meshlets(n_cmd * 64, seed)
+    draws["meshletVisibilityOffset"] = np.arange(draw_count, dtype=np.uint32) * (commands_per_draw * 64)
+    commands = make_task_commands(draw_count, commands_per_draw)
+    return draws, meshlets, commands

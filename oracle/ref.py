@@ -1,0 +1,81 @@
+"""oracle.ref — ctypes binding over oracle/_ref/libniagara_ref.so: the reference's own shader sources
+(translated syntactically by oracle/ref_translate.py) executing on the CPU.  TEST INFRASTRUCTURE ONLY.
+
+The library is built by `make -C oracle ref` where /root/reference exists; the prebuilt .so travels to the
+GPU box with the snapshot.  available() is False when neither is possible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libniagara_ref.so")
+_lib = None
+
+
+def available():
+    return os.path.exists(_SO)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(_SO)
+        _lib.ref_occlusion_mip.restype = C.c_float
+        _lib.ref_sizeof.restype = C.c_uint32
+        _lib.ref_previous_pow2.restype = C.c_uint32
+        _lib.ref_image_mip_levels.restype = C.c_uint32
+        _lib.ref_rand32.restype = C.c_uint32
+        _lib.ref_rand01.restype = C.c_double
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _pyr(p):
+    return None if p is None else p.ref()  # same struct layout as oracle.Pyramid
+
+
+def drawcull(cd, late, task, draws, meshes, commands, count4, dvb, pyr=None):
+    lib().ref_drawcull(_p(cd), int(late), int(task), _p(draws), _p(meshes), _p(commands), _p(count4), _p(dvb), _pyr(pyr))
+
+
+def tasksubmit(count4, commands):
+    lib().ref_tasksubmit(_p(count4), _p(commands))
+
+
+def clustercull(cd, late, commands, count4, draws, meshlets, mvb, pyr, cib, cc4):
+    lib().ref_clustercull(_p(cd), int(late), _p(commands), _p(count4), _p(draws), _p(meshlets), _p(mvb), _pyr(pyr), _p(cib), _p(cc4))
+
+
+def clustersubmit(cc4, cib):
+    lib().ref_clustersubmit(_p(cc4), _p(cib))
+
+
+def depthreduce(depth, pyr):
+    h, w = depth.shape
+    offs = (C.c_uint32 * 16)(*pyr.mip_offset)
+    lib().ref_depthreduce(_p(depth), C.c_uint32(w), C.c_uint32(h), _p(pyr.data), C.c_uint32(pyr.width), C.c_uint32(pyr.height),
+                          C.c_uint32(pyr.levels), offs)
+
+
+def rotate_quat(v, q):
+    out = np.zeros(3, np.float32)
+    lib().ref_rotate_quat(_p(np.asarray(v, np.float32)), _p(np.asarray(q, np.float32)), _p(out))
+    return out
+
+
+def project_sphere(c, r, znear, p00, p11):
+    aabb = np.zeros(4, np.float32)
+    ok = lib().ref_project_sphere(_p(np.asarray(c, np.float32)), C.c_float(r), C.c_float(znear), C.c_float(p00), C.c_float(p11), _p(aabb))
+    return bool(ok), aabb
+
+
+def occlusion_mip(aabb, pw, ph):
+    return float(lib().ref_occlusion_mip(_p(np.asarray(aabb, np.float32)), C.c_float(pw), C.c_float(ph)))
+
+
+def cone_cull(c, r, axis, cutoff):
+    return bool(lib().ref_cone_cull(_p(np.asarray(c, np.float32)), C.c_float(r), _p(np.asarray(axis, np.float32)), C.c_float(cutoff)))

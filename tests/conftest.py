@@ -1,0 +1,26 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+    # test infrastructure: the CPU oracle (and oracle/_ref where the reference tree exists)
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(so) or os.path.isdir("/root/reference/src/shaders"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    lib = os.path.join(ROOT, "niagara_amd", "libniagara_vis.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "niagara_amd", "csrc")])
+
+
+@pytest.fixture(scope="session")
+def has_gpu():
+    import torch
+    return torch.cuda.is_available()

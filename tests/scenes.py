@@ -1,0 +1,58 @@
+"""Small seeded scenes for the parity tests (test infrastructure)."""
+import numpy as np
+
+from niagara_amd import host, synth
+from niagara_amd import layouts as L
+
+
+def random_quat(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    return q.astype(np.float32)
+
+
+def make_scene(seed=0, n_draws=300, n_meshes=3, lods=4, meshlets_lod0=150, scene_radius=25.0, viewport=(256, 192),
+               random_camera=True, post_pass_fraction=0.0, zero_radius_fraction=0.0):
+    """draws scattered in a cube around a camera; enough of them visible to exercise every branch"""
+    rng = np.random.default_rng(seed)
+    meshes, total = synth.make_meshes(n_meshes, lods, meshlets_lod0, seed=seed + 11)
+    meshlets = synth.make_meshlets(total, seed=seed + 12)
+    if zero_radius_fraction:
+        z = rng.random(total) < zero_radius_fraction
+        meshlets["radius"][z] = 0
+    draws = host.synth_draws(n_draws, n_meshes, scene_radius)
+    if post_pass_fraction:
+        draws["postPass"] = (rng.random(n_draws) < post_pass_fraction).astype(np.uint32)
+    slots, mask = host.assign_visibility_offsets(draws, meshes)
+    cam_pos = rng.uniform(-3, 3, 3).astype(np.float32) if random_camera else np.zeros(3, np.float32)
+    cam_q = random_quat(rng) if random_camera else np.array([0, 0, 0, 1], np.float32)
+    pw, ph = host.previous_pow2(viewport[0]), host.previous_pow2(viewport[1])
+    cd = host.build_cull_data(cam_pos, cam_q, draw_distance=60.0, viewport=viewport, pyramid=(pw, ph), draw_count=n_draws,
+                              cullingEnabled=1, lodEnabled=1)
+    # occluders that matter at this scale: big rectangles at z in [3, 30] (reverse-Z: depth = znear / z, far = 0)
+    depth = np.zeros((viewport[1], viewport[0]), np.float32)
+    for _ in range(10):
+        w = int(rng.integers(viewport[0] // 6, viewport[0] // 2))
+        h = int(rng.integers(viewport[1] // 6, viewport[1] // 2))
+        x, y = int(rng.integers(0, viewport[0] - w)), int(rng.integers(0, viewport[1] - h))
+        depth[y:y + h, x:x + w] = np.maximum(depth[y:y + h, x:x + w], np.float32(0.1) / np.float32(rng.uniform(3, 30)))
+    return dict(meshes=meshes, meshlets=meshlets, draws=draws, slots=slots, post_mask=mask, cull=cd, depth=depth, viewport=viewport)
+
+
+def task_capacity(scene):
+    """upper bound on task commands any pass can emit for this scene (+64 for the tasksubmit padding)"""
+    meshes, draws = scene["meshes"], scene["draws"]
+    per_mesh = np.array([max((int(m["lods"][l]["meshletCount"]) + 63) // 64 for l in range(int(m["lodCount"]))) for m in meshes])
+    return int(per_mesh[draws["meshIndex"]].sum()) + 64
+
+
+def flag_matrix():
+    """(cullingEnabled, lodEnabled, occlusionEnabled, clusterOcclusionEnabled, clusterBackfaceEnabled)"""
+    out = []
+    for ce in (0, 1):
+        for le in (0, 1):
+            for oe in (0, 1):
+                for coe in (0, 1):
+                    for cbe in (0, 1):
+                        out.append((ce, le, oe, coe, cbe))
+    return out
