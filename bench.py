@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py — meshlets culled+compacted per second (BASELINE.json metric) on N MI355X GPUs of one node.
+
+Workload (config.workload = "config3A"): BASELINE.json configs[2] — synthetic 10 M meshlets (bistro scale), i.e.
+156 250 full MeshTaskCommands over 15 625 draws, per-meshlet cone + frustum cull (`clustercull`, LATE = 0,
+clusterBackfaceEnabled = 1) with ordered compaction of the visible IDs.  One "step" = one pass of the hot path over
+one batch: reset of the count word (the caller's vkCmdFillBuffer, src/niagara.cpp:1586) + nv_clustercull, with
+inputs resident in HBM.  Steps rotate over `--copies` distinct input sets so that every pass streams from HBM rather
+than from the 256 MiB Infinity Cache.  N > 1: the pool shards by contiguous command ranges, every rank culls its own
+10 M meshlets (weak scaling) and the only collective is one all-reduce of the visible counts per step (RCCL).
+
+Prints ONE JSON line (rank 0):  metric/value/unit as in BASELINE.json + "roofline" (dominant kernel, HIP events on
+the launch stream) + "cpu_baseline" (the CPU oracle timed on this host's cores; a reported baseline, not a target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--draws", type=int, default=15625, help="draws per GPU (x commands-per-draw x 64 = meshlets)")
+    ap.add_argument("--commands-per-draw", type=int, default=10)
+    ap.add_argument("--copies", type=int, default=4, help="distinct input sets rotated through (cache-cold passes)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0)
+    ap.add_argument("--aos", action="store_true", help="read the 24-B AoS meshlets in place (no SoA mirror)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import niagara_amd  # raises if libniagara_vis.so is missing: there is no fallback
+    from niagara_amd import host, synth
+    from niagara_amd import layouts as L
+    from niagara_amd import pipeline as P
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- inputs: rank r owns commands [r*C, (r+1)*C) of a world*C command pool; weak scaling
+    n_draws, cpd = args.draws, args.commands_per_draw
+    n_cmd = n_draws * cpd
+    n_meshlets = n_cmd * 64
+    copies = max(1, args.copies)
+    draws = host.synth_draws(n_draws * world, 1, 300.0)[rank * n_draws:(rank + 1) * n_draws].copy()
+    draws["meshletVisibilityOffset"] = np.arange(n_draws, dtype=np.uint32) * (cpd * 64)
+    meshlets = synth.make_meshlets(n_meshlets, seed=2 + rank)
+    cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, clusterBackfaceEnabled=1)
+    count4 = synth.count4_for(n_cmd)
+
+    ctx = P.Context(local_rank)
+    db = P.to_device(draws, dev)
+    mlb = torch.empty(copies * n_meshlets * L.MESHLET.itemsize, dtype=torch.uint8, device=dev)
+    one = torch.from_numpy(meshlets.view(np.uint8).reshape(-1))
+    for c in range(copies):
+        mlb[c * one.numel():(c + 1) * one.numel()].copy_(one)
+    dcbs = [P.to_device(synth.make_task_commands(n_draws, cpd, meshlet_base=c * n_meshlets), dev) for c in range(copies)]
+    dccb = torch.from_numpy(count4.view(np.int32).copy()).to(dev)
+    cib = torch.zeros(min(n_meshlets, L.CLUSTER_LIMIT) + 256, dtype=torch.int32, device=dev)
+    ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+    counts = torch.zeros(3, dtype=torch.int64, device=dev)
+    if not args.aos:
+        ctx.upload_meshlets(mlb, copies * n_meshlets)
+    torch.cuda.synchronize()
+
+    def step(i, ev=None):
+        ccb[0:1].zero_()
+        if ev is not None:
+            ev[0].record()
+        ctx.clustercull(cd, 0, dcbs[i % copies], dccb, db, mlb, None, None, cib, ccb)
+        if ev is not None:
+            ev[1].record()
+        if world > 1:
+            ctx.pack_counts(None, dccb, ccb, counts)
+            dist.all_reduce(counts)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, events[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ctx.status()
+
+    visible = int(ccb[0].item())
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        total_visible = int(counts[2].item())
+    else:
+        total_visible = visible
+
+    kernel_ms = sorted(a.elapsed_time(b) for a, b in events)
+    kernel_avg_s = (sum(kernel_ms) / len(kernel_ms)) * 1e-3
+    kernel_med_s = kernel_ms[len(kernel_ms) // 2] * 1e-3
+
+    # algorithmic bytes per launch: 12 cull bytes per meshlet + (20 + 48) per command + 4 per survivor + 4
+    algo_bytes = n_meshlets * (24 if args.aos else 12) + n_cmd * 68 + visible * 4 + 4
+    achieved = algo_bytes / kernel_avg_s / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "meshlets culled+compacted /sec",
+            "value": n_meshlets * world * args.steps / elapsed,
+            "unit": "meshlets/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "config3A: %d meshlets/GPU, %d task commands over %d draws, cone+frustum clustercull (LATE=0) + ordered compaction"
+                                   % (n_meshlets, n_cmd, n_draws),
+                       "meshlets_per_gpu": n_meshlets, "commands_per_gpu": n_cmd, "draws_per_gpu": n_draws,
+                       "input_copies_rotated": copies, "meshlet_layout": "AoS24" if args.aos else "SoA12",
+                       "visible_per_gpu": visible, "visible_total": total_visible, "sharding": "commands x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "clustercull_kernel", "kernel_avg_us": kernel_avg_s * 1e6,
+                         "kernel_median_us": kernel_med_s * 1e6, "algorithmic_bytes": algo_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, cd, draws, meshlets, n_cmd, visible)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, cd, draws, meshlets, n_cmd, gpu_visible):
+    """the CPU oracle (oracle/ = test infrastructure; here ONLY as the timed baseline and as a checker) on this host"""
+    import oracle
+    from niagara_amd import synth
+    commands = synth.make_task_commands(len(draws), args.commands_per_draw)
+    c4 = synth.count4_for(n_cmd)
+    threads = oracle.max_threads()
+    cib = np.zeros(n_cmd * 64, np.uint32)
+    times = []
+    spent = 0.0
+    while spent < args.cpu_seconds or len(times) < 3:
+        cc4 = np.zeros(4, np.uint32)
+        t = time.perf_counter()
+        oracle.clustercull(cd, 0, commands, c4, draws, meshlets, None, None, cib, cc4, threads=threads)
+        dt = time.perf_counter() - t
+        times.append(dt)
+        spent += dt
+    if int(cc4[0]) != gpu_visible:
+        raise SystemExit("parity failure: CPU oracle sees %d visible meshlets, GPU %d" % (int(cc4[0]), gpu_visible))
+    med = sorted(times)[len(times) // 2]
+    return {"value": n_cmd * 64 / med, "unit": "meshlets/s", "cores": threads, "kind": "port",
+            "sample": "%d passes of the full %d-meshlet config3A batch, OpenMP oracle, median pass" % (len(times), n_cmd * 64)}
+
+
+if __name__ == "__main__":
+    main()

@@ -52,18 +52,26 @@ def make_meshes(mesh_count, lod_count, meshlets_lod0, center=(0.0, 0.0, 0.0), ra
     return meshes, offset
 
 
-def make_task_commands(draw_count, commands_per_draw, late_draw_visibility=None):
-    """config 3A: full commands (taskCount 64), command k covers meshlets [64k, 64k+64) and visibility slots alike"""
+def make_task_commands(draw_count, commands_per_draw, late_draw_visibility=None, meshlet_base=0):
+    """config 3A: full commands (taskCount 64), command k covers meshlets [64k, 64k+64) and visibility slots alike.
+    The array is padded with zeroed dummy commands to a multiple of 64, exactly what tasksubmit leaves behind
+    (tasksubmit.comp.glsl:40-46); use count4_for() for the matching {count, X, 64, 1} words."""
     n = draw_count * commands_per_draw
-    c = np.zeros(n, dtype=L.TASKCMD)
+    c = np.zeros((n + 63) // 64 * 64, dtype=L.TASKCMD)
     k = np.arange(n, dtype=np.uint32)
-    c["drawId"] = k // commands_per_draw
-    c["taskOffset"] = k * 64
-    c["taskCount"] = 64
-    c["meshletVisibilityOffset"] = k * 64
+    c["drawId"][:n] = k // commands_per_draw
+    c["taskOffset"][:n] = k * 64 + meshlet_base
+    c["taskCount"][:n] = 64
+    c["meshletVisibilityOffset"][:n] = k * 64
     if late_draw_visibility is not None:
-        c["lateDrawVisibility"] = late_draw_visibility[c["drawId"]]
+        c["lateDrawVisibility"][:n] = late_draw_visibility[c["drawId"][:n]]
     return c
+
+
+def count4_for(command_count):
+    """the dccb words tasksubmit writes for `command_count` commands (tasksubmit.comp.glsl:30-38)"""
+    count = min(command_count, L.TASK_WGLIMIT)
+    return np.array([command_count, min((count + 63) // 64, 65535), 64, 1], np.uint32)
 
 
 def make_depth(width, height, znear=0.1, rects=64, seed=4):
@@ -81,10 +89,10 @@ def make_depth(width, height, znear=0.1, rects=64, seed=4):
 
 
 def cluster_scene(draw_count, commands_per_draw=10, seed=2, scene_radius=300.0):
-    """config 3A / 5 inputs: draws (niagara generator), meshlet pool, full task commands"""
+    """config 3A / 5 inputs: draws (niagara generator), meshlet pool, padded task commands, real command count"""
     draws = host.synth_draws(draw_count, 1, scene_radius)
     n_cmd = draw_count * commands_per_draw
     meshlets = make_meshlets(n_cmd * 64, seed)
     draws["meshletVisibilityOffset"] = np.arange(draw_count, dtype=np.uint32) * (commands_per_draw * 64)
     commands = make_task_commands(draw_count, commands_per_draw)
-    return draws, meshlets, commands
+    return draws, meshlets, commands, n_cmd

@@ -1,0 +1,352 @@
+"""GPU parity: every HIP pass, called through the C ABI, against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for indices, counts, commands, visibility words and the depth pyramid; scalar intermediates
+(sphere, cone, HiZ) within 1 ULP (`ULP_TOL`; in practice they are bit-exact too).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from niagara_amd import host, synth
+from niagara_amd import layouts as L
+from niagara_amd import pipeline as P
+
+import gpu_passes as G
+import passes
+from scenes import flag_matrix, make_scene, task_capacity
+
+pytestmark = pytest.mark.gpu
+
+ULP_TOL = 1  # north_star: "within 1 ULP on the sphere/cone/HiZ tests"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = P.Context()
+    yield c
+    c.close()
+
+
+def ulp_diff(a, b):
+    ai = a.view(np.int32).astype(np.int64)
+    bi = b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7fffffff), ai)
+    bi = np.where(bi < 0, -(bi & 0x7fffffff), bi)
+    return np.abs(ai - bi)
+
+
+def test_extension_is_the_hip_library():
+    import niagara_amd
+    assert niagara_amd.SO_PATH.endswith("niagara_amd/libniagara_vis.so")
+    assert torch.cuda.is_available()
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+@pytest.mark.parametrize("use_soa", [True, False])
+def test_scalar_intermediates_within_one_ulp(ctx, use_soa):
+    scene = make_scene(seed=31, n_draws=200, meshlets_lod0=200, zero_radius_fraction=0.02)
+    g = G.GpuScene(ctx, scene, use_soa)
+    pyr = oracle.Pyramid(*scene["viewport"])
+    oracle.depthreduce(scene["depth"], pyr)
+    g.depthreduce(scene["depth"])
+    cd = passes.set_flags(scene["cull"], (1, 1, 1, 1, 1))
+    dvb = np.ones(len(scene["draws"]), np.uint32)
+    cmds, c4 = passes.run_drawcull(oracle, scene, cd, 0, 1, dvb, pyr)
+    n = int(c4[0])
+    assert n > 50
+    cmds = cmds[:n].copy()
+    cmds["taskCount"] = 64  # probe every lane; keep reads in range
+    total = len(scene["meshlets"])
+    cmds["taskOffset"] = np.minimum(cmds["taskOffset"], total - 64)
+    ref = oracle.probe_cluster_scalars(cd, cmds, scene["draws"], scene["meshlets"], pyr)
+    got = ctx.probe_cluster_scalars(cd, P.to_device(cmds, ctx.device), n, g.db, g.mlb, g.pyramid.desc).cpu().numpy()
+    d = ulp_diff(got, ref)
+    assert d.max() <= ULP_TOL, int(d.max())
+    assert (got.view(np.uint32) == ref.view(np.uint32)).mean() == 1.0  # in fact bit-exact
+    assert ref[:, :, 13].mean() > 0.05 and ref[:, :, 15].mean() > 0.05  # projected spheres and cone-culled lanes exist
+
+
+@pytest.mark.parametrize("late", [0, 1])
+@pytest.mark.parametrize("task", [0, 1])
+def test_drawcull_flag_matrix(ctx, late, task):
+    scene = make_scene(seed=5 + late * 2 + task, n_draws=2500, post_pass_fraction=0.1)
+    g = G.GpuScene(ctx, scene)
+    pyr = oracle.Pyramid(*scene["viewport"])
+    oracle.depthreduce(scene["depth"], pyr)
+    assert g.depthreduce(scene["depth"]).tobytes() == pyr.data.tobytes()
+    rng = np.random.default_rng(9)
+    dt = L.TASKCMD if task else L.DRAWCMD
+    for flags in flag_matrix():
+        for post in (0, 1):
+            cd = passes.set_flags(scene["cull"], flags)
+            dvb0 = (rng.random(len(scene["draws"])) < 0.6).astype(np.uint32)
+            dvb_o = dvb0.copy()
+            co, c4o = passes.run_drawcull(oracle, scene, cd, late, task, dvb_o, pyr, post)
+            dcb, dccb, dvb = g.drawcull(cd, late, task, dvb0, post)
+            n = int(c4o[0])
+            assert G.host_u32(dccb)[0] == n, (flags, post)
+            assert P.from_device(dcb, dt)[:n].tobytes() == co[:n].tobytes(), (flags, post)
+            assert (G.host_u32(dvb) == dvb_o).all(), (flags, post)
+    ctx.status()
+
+
+def test_drawcull_counter_base_and_empty_input(ctx):
+    """append indices start at the value already in the count word (atomicAdd semantics); drawCount 0 is a no-op"""
+    scene = make_scene(seed=40, n_draws=700)
+    g = G.GpuScene(ctx, scene)
+    cd = passes.set_flags(scene["cull"], (1, 1, 0, 0, 0))
+    dvb0 = np.ones(700, np.uint32)
+    co, c4o = passes.run_drawcull(oracle, scene, cd, 0, 0, dvb0.copy(), None)
+    dev = ctx.device
+    dcb = torch.zeros((700 + 8) * 24, dtype=torch.uint8, device=dev)
+    dccb = torch.tensor([5, 0, 0, 0], dtype=torch.int32, device=dev)
+    dvb = torch.ones(700, dtype=torch.int32, device=dev)
+    ctx.drawcull(cd, 0, 0, g.db, g.mb, dcb, dccb, dvb, None)
+    n = int(c4o[0])
+    assert int(dccb[0].item()) == n + 5
+    assert P.from_device(dcb, L.DRAWCMD)[5:5 + n].tobytes() == co[:n].tobytes()
+    empty = cd.copy()
+    empty["drawCount"] = 0
+    dccb.zero_()
+    ctx.drawcull(empty, 0, 0, g.db, g.mb, dcb, dccb, dvb, None)
+    assert int(dccb[0].item()) == 0
+    ctx.status()
+
+
+def test_submit_kernels(ctx):
+    dev = ctx.device
+    for count in [0, 1, 63, 64, 65, 1000, 4095, 4096]:
+        a = np.full(count + 80, 7, dtype=L.TASKCMD)
+        c4a = np.array([count, 9, 9, 9], np.uint32)
+        d_cmd, d_c4 = P.to_device(a, dev), torch.from_numpy(c4a.view(np.int32).copy()).to(dev)
+        oracle.tasksubmit(c4a, a)
+        ctx.tasksubmit(d_c4, d_cmd)
+        assert (G.host_u32(d_c4) == c4a).all() and P.from_device(d_cmd, L.TASKCMD).tobytes() == a.tobytes()
+    for count in [0, 1, 255, 256, 257, 5000]:
+        a = np.full(count + 300, 5, np.uint32)
+        c4a = np.array([count, 9, 9, 9], np.uint32)
+        d_cib, d_c4 = torch.from_numpy(a.view(np.int32).copy()).to(dev), torch.from_numpy(c4a.view(np.int32).copy()).to(dev)
+        oracle.clustersubmit(c4a, a)
+        ctx.clustersubmit(d_c4, d_cib)
+        assert (G.host_u32(d_c4) == c4a).all() and (G.host_u32(d_cib) == a).all()
+
+
+@pytest.mark.parametrize("use_soa", [True, False])
+@pytest.mark.parametrize("seed", [21, 22])
+def test_two_frame_protocol(ctx, seed, use_soa):
+    """early -> pyramid -> late over three frames, every intermediate buffer bit-identical to the oracle"""
+    scene = make_scene(seed=seed, n_draws=1500, meshlets_lod0=130, zero_radius_fraction=0.02)
+    for flags in [(1, 1, 1, 1, 1), (1, 1, 1, 0, 1), (1, 0, 0, 0, 0), (0, 1, 1, 1, 0), (1, 1, 0, 1, 1)]:
+        fo = passes.run_frames(oracle, scene, flags, frames=3)
+        fg = G.run_frames(ctx, scene, flags, frames=3, use_soa=use_soa)
+        for a, b in zip(fo, fg):
+            assert a["pyramid"].tobytes() == b["pyramid"].tobytes()
+            for phase in ("early", "late"):
+                for key in ("count4", "commands", "cc4", "cib", "dvb", "mvb"):
+                    assert a[phase][key].tobytes() == b[phase][key].tobytes(), (flags, phase, key)
+        assert fo[0]["late"]["cc4"][0] > 0
+
+
+def test_taskcull_payloads(ctx):
+    scene = make_scene(seed=23, n_draws=800, meshlets_lod0=130)
+    g = G.GpuScene(ctx, scene)
+    pyr = oracle.Pyramid(*scene["viewport"])
+    oracle.depthreduce(scene["depth"], pyr)
+    g.depthreduce(scene["depth"])
+    rng = np.random.default_rng(3)
+    for late, flags in [(0, (1, 1, 0, 0, 1)), (1, (1, 1, 1, 1, 1)), (0, (1, 1, 1, 1, 1))]:
+        cd = passes.set_flags(scene["cull"], flags)
+        dvb = np.ones(len(scene["draws"]), np.uint32)
+        cmds, c4 = passes.run_drawcull(oracle, scene, cd, 0, 1, dvb, pyr)
+        oracle.tasksubmit(c4, cmds)
+        ncmd = int(c4[1]) * 64
+        mvb0 = rng.integers(0, 2 ** 32, (scene["slots"] + 31) // 32 + 2, dtype=np.uint64).astype(np.uint32)
+        mvb_o = mvb0.copy()
+        pay_o, cnt_o = np.zeros((ncmd, 64), np.uint32), np.zeros(ncmd, np.uint32)
+        oracle.taskcull(cd, late, cmds, c4, scene["draws"], scene["meshlets"], mvb_o, pyr, pay_o, cnt_o)
+        dev = ctx.device
+        d_pay = torch.zeros(ncmd * 64, dtype=torch.int32, device=dev)
+        d_cnt = torch.zeros(ncmd, dtype=torch.int32, device=dev)
+        d_mvb = torch.from_numpy(mvb0.view(np.int32).copy()).to(dev)
+        ctx.taskcull(cd, late, P.to_device(cmds[:ncmd], dev), torch.from_numpy(c4.view(np.int32).copy()).to(dev), g.db, g.mlb, d_mvb,
+                     g.pyramid.desc, d_pay, d_cnt)
+        assert (G.host_u32(d_cnt) == cnt_o).all()
+        pay_g = G.host_u32(d_pay).reshape(ncmd, 64)
+        for c in range(ncmd):
+            assert (pay_g[c, :cnt_o[c]] == pay_o[c, :cnt_o[c]]).all()
+        assert (G.host_u32(d_mvb) == mvb_o).all()
+
+
+@pytest.mark.parametrize("size", [(64, 64), (128, 32), (100, 75), (257, 130), (33, 2), (5, 3), (1024, 768), (4096, 4096), (2048, 1024)])
+def test_depthreduce_sizes(ctx, size):
+    w, h = size
+    rng = np.random.default_rng(w * 1000 + h)
+    depth = rng.random((h, w), dtype=np.float32)
+    po = oracle.Pyramid(w, h)
+    oracle.depthreduce(depth, po)
+    pg = P.DepthPyramid(ctx.device, w, h)
+    ctx.depthreduce(torch.from_numpy(depth).to(ctx.device), w, h, pg.desc)
+    assert (pg.width, pg.height, pg.levels) == (po.width, po.height, po.levels)
+    assert pg.data.cpu().numpy().tobytes() == po.data.tobytes()
+
+
+def _cluster_inputs(draw_count, commands_per_draw, seed=2):
+    draws, meshlets, commands, n = synth.cluster_scene(draw_count, commands_per_draw, seed)
+    cd = host.build_cull_data(draw_count=draw_count, cullingEnabled=1, clusterBackfaceEnabled=1)
+    return draws, meshlets, commands, n, cd
+
+
+def _gpu_clustercull(ctx, draws, meshlets, commands, n, cd, late=0, mvb=None, pyramid=None, soa=True, repeats=1):
+    """commands must be padded to a multiple of 64 with dummy commands (what tasksubmit guarantees)"""
+    dev = ctx.device
+    assert len(commands) % 64 == 0 and len(commands) >= n
+    db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+    if soa:
+        ctx.upload_meshlets(mlb, len(meshlets))
+    dccb = torch.from_numpy(synth.count4_for(n).view(np.int32).copy()).to(dev)
+    cib = torch.zeros(min(n * 64, L.CLUSTER_LIMIT) + 256, dtype=torch.int32, device=dev)
+    ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+    outs = []
+    for _ in range(repeats):
+        ccb.zero_()
+        ctx.clustercull(cd, late, dcb, dccb, db, mlb, mvb, pyramid, cib, ccb)
+        total = int(ccb[0].item())
+        outs.append((total, G.host_u32(cib)[:min(total, L.CLUSTER_LIMIT)].copy()))
+    ctx.status()
+    return outs
+
+
+def test_config3_full_size_bit_identical_and_properties(ctx):
+    """BASELINE config 3: 10 M meshlets (156 250 commands over 15 625 draws), cone + frustum.  The multithreaded
+    oracle finishes this in seconds, so the full list is compared; properties checked on top: count == length,
+    strictly ascending (command, lane) order, idempotence over repeated launches."""
+    draws, meshlets, commands, n, cd = _cluster_inputs(15625, 10)
+    assert n * 64 == 10_000_000
+    c4 = synth.count4_for(n)
+    cib_o, cc4_o = np.zeros(n * 64, np.uint32), np.zeros(4, np.uint32)
+    oracle.clustercull(cd, 0, commands, c4, draws, meshlets, None, None, cib_o, cc4_o, threads=oracle.max_threads())
+    total_o = int(cc4_o[0])
+    assert 0.005 * n * 64 < total_o < 0.2 * n * 64
+    outs = _gpu_clustercull(ctx, draws, meshlets, commands, n, cd, repeats=3)
+    for total, ids in outs:
+        assert total == total_o
+        assert (ids == cib_o[:total_o]).all()
+        key = (ids & 0xffffff).astype(np.int64) * 64 + (ids >> 24)
+        assert (np.diff(key) > 0).all()
+    # the AoS path (no mirror) gives the same list
+    (total, ids), = _gpu_clustercull(ctx, draws, meshlets, commands, n, cd, soa=False)
+    assert total == total_o and (ids == cib_o[:total_o]).all()
+
+
+def test_ragged_command_counts_and_dummy_commands(ctx):
+    """taskCount < 64, unaligned taskOffset / visibility offsets, and the zeroed dummy commands tasksubmit pads with"""
+    rng = np.random.default_rng(77)
+    draws, meshlets, commands, n, cd = _cluster_inputs(300, 7)
+    commands["taskCount"][:n] = rng.integers(0, 65, n)
+    commands["taskOffset"][:n] = rng.integers(0, len(meshlets) - 64, n)
+    commands["meshletVisibilityOffset"][:n] = np.cumsum(np.r_[0, commands["taskCount"][:n - 1]]) + 13
+    cd["clusterOcclusionEnabled"] = 1
+    slots = int(commands["meshletVisibilityOffset"].max()) + 64
+    mvb0 = rng.integers(0, 2 ** 32, slots // 32 + 3, dtype=np.uint64).astype(np.uint32)
+    pyr = oracle.Pyramid(256, 192)
+    depth = make_scene(seed=3)["depth"]
+    oracle.depthreduce(depth, pyr)
+    cd["pyramidWidth"], cd["pyramidHeight"] = pyr.width, pyr.height
+    commands["lateDrawVisibility"][:n] = rng.integers(0, 2, n)
+    dev = ctx.device
+    gp = P.DepthPyramid(dev, 256, 192)
+    ctx.depthreduce(torch.from_numpy(depth).to(dev), 256, 192, gp.desc)
+    for late in (0, 1):
+        c4 = synth.count4_for(n)
+        cib_o, cc4_o, mvb_o = np.zeros(len(commands) * 64, np.uint32), np.zeros(4, np.uint32), mvb0.copy()
+        oracle.clustercull(cd, late, commands, c4, draws, meshlets, mvb_o, pyr, cib_o, cc4_o)
+        d_mvb = torch.from_numpy(mvb0.view(np.int32).copy()).to(dev)
+        db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+        dccb = torch.from_numpy(c4.view(np.int32).copy()).to(dev)
+        cib = torch.zeros(len(commands) * 64 + 256, dtype=torch.int32, device=dev)
+        ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+        ctx.clustercull(cd, late, dcb, dccb, db, mlb, d_mvb, gp.desc, cib, ccb)
+        total = int(cc4_o[0])
+        assert int(ccb[0].item()) == total and total > 0
+        assert (G.host_u32(cib)[:total] == cib_o[:total]).all()
+        assert (G.host_u32(d_mvb) == mvb_o).all()
+    ctx.status()
+
+
+def test_cluster_limit_overflow_is_dropped_silently(ctx):
+    """> 2^24 survivors: the count keeps counting, entries past CLUSTER_LIMIT are dropped (clustercull.comp.glsl:137)"""
+    ncmd = (L.CLUSTER_LIMIT // 64) + 1024
+    draws = np.zeros(1, dtype=L.MESHDRAW)
+    draws["position"] = (0, 0, 10)
+    draws["scale"] = 1
+    draws["orientation"] = (0, 0, 0, 1)
+    meshlets = synth.make_meshlets(4096, seed=5)
+    meshlets["cone_cutoff"] = 127  # never cone-culled
+    assert ncmd % 64 == 0
+    commands = np.zeros(ncmd, dtype=L.TASKCMD)
+    commands["taskCount"] = 64
+    commands["taskOffset"] = (np.arange(ncmd) % 63) * 64
+    cd = host.build_cull_data(draw_count=1, cullingEnabled=1, clusterBackfaceEnabled=0)
+    (total, ids), = _gpu_clustercull(ctx, draws, meshlets, commands, ncmd, cd)
+    assert total == ncmd * 64 and total > L.CLUSTER_LIMIT
+    assert len(ids) == L.CLUSTER_LIMIT
+    k = np.arange(L.CLUSTER_LIMIT, dtype=np.uint32)
+    assert (ids == ((k >> 6) | ((k & 63) << 24))).all()
+
+
+def test_task_limit_overflow_drops_whole_draws(ctx):
+    """> 2^22 task commands: a draw whose range would cross TASK_WGLIMIT is dropped entirely, the count still advances
+    (drawcull.comp.glsl:128), tasksubmit clamps (tasksubmit.comp.glsl:30,36)"""
+    n_draws = 70_000
+    meshes, total = synth.make_meshes(1, 1, 64 * 61 + 5)  # 62 task groups per draw
+    draws = host.synth_draws(n_draws, 1, 5.0)
+    draws["position"] = (0, 0, 50)
+    host.assign_visibility_offsets(draws, meshes)
+    cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=0)
+    dvb0 = np.ones(n_draws, np.uint32)
+    cap = L.TASK_WGLIMIT + 64
+    co, c4o = np.zeros(cap, dtype=L.TASKCMD), np.zeros(4, np.uint32)
+    oracle.drawcull(cd, 0, 1, draws, meshes, co, c4o, dvb0.copy(), None, threads=oracle.max_threads())
+    assert c4o[0] == n_draws * 62 > L.TASK_WGLIMIT
+    dev = ctx.device
+    dcb = torch.zeros(cap * 20, dtype=torch.uint8, device=dev)
+    dccb = torch.zeros(4, dtype=torch.int32, device=dev)
+    dvb = torch.ones(n_draws, dtype=torch.int32, device=dev)
+    ctx.drawcull(cd, 0, 1, P.to_device(draws, dev), P.to_device(meshes, dev), dcb, dccb, dvb, None)
+    ctx.tasksubmit(dccb, dcb)
+    oracle.tasksubmit(c4o, co)
+    assert (G.host_u32(dccb) == c4o).all()
+    assert P.from_device(dcb, L.TASKCMD)[:L.TASK_WGLIMIT].tobytes() == co[:L.TASK_WGLIMIT].tobytes()
+    ctx.status()
+
+
+def test_graph_replay_is_safe(ctx):
+    """the ordered-append state is self-cleaning (epoch in device memory): a captured launch replays correctly"""
+    draws, meshlets, commands, n, cd = _cluster_inputs(2000, 4)
+    dev = ctx.device
+    db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+    ctx.upload_meshlets(mlb, len(meshlets))
+    c4 = synth.count4_for(n)
+    dccb = torch.from_numpy(c4.view(np.int32).copy()).to(dev)
+    cib = torch.zeros(n * 64 + 256, dtype=torch.int32, device=dev)
+    ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+    cib_o, cc4_o = np.zeros(n * 64, np.uint32), np.zeros(4, np.uint32)
+    oracle.clustercull(cd, 0, commands, c4, draws, meshlets, None, None, cib_o, cc4_o)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)  # warm-up outside capture
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        ccb.zero_()
+        with torch.cuda.graph(graph, stream=s):
+            ccb.zero_()
+            ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
+        for _ in range(4):
+            cib.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            total = int(ccb[0].item())
+            assert total == int(cc4_o[0])
+            assert (G.host_u32(cib)[:total] == cib_o[:total]).all()
+    ctx.status()
