@@ -6,6 +6,14 @@ at import time, and every device entry point raises NvError on a non-zero status
 import ctypes as C
 import os
 
+# The Python host layer hands torch-allocated device pointers and torch streams to the library, so both must sit on
+# ONE HIP runtime.  torch bundles its own libamdhip64.so.7; loading it first makes the library's NEEDED entry resolve
+# to that same copy (same SONAME).  A C++ host that does not use torch simply links /opt/rocm's runtime.
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover - the C ABI itself does not need torch
+    pass
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libniagara_vis.so")
 

@@ -29,6 +29,7 @@ struct ClusterArgs
 	uint32_t stateCapacity;
 	uint32_t commandCountOverride; // probe/taskcull: explicit command count (0 = use count4[1]*64)
 	float* __restrict__ probeOut;
+	uint32_t debugMode; // tuning experiments only (NV_DEBUG_MODE); 0 in production
 };
 
 struct DrawArgs

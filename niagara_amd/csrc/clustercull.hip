@@ -214,122 +214,172 @@ NV_DEV uint32_t indirect_command_count(const ClusterArgs& a)
 
 // ---------------------------------------------------------------------------------------------------------------
 // ordered cluster append (clustercull.comp.glsl)
+//
+// Static tiles: the grid is a fixed, co-resident set of G workgroups (context.hip sizes it to 4 per CU); tile t covers
+// commands [t*T, (t+1)*T) with T = ceil(numCmds / G) (device-computed from the indirect words, clamped to CC_TMAX),
+// so a pass is ONE tile per workgroup and the chained scan runs once per workgroup at the tail, after its whole
+// range has been culled: phase 1 cull -> 64-bit ballots in LDS, phase 2 tile total, phase 3 look-back across tiles,
+// phase 4 ordered scatter from the LDS ballots.  No tickets, no per-tile atomics.
+constexpr uint32_t CC_TMAX = 4096; // commands per tile: 32 KiB of ballots in LDS
+
+template <int K>
+struct Batch
+{
+	NvMeshTaskCommand cmd[K];
+	LaneData ld[K];
+};
+
+template <bool LATE, bool SOA, int K>
+NV_DEV void load_batch(const ClusterArgs& a, Batch<K>& b, uint32_t first, uint32_t i, uint32_t n, uint32_t lane)
+{
+#pragma unroll
+	for (int k = 0; k < K; ++k)
+		b.cmd[k] = (i + k < n) ? load_command(a.commands, first + i + k) : NvMeshTaskCommand{ 0, 0, 0, 0, 0 };
+#pragma unroll
+	for (int k = 0; k < K; ++k)
+	{
+		const bool valid = lane < b.cmd[k].taskCount;
+		b.ld[k] = load_lane<SOA>(a, b.cmd[k].taskOffset + lane, valid);
+		b.ld[k].mvbWord = load_mvb_word<LATE>(a, b.cmd[k], lane, valid);
+	}
+}
+
 template <bool LATE, bool SOA, int K>
 __global__ __launch_bounds__(CC_THREADS) void clustercull_kernel(ClusterArgs a)
 {
-	constexpr uint32_t TILE_CMDS = CC_WAVES * K;
-
-	__shared__ uint32_t s_tile;
-	__shared__ uint32_t s_waveCount[CC_WAVES];
+	__shared__ uint64_t s_mask[CC_TMAX];
+	__shared__ uint32_t s_part[CC_WAVES];
 	__shared__ uint32_t s_base;
-	__shared__ uint32_t s_wrapped;
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const uint32_t shard = blockIdx.x % NV_SHARDS;
+	const uint32_t G = gridDim.x;
+	constexpr uint32_t STEP = CC_WAVES * K;
 
-	const uint32_t epoch = load_epoch(a.ctl);
 	const uint32_t numCmds = indirect_command_count(a);
-	const uint32_t numTiles = (numCmds + TILE_CMDS - 1) / TILE_CMDS;
+	uint32_t T = ((numCmds + G - 1) / G + STEP - 1) / STEP * STEP;
+	T = T < STEP ? STEP : (T > CC_TMAX ? CC_TMAX : T);
+	const uint32_t numTiles = (numCmds + T - 1) / T;
+	const uint32_t epoch = load_epoch(a.ctl);
 	const uint32_t base0 = a.clusterCount4[0];
+	const bool dbgNoScan = a.debugMode & 1u, dbgNoScatter = a.debugMode & 4u; // experiments only
 
-	uint32_t nextTile = 0;
-	if (tid == 0)
-		nextTile = draw_ticket(a.ctl, shard);
-
-	for (;;)
+	for (uint32_t tile = blockIdx.x; tile < numTiles; tile += G)
 	{
-		if (tid == 0)
-			s_tile = nextTile;
-		__syncthreads();
-		const uint32_t tile = __builtin_amdgcn_readfirstlane(s_tile);
-		if (tile >= numTiles)
-			break;
-		if (tid == 0)
-			nextTile = draw_ticket(a.ctl, shard); // prefetch: the atomic's latency hides under this tile's work
+		const uint32_t first = tile * T;
+		const uint32_t n = numCmds - first < T ? numCmds - first : T;
 
-		// ---- phase 1: loads of all K commands of this wave
-		const uint32_t cmd0 = tile * TILE_CMDS + wave * K;
-		NvMeshTaskCommand cmd[K];
-		DrawUniform du[K];
-		LaneData ld[K];
-#pragma unroll
-		for (int k = 0; k < K; ++k)
-		{
-			const uint32_t ci = cmd0 + k;
-			if (ci < numCmds)
-				cmd[k] = load_command(a.commands, ci);
-			else
-				cmd[k] = NvMeshTaskCommand{ 0, 0, 0, 0, 0 };
-		}
-#pragma unroll
-		for (int k = 0; k < K; ++k)
-		{
-			const bool valid = lane < cmd[k].taskCount;
-			ld[k] = load_lane<SOA>(a, cmd[k].taskOffset + lane, valid);
-			ld[k].mvbWord = load_mvb_word<LATE>(a, cmd[k], lane, valid);
-			du[k] = load_draw(a.draws, cmd[k].drawId);
-		}
-
-		// ---- phase 2: tests -> one ballot per command
-		uint64_t mask[K];
+		// ---- phase 1: cull; the loads of batch i+1 are in flight while batch i is tested
 		uint32_t waveCount = 0;
-#pragma unroll
-		for (int k = 0; k < K; ++k)
+		uint32_t curDraw = ~0u;
+		DrawUniform du = {};
+		Batch<K> cur, nxt;
+		load_batch<LATE, SOA, K>(a, cur, first, wave * K, n, lane);
+		for (uint32_t i = wave * K; i < n; i += STEP)
 		{
-			mask[k] = cmd[k].taskCount ? cull_command<LATE>(a, cmd[k], du[k], ld[k], lane) : 0ull;
-			waveCount += (uint32_t)__builtin_popcountll(mask[k]);
+			if (i + STEP < n)
+				load_batch<LATE, SOA, K>(a, nxt, first, i + STEP, n, lane);
+#pragma unroll
+			for (int k = 0; k < K; ++k)
+			{
+				if (i + k < n)
+				{
+					uint64_t m = 0;
+					if (cur.cmd[k].taskCount)
+					{
+						if (cur.cmd[k].drawId != curDraw) // a draw's task commands are consecutive: usually a hit
+						{
+							curDraw = cur.cmd[k].drawId;
+							du = load_draw(a.draws, curDraw);
+						}
+						m = cull_command<LATE>(a, cur.cmd[k], du, cur.ld[k], lane);
+					}
+					if (lane == 0)
+						s_mask[i + k] = m;
+					waveCount += (uint32_t)__builtin_popcountll(m);
+				}
+			}
+			cur = nxt;
 		}
 
-		// ---- phase 3: tile aggregate, chained scan across tiles
+		// ---- phase 2 + 3: tile total, chained scan across tiles
 		if (lane == 0)
-			s_waveCount[wave] = waveCount;
+			s_part[wave] = waveCount;
 		__syncthreads();
 		if (wave == 0)
 		{
 			uint32_t aggregate = 0;
 #pragma unroll
 			for (int w = 0; w < CC_WAVES; ++w)
-				aggregate += s_waveCount[w];
-			uint32_t exclusive = lookback_exclusive(a.state, a.ctl, tile, epoch, aggregate, base0);
+				aggregate += s_part[w];
+			uint32_t exclusive = dbgNoScan ? 0u : lookback_exclusive(a.state, a.ctl, tile, epoch, aggregate, base0);
 			if (lane == 0)
 			{
 				s_base = exclusive;
 				if (tile == numTiles - 1)
+				{
 					a.clusterCount4[0] = exclusive + aggregate; // what the chain of atomicAdds leaves in clusterCount
+					advance_epoch(a.ctl, epoch);                 // every tile has published: nobody polls any more
+				}
 			}
 		}
 		__syncthreads();
 
-		// ---- phase 4: ordered scatter; clustercull.comp.glsl:137-138 drops entries past CLUSTER_LIMIT
-		uint32_t offset = s_base;
-#pragma unroll
-		for (int w = 0; w < CC_WAVES; ++w)
-			offset += w < (int)wave ? s_waveCount[w] : 0u;
-#pragma unroll
-		for (int k = 0; k < K; ++k)
+		// ---- phase 4: ordered scatter, 256 commands per step, one command per lane for the scan and one command
+		// per iteration for the (coalesced) stores; clustercull.comp.glsl:137-138 drops entries past CLUSTER_LIMIT
+		uint32_t running = s_base;
+		for (uint32_t c0 = 0; c0 < n; c0 += CC_THREADS)
 		{
-			const uint64_t m = mask[k];
-			if (m >> lane & 1ull)
+			const uint32_t c = c0 + tid;
+			const uint64_t m = c < n ? s_mask[c] : 0ull;
+			const uint32_t pc = (uint32_t)__builtin_popcountll(m);
+			uint32_t incl = pc;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1)
 			{
-				uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-				uint32_t index = offset + rank;
-				if (index < NV_CLUSTER_LIMIT)
-					a.clusterIndices[index] = (cmd0 + k) | (lane << 24);
+				uint32_t t = __shfl_up(incl, o, 64);
+				if ((int)lane >= o)
+					incl += t;
 			}
-			offset += (uint32_t)__builtin_popcountll(m);
-		}
-		// s_tile / s_waveCount / s_base are rewritten only after the next __syncthreads() at the loop head
-	}
+			__syncthreads(); // previous step's s_part readers are done
+			if (lane == 63)
+				s_part[wave] = incl;
+			__syncthreads();
+			uint32_t waveBase = running;
+#pragma unroll
+			for (int w = 0; w < CC_WAVES; ++w)
+			{
+				uint32_t p = s_part[w];
+				waveBase += w < (int)wave ? p : 0u;
+				running += p;
+			}
+			const uint32_t excl = waveBase + incl - pc;
 
-	// ---- leave; the last workgroup out re-arms tickets and epoch for the next launch
-	if (tid == 0)
-		s_wrapped = leave_and_maybe_reset(a.ctl, epoch) ? 1u : 0u;
-	__syncthreads();
-	if (s_wrapped)
-		for (uint32_t i = tid; i < a.stateCapacity; i += CC_THREADS)
-			a.state[i] = 0;
+			uint64_t owners = dbgNoScatter ? 0ull : __ballot(pc != 0);
+			while (owners)
+			{
+				const int src = __builtin_ctzll(owners);
+				owners &= owners - 1;
+				const uint32_t mlo = __builtin_amdgcn_readlane((uint32_t)m, src);
+				const uint32_t mhi = __builtin_amdgcn_readlane((uint32_t)(m >> 32), src);
+				const uint32_t off = __builtin_amdgcn_readlane(excl, src);
+				const uint64_t ms = ((uint64_t)mhi << 32) | mlo;
+				if (ms >> lane & 1ull)
+				{
+					uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+					uint32_t index = off + rank;
+					if (index < NV_CLUSTER_LIMIT)
+						a.clusterIndices[index] = (first + c0 + wave * 64 + src) | (lane << 24);
+				}
+			}
+		}
+		__syncthreads(); // s_mask is rewritten by the next tile
+
+		if (tile == numTiles - 1 && ((epoch + 1) & 0x3fffffffu) == 0)
+			for (uint32_t i = tid; i < a.stateCapacity; i += CC_THREADS) // epoch wrapped: drop 2^30-launch-old tags
+				a.state[i] = 0;
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -439,29 +489,44 @@ __global__ __launch_bounds__(256) void soa_split_kernel(const NvMeshlet* __restr
 // ---------------------------------------------------------------------------------------------------------------
 // launchers (called from context.hip)
 
-constexpr int CC_K = 4;
-
-int launch_clustercull(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t gridBlocks)
+template <int K>
+static void launch_cc_k(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t gridBlocks)
 {
 	dim3 grid(gridBlocks), block(CC_THREADS);
 	if (late)
 	{
 		if (soa)
-			hipLaunchKernelGGL((clustercull_kernel<true, true, CC_K>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((clustercull_kernel<true, true, K>), grid, block, 0, stream, a);
 		else
-			hipLaunchKernelGGL((clustercull_kernel<true, false, CC_K>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((clustercull_kernel<true, false, K>), grid, block, 0, stream, a);
 	}
 	else
 	{
 		if (soa)
-			hipLaunchKernelGGL((clustercull_kernel<false, true, CC_K>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((clustercull_kernel<false, true, K>), grid, block, 0, stream, a);
 		else
-			hipLaunchKernelGGL((clustercull_kernel<false, false, CC_K>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((clustercull_kernel<false, false, K>), grid, block, 0, stream, a);
+	}
+}
+
+// K = commands per wave per tile (tile = 4*K commands); chosen per context (NV_CC_K, default CC_K_DEFAULT)
+constexpr int CC_K_DEFAULT = 2;
+
+int launch_clustercull(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t gridBlocks, int k)
+{
+	switch (k)
+	{
+	case 1: launch_cc_k<1>(stream, a, late, soa, gridBlocks); break;
+	case 2: launch_cc_k<2>(stream, a, late, soa, gridBlocks); break;
+	case 3: launch_cc_k<3>(stream, a, late, soa, gridBlocks); break;
+	case 4: launch_cc_k<4>(stream, a, late, soa, gridBlocks); break;
+	default: launch_cc_k<CC_K_DEFAULT>(stream, a, late, soa, gridBlocks); break;
 	}
 	return (int)hipGetLastError();
 }
 
-uint32_t clustercull_tile_commands() { return CC_WAVES * CC_K; }
+uint32_t clustercull_max_tiles(uint32_t gridBlocks) { return (gridBlocks > NV_TASK_WGLIMIT / CC_TMAX ? gridBlocks : NV_TASK_WGLIMIT / CC_TMAX) + 1; }
+int clustercull_default_k() { return CC_K_DEFAULT; }
 
 int launch_taskcull(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t gridBlocks)
 {

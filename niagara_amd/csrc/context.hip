@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <new>
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -15,13 +16,14 @@
 namespace nv
 {
 
-int launch_clustercull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t gridBlocks);
+int launch_clustercull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t gridBlocks, int k);
+int clustercull_default_k();
 int launch_taskcull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t gridBlocks);
 int launch_probe(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
 int launch_soa_split(hipStream_t, const NvMeshlet*, uint32_t count, uint32_t padded, uint2* bounds, uint32_t* cones);
-uint32_t clustercull_tile_commands();
+uint32_t clustercull_max_tiles(uint32_t gridBlocks);
 int launch_drawcull(hipStream_t, const DrawArgs&, int late, int task, uint32_t gridBlocks);
-uint32_t drawcull_tile_draws();
+uint32_t drawcull_max_tiles(uint32_t drawCount, uint32_t gridBlocks);
 int launch_tasksubmit(hipStream_t, uint32_t* count4, NvMeshTaskCommand* commands);
 int launch_clustersubmit(hipStream_t, uint32_t* cc4, uint32_t* clusterIndices);
 int launch_pack_counts(hipStream_t, const uint32_t*, const uint32_t*, const uint32_t*, uint64_t*);
@@ -42,6 +44,10 @@ struct nv_context
 	uint2* soaBounds;
 	uint32_t* soaCones;
 	uint32_t soaCapacity;
+	// tuning knobs (environment, read once in nv_create): NV_CC_K in {1,2,4,8}, NV_DEBUG_MODE bit mask, NV_CC_BLOCKS_PER_CU
+	int ccK;
+	uint32_t debugMode;
+	uint32_t ccBlocksPerCU;
 };
 
 namespace
@@ -94,13 +100,10 @@ int ensure_state(nv_context* ctx, uint32_t tiles)
 	return NV_OK;
 }
 
-uint32_t persistent_grid(const nv_context* ctx, uint32_t blocksPerCU, uint32_t tilesKnown)
+// co-resident grid of the ordered passes (ordered.cuh): blocksPerCU workgroups of 256 threads per CU
+uint32_t persistent_grid(const nv_context* ctx, uint32_t blocksPerCU)
 {
-	uint32_t grid = (uint32_t)ctx->numCUs * blocksPerCU;
-	if (tilesKnown && tilesKnown < grid)
-		grid = tilesKnown;
-	// every ticket shard needs at least one workgroup (ordered.cuh)
-	return round_up(grid < NV_SHARDS ? NV_SHARDS : grid, NV_SHARDS);
+	return (uint32_t)ctx->numCUs * blocksPerCU;
 }
 
 } // namespace
@@ -135,6 +138,14 @@ int nv_create(nv_context** out_ctx, int device)
 		return (int)e;
 	}
 	ctx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	ctx->ccK = nv::clustercull_default_k();
+	ctx->ccBlocksPerCU = 4;
+	if (const char* v = getenv("NV_CC_K"))
+		ctx->ccK = atoi(v);
+	if (const char* v = getenv("NV_DEBUG_MODE"))
+		ctx->debugMode = (uint32_t)atoi(v);
+	if (const char* v = getenv("NV_CC_BLOCKS_PER_CU"))
+		ctx->ccBlocksPerCU = (uint32_t)atoi(v) ? (uint32_t)atoi(v) : 4;
 
 	e = hipMalloc(&ctx->ctl, sizeof(nv::OrderCtl));
 	if (e == hipSuccess)
@@ -150,9 +161,9 @@ int nv_create(nv_context** out_ctx, int device)
 		return e == hipErrorOutOfMemory ? NV_ENOMEM : (int)e;
 	}
 
-	// enough tiles for NV_TASK_WGLIMIT commands and for 2^28 draws
-	uint32_t tiles = NV_TASK_WGLIMIT / nv::clustercull_tile_commands() + 1;
-	int rc = ensure_state(ctx, tiles < (1u << 18) ? (1u << 18) : tiles);
+	// one granule per tile of the largest pass
+	uint32_t tiles = nv::clustercull_max_tiles(persistent_grid(ctx, ctx->ccBlocksPerCU));
+	int rc = ensure_state(ctx, tiles < (1u << 16) ? (1u << 16) : tiles);
 	if (rc != NV_OK)
 	{
 		nv_destroy(ctx);
@@ -247,8 +258,8 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 		return NV_EINVAL;
 	DeviceGuard guard(ctx->device);
 
-	const uint32_t tiles = (cull->drawCount + nv::drawcull_tile_draws() - 1) / nv::drawcull_tile_draws();
-	int rc = ensure_state(ctx, tiles);
+	const uint32_t grid = persistent_grid(ctx, 4);
+	int rc = ensure_state(ctx, nv::drawcull_max_tiles(cull->drawCount, grid));
 	if (rc)
 		return rc;
 
@@ -263,7 +274,7 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 	a.state = ctx->state;
 	a.ctl = ctx->ctl;
 	a.stateCapacity = ctx->stateCapacity;
-	return nv::launch_drawcull((hipStream_t)stream, a, late, task, persistent_grid(ctx, 3, tiles ? tiles : 1));
+	return nv::launch_drawcull((hipStream_t)stream, a, late, task, grid);
 }
 
 int nv_tasksubmit(nv_context* ctx, void* stream, uint32_t* d_count4, NvMeshTaskCommand* d_commands)
@@ -315,7 +326,8 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	DeviceGuard guard(ctx->device);
 	a.clusterIndices = d_clusterIndices;
 	a.clusterCount4 = d_clusterCount4;
-	return nv::launch_clustercull((hipStream_t)stream, a, late, a.soaBounds != nullptr, persistent_grid(ctx, 8, 0));
+	a.debugMode = ctx->debugMode;
+	return nv::launch_clustercull((hipStream_t)stream, a, late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), ctx->ccK);
 }
 
 int nv_clustersubmit(nv_context* ctx, void* stream, uint32_t* d_clusterCount4, uint32_t* d_clusterIndices)

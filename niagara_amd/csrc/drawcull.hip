@@ -3,11 +3,11 @@
 // Replaces src/shaders/drawcull.comp.glsl:54-156 (4 pipelines LATE x TASK, src/niagara.cpp:724-727).
 //
 // Mapping to CDNA4:
-//   * one lane per draw, 4 draws per lane per tile (tile = 1024 consecutive draws per 256-thread workgroup): the
-//     12 independent 16-B loads of the four 48-B MeshDraw records are issued before any arithmetic;
+//   * one lane per draw; a workgroup owns one contiguous tile of draws per pass and keeps the next step's 48-B
+//     MeshDraw record (3 x 16-B loads) + visibility word in flight while it tests the current one;
 //   * the emit count of a draw (1 command, or ceil(meshletCount/64) task commands) is scanned inside the wave with
-//     DPP shuffles, across waves through 16 LDS words, and across tiles through ordered.cuh — append index =
-//     exclusive prefix in draw order, no per-draw global atomic (drawcull.comp.glsl:123,143);
+//     DPP shuffles, across waves through LDS, and across tiles through ordered.cuh — append index = exclusive prefix
+//     in draw order, no per-draw global atomic (drawcull.comp.glsl:123,143);
 //   * TASK mode expands a draw's commands wave-cooperatively: the owning lane's (draw, LOD range, dci) is broadcast
 //     with readlane and all 64 lanes write consecutive 20-B MeshTaskCommands, instead of one lane looping over
 //     up to hundreds of commands (drawcull.comp.glsl:131-138).
@@ -20,8 +20,7 @@ namespace nv
 
 constexpr int DC_WAVES = 4;
 constexpr int DC_THREADS = DC_WAVES * 64;
-constexpr int DC_ITEMS = 4; // draws per lane per tile
-constexpr uint32_t DC_TILE = DC_THREADS * DC_ITEMS;
+constexpr uint32_t DC_TMAX = 2048; // draws per tile: 3 x 8 KiB of per-draw results in LDS
 
 
 struct DrawResult
@@ -100,123 +99,142 @@ NV_DEV DrawResult decide_draw(const DrawArgs& a, uint32_t di, const float4& d0, 
 	return res;
 }
 
+struct DrawLoad
+{
+	float4 d0, d1; // position.xyz, scale | orientation
+	uint4 d2;      // meshIndex, meshletVisibilityOffset, postPass, materialIndex
+	uint32_t oldVis;
+};
+
+NV_DEV DrawLoad load_draw_record(const DrawArgs& a, uint32_t di)
+{
+	DrawLoad l;
+	const float4* p = reinterpret_cast<const float4*>(a.draws + di);
+	l.d0 = p[0];
+	l.d1 = p[1];
+	l.d2 = *reinterpret_cast<const uint4*>(p + 2);
+	l.oldVis = a.dvb[di];
+	return l;
+}
+
+// Static tiles, one per workgroup per pass (see ordered.cuh and clustercull.hip): phase 1 decide -> per-draw emit
+// count / LOD / old visibility in LDS, phase 2 tile total, phase 3 look-back across tiles, phase 4 ordered emit.
 template <bool LATE, bool TASK>
 __global__ __launch_bounds__(DC_THREADS) void drawcull_kernel(DrawArgs a)
 {
-	__shared__ uint32_t s_tile;
-	__shared__ uint32_t s_part[DC_ITEMS * DC_WAVES];
+	__shared__ uint32_t s_count[DC_TMAX];
+	__shared__ uint32_t s_flags[DC_TMAX];
+	__shared__ uint32_t s_old[DC_TMAX];
+	__shared__ uint32_t s_part[DC_WAVES];
 	__shared__ uint32_t s_base;
-	__shared__ uint32_t s_wrapped;
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const uint32_t shard = blockIdx.x % NV_SHARDS;
+	const uint32_t G = gridDim.x;
 
-	const uint32_t epoch = load_epoch(a.ctl);
 	const uint32_t drawCount = a.cd.drawCount;
-	const uint32_t numTiles = (drawCount + DC_TILE - 1) / DC_TILE;
+	uint32_t T = ((drawCount + G - 1) / G + DC_THREADS - 1) / DC_THREADS * DC_THREADS;
+	T = T < DC_THREADS ? DC_THREADS : (T > DC_TMAX ? DC_TMAX : T);
+	const uint32_t numTiles = (drawCount + T - 1) / T;
+	const uint32_t epoch = load_epoch(a.ctl);
 	const uint32_t base0 = a.count4[0];
 
-	uint32_t nextTile = 0;
-	if (tid == 0)
-		nextTile = draw_ticket(a.ctl, shard);
-
-	for (;;)
+	for (uint32_t tile = blockIdx.x; tile < numTiles; tile += G)
 	{
-		if (tid == 0)
-			s_tile = nextTile;
-		__syncthreads();
-		const uint32_t tile = __builtin_amdgcn_readfirstlane(s_tile);
-		if (tile >= numTiles)
-			break;
-		if (tid == 0)
-			nextTile = draw_ticket(a.ctl, shard);
+		const uint32_t first = tile * T;
+		const uint32_t n = drawCount - first < T ? drawCount - first : T;
 
-		// ---- loads: item j of this lane is draw tile*1024 + j*256 + tid (coalesced across the workgroup)
-		float4 d0[DC_ITEMS], d1[DC_ITEMS];
-		uint4 d2[DC_ITEMS];
-		uint32_t oldVis[DC_ITEMS];
-		uint32_t di[DC_ITEMS];
-#pragma unroll
-		for (int j = 0; j < DC_ITEMS; ++j)
+		// ---- phase 1: one draw per lane per step; the next step's 52 bytes are in flight during the tests
+		uint32_t threadSum = 0;
+		DrawLoad cur = {}, nxt = {};
+		if (tid < n)
+			cur = load_draw_record(a, first + tid);
+		for (uint32_t c = tid; c < n; c += DC_THREADS)
 		{
-			di[j] = tile * DC_TILE + j * DC_THREADS + tid;
-			if (di[j] < drawCount)
-			{
-				const float4* p = reinterpret_cast<const float4*>(a.draws + di[j]);
-				d0[j] = p[0];
-				d1[j] = p[1];
-				d2[j] = *reinterpret_cast<const uint4*>(p + 2);
-				oldVis[j] = a.dvb[di[j]];
-			}
+			if (c + DC_THREADS < n)
+				nxt = load_draw_record(a, first + c + DC_THREADS);
+			DrawResult res = decide_draw<LATE, TASK>(a, first + c, cur.d0, cur.d1, cur.d2, cur.oldVis);
+			s_count[c] = res.count;
+			s_flags[c] = res.lodWord;
+			s_old[c] = cur.oldVis;
+			threadSum += res.count;
+			cur = nxt;
 		}
 
-		// ---- decisions
-		DrawResult res[DC_ITEMS];
-		uint32_t incl[DC_ITEMS];
-#pragma unroll
-		for (int j = 0; j < DC_ITEMS; ++j)
-		{
-			res[j] = DrawResult{ 0, 0, 0 };
-			if (di[j] < drawCount)
-				res[j] = decide_draw<LATE, TASK>(a, di[j], d0[j], d1[j], d2[j], oldVis[j]);
-			incl[j] = wave_inclusive_scan(res[j].count, lane);
-			if (lane == 63)
-				s_part[j * DC_WAVES + wave] = incl[j];
-		}
+		// ---- phase 2 + 3
+		uint32_t waveSum = wave_sum_u32(threadSum);
+		if (lane == 0)
+			s_part[wave] = waveSum;
 		__syncthreads();
-
-		// ---- tile aggregate + chained scan
 		if (wave == 0)
 		{
 			uint32_t aggregate = 0;
 #pragma unroll
-			for (int i = 0; i < DC_ITEMS * DC_WAVES; ++i)
-				aggregate += s_part[i];
+			for (int w = 0; w < DC_WAVES; ++w)
+				aggregate += s_part[w];
 			uint32_t exclusive = lookback_exclusive(a.state, a.ctl, tile, epoch, aggregate, base0);
 			if (lane == 0)
 			{
 				s_base = exclusive;
 				if (tile == numTiles - 1)
+				{
 					a.count4[0] = exclusive + aggregate;
+					advance_epoch(a.ctl, epoch);
+				}
 			}
 		}
 		__syncthreads();
 
-		// ---- emit in draw order: parts are ordered item-major, wave-minor
-		uint32_t partBase = s_base;
-#pragma unroll
-		for (int j = 0; j < DC_ITEMS; ++j)
+		// ---- phase 4: ordered emit, 256 draws per step
+		uint32_t running = s_base;
+		for (uint32_t c0 = 0; c0 < n; c0 += DC_THREADS)
 		{
-			uint32_t before = partBase;
+			const uint32_t c = c0 + tid;
+			const uint32_t cnt = c < n ? s_count[c] : 0u;
+			const uint32_t flags = c < n ? s_flags[c] : 0u;
+			const uint32_t incl = wave_inclusive_scan(cnt, lane);
+			__syncthreads();
+			if (lane == 63)
+				s_part[wave] = incl;
+			__syncthreads();
+			uint32_t waveBase = running;
 #pragma unroll
 			for (int w = 0; w < DC_WAVES; ++w)
 			{
-				uint32_t p = s_part[j * DC_WAVES + w];
-				before += w < (int)wave ? p : 0u;
-				partBase += p;
+				uint32_t p = s_part[w];
+				waveBase += w < (int)wave ? p : 0u;
+				running += p;
 			}
-			const uint32_t dci = before + incl[j] - res[j].count;
-			const bool emit = (res[j].lodWord & 0x100u) != 0;
-			const uint32_t lodIndex = res[j].lodWord & 0xffu;
+			const uint32_t dci = waveBase + incl - cnt;
+			const bool emit = (flags & 0x100u) != 0;
+			const uint32_t lodIndex = flags & 0xffu;
+			const uint32_t di = first + c;
 
 			if (TASK)
 			{
 				// wave-cooperative expansion, one owning lane at a time (drawcull.comp.glsl:120-139)
-				uint64_t owners = __ballot(emit && res[j].count != 0);
+				uint64_t owners = __ballot(emit && cnt != 0);
 				NvMeshTaskCommand* tc = static_cast<NvMeshTaskCommand*>(a.commands);
+				uint32_t meshIndex = 0, mvo = 0, oldVis = 0;
+				if (emit && cnt != 0)
+				{
+					const uint2 ids = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.draws + di) + 32);
+					meshIndex = ids.x;
+					mvo = ids.y;
+					oldVis = s_old[c];
+				}
 				while (owners)
 				{
 					const int src = __builtin_ctzll(owners);
 					owners &= owners - 1;
-					const uint32_t oDraw = __shfl(di[j], src, 64);
-					const uint32_t oDci = __shfl(dci, src, 64);
-					const uint32_t oGroups = __shfl(res[j].count, src, 64);
-					const uint32_t oLod = __shfl(lodIndex, src, 64);
-					const uint32_t oVis = __shfl(res[j].oldVis, src, 64);
-					const uint32_t oMesh = __shfl(d2[j].x, src, 64);
-					const uint32_t oMvo = __shfl(d2[j].y, src, 64);
+					const uint32_t oDraw = first + c0 + wave * 64 + src;
+					const uint32_t oDci = __builtin_amdgcn_readlane(dci, src);
+					const uint32_t oGroups = __builtin_amdgcn_readlane(cnt, src);
+					const uint32_t oLod = __builtin_amdgcn_readlane(lodIndex, src);
+					const uint32_t oVis = __builtin_amdgcn_readlane(oldVis, src);
+					const uint32_t oMesh = __builtin_amdgcn_readlane(meshIndex, src);
+					const uint32_t oMvo = __builtin_amdgcn_readlane(mvo, src);
 					if (oDci + oGroups <= NV_TASK_WGLIMIT) // drop the whole draw on overflow (:128)
 					{
 						const char* mesh = reinterpret_cast<const char*>(a.meshes + oMesh);
@@ -224,14 +242,14 @@ __global__ __launch_bounds__(DC_THREADS) void drawcull_kernel(DrawArgs a)
 						const uint32_t meshletCount = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * oLod + 12);
 						for (uint32_t i = lane; i < oGroups; i += 64)
 						{
-							NvMeshTaskCommand c;
-							c.drawId = oDraw;
-							c.taskOffset = meshletOffset + i * NV_TASK_WGSIZE;
+							NvMeshTaskCommand cmd;
+							cmd.drawId = oDraw;
+							cmd.taskOffset = meshletOffset + i * NV_TASK_WGSIZE;
 							uint32_t rest = meshletCount - i * NV_TASK_WGSIZE;
-							c.taskCount = rest < NV_TASK_WGSIZE ? rest : NV_TASK_WGSIZE;
-							c.lateDrawVisibility = oVis;
-							c.meshletVisibilityOffset = oMvo + i * NV_TASK_WGSIZE;
-							tc[oDci + i] = c;
+							cmd.taskCount = rest < NV_TASK_WGSIZE ? rest : NV_TASK_WGSIZE;
+							cmd.lateDrawVisibility = oVis;
+							cmd.meshletVisibilityOffset = oMvo + i * NV_TASK_WGSIZE;
+							tc[oDci + i] = cmd;
 						}
 					}
 				}
@@ -239,24 +257,23 @@ __global__ __launch_bounds__(DC_THREADS) void drawcull_kernel(DrawArgs a)
 			else if (emit)
 			{
 				// drawcull.comp.glsl:141-150
-				const char* mesh = reinterpret_cast<const char*>(a.meshes + d2[j].x);
+				const uint32_t meshIndex = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.draws + di) + 32);
+				const char* mesh = reinterpret_cast<const char*>(a.meshes + meshIndex);
 				const uint32_t indexOffset = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * lodIndex + 0);
 				const uint32_t indexCount = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * lodIndex + 4);
 				const uint32_t vertexOffset = *reinterpret_cast<const uint32_t*>(mesh + 16);
 				uint2* dc = reinterpret_cast<uint2*>(static_cast<NvMeshDrawCommand*>(a.commands) + dci);
-				dc[0] = make_uint2(di[j], indexCount);
+				dc[0] = make_uint2(di, indexCount);
 				dc[1] = make_uint2(1u, indexOffset);
 				dc[2] = make_uint2(vertexOffset, 0u);
 			}
 		}
-	}
+		__syncthreads(); // LDS is rewritten by the next tile
 
-	if (tid == 0)
-		s_wrapped = leave_and_maybe_reset(a.ctl, epoch) ? 1u : 0u;
-	__syncthreads();
-	if (s_wrapped)
-		for (uint32_t i = tid; i < a.stateCapacity; i += DC_THREADS)
-			a.state[i] = 0;
+		if (tile == numTiles - 1 && ((epoch + 1) & 0x3fffffffu) == 0)
+			for (uint32_t i = tid; i < a.stateCapacity; i += DC_THREADS)
+				a.state[i] = 0;
+	}
 }
 
 int launch_drawcull(hipStream_t stream, const DrawArgs& a, int late, int task, uint32_t gridBlocks)
@@ -279,6 +296,10 @@ int launch_drawcull(hipStream_t stream, const DrawArgs& a, int late, int task, u
 	return (int)hipGetLastError();
 }
 
-uint32_t drawcull_tile_draws() { return DC_TILE; }
+uint32_t drawcull_max_tiles(uint32_t drawCount, uint32_t gridBlocks)
+{
+	uint32_t byCap = (drawCount + DC_TMAX - 1) / DC_TMAX;
+	return (byCap > gridBlocks ? byCap : gridBlocks) + 1;
+}
 
 } // namespace nv

