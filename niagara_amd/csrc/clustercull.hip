@@ -72,27 +72,30 @@ NV_DEV NvMeshTaskCommand load_command(const NvMeshTaskCommand* commands, uint32_
 	return NvMeshTaskCommand{ c[0], c[1], c[2], c[3], c[4] };
 }
 
+// The reference reads meshlets[mi] for all 64 lanes and masks the result with `valid` afterwards
+// (clustercull.comp.glsl:72-82).  Here invalid lanes re-read the command's first meshlet instead (taskCount == 0:
+// meshlet 0), so that every load is unconditional and in range: no branch sits between a load and its use, which
+// lets the compiler keep several commands' loads in flight (counted s_waitcnt vmcnt(N) instead of vmcnt(0)).
 template <bool SOA>
-NV_DEV LaneData load_lane(const ClusterArgs& a, uint32_t mi, bool valid)
+NV_DEV LaneData load_lane(const ClusterArgs& a, uint32_t taskOffset, uint32_t taskCount, uint32_t lane)
 {
-	LaneData l = { 0, 0, 0, 0 };
-	if (valid)
+	const uint32_t mi = (taskCount ? taskOffset : 0u) + (lane < taskCount ? lane : 0u);
+	LaneData l;
+	if (SOA)
 	{
-		if (SOA)
-		{
-			uint2 b = a.soaBounds[mi];
-			l.b0 = b.x;
-			l.b1 = b.y;
-			l.cone = a.soaCones[mi];
-		}
-		else
-		{
-			const uint32_t* p = reinterpret_cast<const uint32_t*>(a.meshlets + mi);
-			l.b0 = p[0];
-			l.b1 = p[1];
-			l.cone = p[2];
-		}
+		uint2 b = a.soaBounds[mi];
+		l.b0 = b.x;
+		l.b1 = b.y;
+		l.cone = a.soaCones[mi];
 	}
+	else
+	{
+		const uint32_t* p = reinterpret_cast<const uint32_t*>(a.meshlets + mi);
+		l.b0 = p[0];
+		l.b1 = p[1];
+		l.cone = p[2];
+	}
+	l.mvbWord = 0;
 	return l;
 }
 
@@ -118,18 +121,19 @@ NV_DEV void lane_cone(const NvCullData& cd, const DrawUniform& u, const LaneData
 
 // One command on one wave.  Returns the ballot of lanes that append (visible && !skip) and, for the late pass,
 // applies the visibility-bit update.  All arguments except `l` are wave-uniform.
-template <bool LATE>
+// BITS = (clusterOcclusionEnabled == 1 && postPass == 0), resolved on the host so that the variant without
+// visibility bits carries no load for them.
+template <bool LATE, bool BITS>
 NV_DEV uint64_t cull_command(const ClusterArgs& a, const NvMeshTaskCommand& cmd, const DrawUniform& u, const LaneData& l, uint32_t lane)
 {
 	const NvCullData& cd = a.cd;
 	const bool valid = lane < cmd.taskCount;
-	const bool useBits = cd.clusterOcclusionEnabled == 1 && cd.postPass == 0;
 	const uint32_t mvi = lane + cmd.meshletVisibilityOffset;
 
 	bool visible = valid;
 	bool skip = false;
 
-	if (useBits)
+	if (BITS)
 	{
 		// clustercull.comp.glsl:86-99
 		bool bit = (l.mvbWord & (1u << (mvi & 31))) != 0;
@@ -193,17 +197,12 @@ NV_DEV uint64_t cull_command(const ClusterArgs& a, const NvMeshTaskCommand& cmd,
 	return __ballot(visible && !skip);
 }
 
-template <bool LATE>
-NV_DEV uint32_t load_mvb_word(const ClusterArgs& a, const NvMeshTaskCommand& cmd, uint32_t lane, bool valid)
+NV_DEV uint32_t load_mvb_word(const ClusterArgs& a, uint32_t meshletVisibilityOffset, uint32_t taskCount, uint32_t lane)
 {
-	if (a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0 && valid)
-	{
-		uint32_t mvi = lane + cmd.meshletVisibilityOffset;
-		// late pass: other waves update neighbouring bits of shared words concurrently; an agent-scope load keeps
-		// the read out of a stale L1 line (our own bit is only ever written by this lane, later)
-		return __hip_atomic_load(a.mvb + (mvi >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
-	return 0;
+	const uint32_t mvi = taskCount ? meshletVisibilityOffset + (lane < taskCount ? lane : 0u) : 0u;
+	// late pass: other waves update neighbouring bits of shared words concurrently; an agent-scope load keeps the
+	// read out of a stale L1 line (our own bit is only ever written by this lane, later)
+	return __hip_atomic_load(a.mvb + (mvi >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 NV_DEV uint32_t indirect_command_count(const ClusterArgs& a)
@@ -220,115 +219,255 @@ NV_DEV uint32_t indirect_command_count(const ClusterArgs& a)
 // so a pass is ONE tile per workgroup and the chained scan runs once per workgroup at the tail, after its whole
 // range has been culled: phase 1 cull -> 64-bit ballots in LDS, phase 2 tile total, phase 3 look-back across tiles,
 // phase 4 ordered scatter from the LDS ballots.  No tickets, no per-tile atomics.
-constexpr uint32_t CC_TMAX = 4096; // commands per tile: 32 KiB of ballots in LDS
+constexpr uint32_t CC_TMAX = 1024; // commands per tile: 8 KiB of ballots in LDS
+constexpr int CC_D = 6;            // ring slots per wave: CC_D - 1 commands' meshlet loads in flight behind the one being tested
 
-template <int K>
-struct Batch
+// lane l of a wave holds the l-th command of the wave's current 64-command segment (one coalesced 1280-B read
+// instead of 64 dependent scalar loads) and the MeshDraw it points at; fields are broadcast with v_readlane as the
+// wave walks the segment, so the walk itself contains no scalar-memory wait.
+struct SegmentRegs
 {
-	NvMeshTaskCommand cmd[K];
-	LaneData ld[K];
+	uint32_t drawId, taskOffset, taskCount, lateDrawVisibility, meshletVisibilityOffset;
+	float4 d0, d1; // position.xyz, scale | orientation.xyzw of draws[drawId]
 };
 
-template <bool LATE, bool SOA, int K>
-NV_DEV void load_batch(const ClusterArgs& a, Batch<K>& b, uint32_t first, uint32_t i, uint32_t n, uint32_t lane)
+NV_DEV NvMeshTaskCommand segment_command(const SegmentRegs& r, uint32_t c)
 {
-#pragma unroll
-	for (int k = 0; k < K; ++k)
-		b.cmd[k] = (i + k < n) ? load_command(a.commands, first + i + k) : NvMeshTaskCommand{ 0, 0, 0, 0, 0 };
-#pragma unroll
-	for (int k = 0; k < K; ++k)
+	NvMeshTaskCommand cmd;
+	cmd.drawId = (uint32_t)__builtin_amdgcn_readlane(r.drawId, c);
+	cmd.taskOffset = (uint32_t)__builtin_amdgcn_readlane(r.taskOffset, c);
+	cmd.taskCount = (uint32_t)__builtin_amdgcn_readlane(r.taskCount, c);
+	cmd.lateDrawVisibility = (uint32_t)__builtin_amdgcn_readlane(r.lateDrawVisibility, c);
+	cmd.meshletVisibilityOffset = (uint32_t)__builtin_amdgcn_readlane(r.meshletVisibilityOffset, c);
+	return cmd;
+}
+
+NV_DEV float readlane_f(float v, uint32_t c) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), c)); }
+
+NV_DEV DrawUniform segment_draw(const SegmentRegs& r, uint32_t c)
+{
+	DrawUniform u;
+	u.pos = { readlane_f(r.d0.x, c), readlane_f(r.d0.y, c), readlane_f(r.d0.z, c) };
+	u.scale = readlane_f(r.d0.w, c);
+	u.q = { readlane_f(r.d1.x, c), readlane_f(r.d1.y, c), readlane_f(r.d1.z, c) };
+	u.qw = readlane_f(r.d1.w, c);
+	return u;
+}
+
+// ---- software-pipelined meshlet stream (SoA mirror only)
+// hipcc's s_waitcnt insertion collapses a loop-carried prefetch ring to (almost) vmcnt(0): measured, every command then
+// costs one full memory latency.  The ring's loads are therefore issued from inline asm, which hipcc does not count,
+// and waited for by hand with a counted vmcnt (cdna_hip_programming.md §5.7, form (ii): "=v" loads, then a wait
+// statement that names every destination "+v" before its first consumer).  Rules that keep this safe:
+//   * a slot's registers are touched by nothing but its issue / wait statements until the wait has passed;
+//   * slots are reissued in a fixed rotation with unconditional loads (indices clamped, never branched), so exactly
+//     (CC_D - 1) * LOADS younger ring loads are outstanding at every wait;
+//   * VMEM operations hipcc issues itself in between (HiZ texels, visibility-bit atomics) are younger than the slot
+//     being waited for and are consumed before the next ring issue (the issue statement takes the command's ballot as
+//     an operand), so they can only make a wait stricter, never too weak.
+struct RingSlot
+{
+	uint64_t bounds; // center.xy | center.z, radius (4 x fp16)
+	uint32_t cone;
+	uint32_t mvbWord;
+};
+
+template <bool BITS>
+NV_DEV void ring_issue(RingSlot& s, const ClusterArgs& a, uint32_t taskOffset, uint32_t taskCount, uint32_t mvo, uint32_t lane, uint64_t order)
+{
+	const uint32_t li = lane < taskCount ? lane : 0u;
+	const uint32_t mi = (taskCount ? taskOffset : 0u) + li;
+	const uint32_t off8 = mi * 8u, off4 = mi * 4u;
+	if (BITS)
 	{
-		const bool valid = lane < b.cmd[k].taskCount;
-		b.ld[k] = load_lane<SOA>(a, b.cmd[k].taskOffset + lane, valid);
-		b.ld[k].mvbWord = load_mvb_word<LATE>(a, b.cmd[k], lane, valid);
+		const uint32_t offw = taskCount ? ((mvo + li) >> 5) * 4u : 0u;
+		asm volatile("global_load_dwordx2 %0, %3, %4\n\tglobal_load_dword %1, %5, %6\n\tglobal_load_dword %2, %7, %8 sc1"
+		             : "=&v"(s.bounds), "=&v"(s.cone), "=&v"(s.mvbWord)
+		             : "v"(off8), "s"(a.soaBounds), "v"(off4), "s"(a.soaCones), "v"(offw), "s"(a.mvb), "s"(order)
+		             : "memory");
+	}
+	else
+	{
+		asm volatile("global_load_dwordx2 %0, %2, %3\n\tglobal_load_dword %1, %4, %5"
+		             : "=&v"(s.bounds), "=&v"(s.cone)
+		             : "v"(off8), "s"(a.soaBounds), "v"(off4), "s"(a.soaCones), "s"(order)
+		             : "memory");
+		s.mvbWord = 0;
 	}
 }
 
-template <bool LATE, bool SOA, int K>
+template <bool BITS, int YOUNGER>
+NV_DEV void ring_wait(RingSlot& s)
+{
+	if (BITS)
+		asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s.bounds), "+v"(s.cone), "+v"(s.mvbWord) : "i"(YOUNGER * 3) : "memory");
+	else
+		asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.bounds), "+v"(s.cone) : "i"(YOUNGER * 2) : "memory");
+}
+
+template <bool LATE, bool SOA, bool BITS>
 __global__ __launch_bounds__(CC_THREADS) void clustercull_kernel(ClusterArgs a)
 {
 	__shared__ uint64_t s_mask[CC_TMAX];
 	__shared__ uint32_t s_part[CC_WAVES];
-	__shared__ uint32_t s_base;
+	__shared__ uint32_t s_scratch[16];
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const uint32_t G = gridDim.x;
-	constexpr uint32_t STEP = CC_WAVES * K;
 
 	const uint32_t numCmds = indirect_command_count(a);
-	uint32_t T = ((numCmds + G - 1) / G + STEP - 1) / STEP * STEP;
-	T = T < STEP ? STEP : (T > CC_TMAX ? CC_TMAX : T);
+	uint32_t T = (numCmds + G - 1) / G;
+	T = T < 1 ? 1 : (T > CC_TMAX ? CC_TMAX : T);
 	const uint32_t numTiles = (numCmds + T - 1) / T;
 	const uint32_t epoch = load_epoch(a.ctl);
 	const uint32_t base0 = a.clusterCount4[0];
 	const bool dbgNoScan = a.debugMode & 1u, dbgNoScatter = a.debugMode & 4u; // experiments only
+	// debugMode bit 3: per-wave s_memtime stamps into probeOut (tools/wave_timeline.py); never set in production
+	const bool dbgTime = (a.debugMode & 8u) && a.probeOut;
+	unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.probeOut) + (size_t)(blockIdx.x * CC_WAVES + wave) * 8;
+#define NV_STAMP(i) do { if (dbgTime && lane == 0) stamps[i] = __builtin_readcyclecounter(); } while (0)
+	NV_STAMP(0);
 
 	for (uint32_t tile = blockIdx.x; tile < numTiles; tile += G)
 	{
 		const uint32_t first = tile * T;
 		const uint32_t n = numCmds - first < T ? numCmds - first : T;
 
-		// ---- phase 1: cull; the loads of batch i+1 are in flight while batch i is tested
+		// ---- phase 1: each wave walks a contiguous quarter of the tile, CC_D commands' meshlet loads in flight
+		const uint32_t cw = (n + CC_WAVES - 1) / CC_WAVES;
+		const uint32_t wbeg = wave * cw < n ? wave * cw : n;
+		const uint32_t wend = wbeg + cw < n ? wbeg + cw : n;
 		uint32_t waveCount = 0;
-		uint32_t curDraw = ~0u;
-		DrawUniform du = {};
-		Batch<K> cur, nxt;
-		load_batch<LATE, SOA, K>(a, cur, first, wave * K, n, lane);
-		for (uint32_t i = wave * K; i < n; i += STEP)
+
+		for (uint32_t seg = wbeg; seg < wend; seg += 64)
 		{
-			if (i + STEP < n)
-				load_batch<LATE, SOA, K>(a, nxt, first, i + STEP, n, lane);
-#pragma unroll
-			for (int k = 0; k < K; ++k)
+			const uint32_t cnt = wend - seg < 64u ? wend - seg : 64u;
+
+			SegmentRegs r = {};
+			if (lane < cnt)
 			{
-				if (i + k < n)
+				const uint32_t* p = reinterpret_cast<const uint32_t*>(a.commands + first + seg + lane);
+				r.drawId = p[0];
+				r.taskOffset = p[1];
+				r.taskCount = p[2];
+				r.lateDrawVisibility = p[3];
+				r.meshletVisibilityOffset = p[4];
+				if (r.taskCount)
 				{
-					uint64_t m = 0;
-					if (cur.cmd[k].taskCount)
-					{
-						if (cur.cmd[k].drawId != curDraw) // a draw's task commands are consecutive: usually a hit
-						{
-							curDraw = cur.cmd[k].drawId;
-							du = load_draw(a.draws, curDraw);
-						}
-						m = cull_command<LATE>(a, cur.cmd[k], du, cur.ld[k], lane);
-					}
-					if (lane == 0)
-						s_mask[i + k] = m;
-					waveCount += (uint32_t)__builtin_popcountll(m);
+					const float4* d = reinterpret_cast<const float4*>(a.draws + r.drawId);
+					r.d0 = d[0];
+					r.d1 = d[1];
 				}
 			}
-			cur = nxt;
+
+			uint32_t curDraw = ~0u;
+			DrawUniform du = {};
+			NV_STAMP(1);
+
+			// body of one command, shared by both load paths
+			auto run_command = [&](uint32_t c, const LaneData& cur) -> uint64_t
+			{
+				const NvMeshTaskCommand cmd = segment_command(r, c);
+				uint64_t m = 0;
+				if (cmd.taskCount)
+				{
+					if (cmd.drawId != curDraw) // a draw's task commands are consecutive: usually a hit
+					{
+						curDraw = cmd.drawId;
+						du = segment_draw(r, c);
+					}
+					m = cull_command<LATE, BITS>(a, cmd, du, cur, lane);
+				}
+				if (lane == 0)
+					s_mask[seg + c] = m;
+				waveCount += (uint32_t)__builtin_popcountll(m);
+				return m;
+			};
+
+			if (SOA)
+			{
+				// make sure hipcc has waited for its own segment loads before the first uncounted load is issued
+				asm volatile("" : "+v"(r.d0.x), "+v"(r.d1.x), "+v"(r.taskOffset), "+v"(r.meshletVisibilityOffset));
+
+				// indices past the segment are clamped to its last command: redundant but unconditional loads
+				RingSlot ring[CC_D];
+#pragma unroll
+				for (int k = 0; k < CC_D; ++k)
+				{
+					const uint32_t c = (uint32_t)k < cnt ? k : cnt - 1;
+					ring_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, c), __builtin_amdgcn_readlane(r.taskCount, c),
+					                 __builtin_amdgcn_readlane(r.meshletVisibilityOffset, c), lane, 0);
+				}
+				NV_STAMP(2);
+				for (uint32_t i = 0; i < cnt; i += CC_D)
+				{
+#pragma unroll
+					for (int k = 0; k < CC_D; ++k)
+					{
+						const uint32_t c = i + k;
+						ring_wait<BITS, CC_D - 1>(ring[k]);
+						if (i == 0 && k == 0)
+							NV_STAMP(3);
+						uint64_t m = 0;
+						if (c < cnt)
+						{
+							LaneData cur;
+							cur.b0 = (uint32_t)ring[k].bounds;
+							cur.b1 = (uint32_t)(ring[k].bounds >> 32);
+							cur.cone = ring[k].cone;
+							cur.mvbWord = ring[k].mvbWord;
+							m = run_command(c, cur);
+						}
+						const uint32_t cn = c + CC_D < cnt ? c + CC_D : cnt - 1;
+						ring_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, cn), __builtin_amdgcn_readlane(r.taskCount, cn),
+						                 __builtin_amdgcn_readlane(r.meshletVisibilityOffset, cn), lane, m);
+					}
+				}
+				// drain: nothing of the ring may be in flight when the registers are reused
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			}
+			else
+			{
+				// AoS records read in place: compiler-scheduled loads, one command ahead
+				LaneData nxt = load_lane<false>(a, __builtin_amdgcn_readlane(r.taskOffset, 0), __builtin_amdgcn_readlane(r.taskCount, 0), lane);
+				if (BITS)
+					nxt.mvbWord = load_mvb_word(a, __builtin_amdgcn_readlane(r.meshletVisibilityOffset, 0), __builtin_amdgcn_readlane(r.taskCount, 0), lane);
+				for (uint32_t c = 0; c < cnt; ++c)
+				{
+					const LaneData cur = nxt;
+					const uint32_t cn = c + 1 < cnt ? c + 1 : cnt - 1;
+					nxt = load_lane<false>(a, __builtin_amdgcn_readlane(r.taskOffset, cn), __builtin_amdgcn_readlane(r.taskCount, cn), lane);
+					if (BITS)
+						nxt.mvbWord = load_mvb_word(a, __builtin_amdgcn_readlane(r.meshletVisibilityOffset, cn), __builtin_amdgcn_readlane(r.taskCount, cn), lane);
+					run_command(c, cur);
+				}
+			}
 		}
 
 		// ---- phase 2 + 3: tile total, chained scan across tiles
+		NV_STAMP(4);
 		if (lane == 0)
 			s_part[wave] = waveCount;
 		__syncthreads();
-		if (wave == 0)
-		{
-			uint32_t aggregate = 0;
+		NV_STAMP(5);
+		uint32_t aggregate = 0;
 #pragma unroll
-			for (int w = 0; w < CC_WAVES; ++w)
-				aggregate += s_part[w];
-			uint32_t exclusive = dbgNoScan ? 0u : lookback_exclusive(a.state, a.ctl, tile, epoch, aggregate, base0);
-			if (lane == 0)
-			{
-				s_base = exclusive;
-				if (tile == numTiles - 1)
-				{
-					a.clusterCount4[0] = exclusive + aggregate; // what the chain of atomicAdds leaves in clusterCount
-					advance_epoch(a.ctl, epoch);                 // every tile has published: nobody polls any more
-				}
-			}
+		for (int w = 0; w < CC_WAVES; ++w)
+			aggregate += s_part[w];
+		const uint32_t exclusive = dbgNoScan ? 0u : lookback_exclusive(a.state, a.ctl, tile, epoch, aggregate, base0, s_scratch);
+		if (tid == 0 && tile == numTiles - 1)
+		{
+			a.clusterCount4[0] = exclusive + aggregate; // what the chain of atomicAdds leaves in clusterCount
+			advance_epoch(a.ctl, epoch);                 // every tile has published: nobody polls any more
 		}
-		__syncthreads();
+		__syncthreads(); // s_part is reused by the scatter
 
+		NV_STAMP(6);
 		// ---- phase 4: ordered scatter, 256 commands per step, one command per lane for the scan and one command
 		// per iteration for the (coalesced) stores; clustercull.comp.glsl:137-138 drops entries past CLUSTER_LIMIT
-		uint32_t running = s_base;
+		uint32_t running = exclusive;
 		for (uint32_t c0 = 0; c0 < n; c0 += CC_THREADS)
 		{
 			const uint32_t c = c0 + tid;
@@ -375,6 +514,7 @@ __global__ __launch_bounds__(CC_THREADS) void clustercull_kernel(ClusterArgs a)
 			}
 		}
 		__syncthreads(); // s_mask is rewritten by the next tile
+		NV_STAMP(7);
 
 		if (tile == numTiles - 1 && ((epoch + 1) & 0x3fffffffu) == 0)
 			for (uint32_t i = tid; i < a.stateCapacity; i += CC_THREADS) // epoch wrapped: drop 2^30-launch-old tags
@@ -394,11 +534,14 @@ __global__ __launch_bounds__(CC_THREADS) void taskcull_kernel(ClusterArgs a)
 	for (uint32_t ci = blockIdx.x * CC_WAVES + wave; ci < numCmds; ci += gridDim.x * CC_WAVES)
 	{
 		const NvMeshTaskCommand cmd = load_command(a.commands, __builtin_amdgcn_readfirstlane(ci));
-		const bool valid = lane < cmd.taskCount;
-		LaneData ld = load_lane<SOA>(a, cmd.taskOffset + lane, valid);
-		ld.mvbWord = load_mvb_word<LATE>(a, cmd, lane, valid);
+		LaneData ld = load_lane<SOA>(a, cmd.taskOffset, cmd.taskCount, lane);
+		const bool bits = a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0;
+		if (bits)
+			ld.mvbWord = load_mvb_word(a, cmd.meshletVisibilityOffset, cmd.taskCount, lane);
 		const DrawUniform du = load_draw(a.draws, cmd.drawId);
-		const uint64_t m = cmd.taskCount ? cull_command<LATE>(a, cmd, du, ld, lane) : 0ull;
+		uint64_t m = 0;
+		if (cmd.taskCount)
+			m = bits ? cull_command<LATE, true>(a, cmd, du, ld, lane) : cull_command<LATE, false>(a, cmd, du, ld, lane);
 		if (m >> lane & 1ull)
 		{
 			uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -422,7 +565,7 @@ __global__ __launch_bounds__(CC_THREADS) void probe_kernel(ClusterArgs a)
 	for (uint32_t ci = blockIdx.x * CC_WAVES + wave; ci < numCmds; ci += gridDim.x * CC_WAVES)
 	{
 		const NvMeshTaskCommand cmd = load_command(a.commands, __builtin_amdgcn_readfirstlane(ci));
-		LaneData ld = load_lane<SOA>(a, cmd.taskOffset + lane, true);
+		LaneData ld = load_lane<SOA>(a, cmd.taskOffset, 64u, lane);
 		const DrawUniform du = load_draw(a.draws, cmd.drawId);
 
 		f3 c, axis;
@@ -489,44 +632,36 @@ __global__ __launch_bounds__(256) void soa_split_kernel(const NvMeshlet* __restr
 // ---------------------------------------------------------------------------------------------------------------
 // launchers (called from context.hip)
 
-template <int K>
-static void launch_cc_k(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t gridBlocks)
+template <bool LATE, bool SOA>
+static void launch_cc(hipStream_t stream, const ClusterArgs& a, uint32_t gridBlocks)
 {
 	dim3 grid(gridBlocks), block(CC_THREADS);
+	if (a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0)
+		hipLaunchKernelGGL((clustercull_kernel<LATE, SOA, true>), grid, block, 0, stream, a);
+	else
+		hipLaunchKernelGGL((clustercull_kernel<LATE, SOA, false>), grid, block, 0, stream, a);
+}
+
+int launch_clustercull(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t gridBlocks)
+{
 	if (late)
 	{
 		if (soa)
-			hipLaunchKernelGGL((clustercull_kernel<true, true, K>), grid, block, 0, stream, a);
+			launch_cc<true, true>(stream, a, gridBlocks);
 		else
-			hipLaunchKernelGGL((clustercull_kernel<true, false, K>), grid, block, 0, stream, a);
+			launch_cc<true, false>(stream, a, gridBlocks);
 	}
 	else
 	{
 		if (soa)
-			hipLaunchKernelGGL((clustercull_kernel<false, true, K>), grid, block, 0, stream, a);
+			launch_cc<false, true>(stream, a, gridBlocks);
 		else
-			hipLaunchKernelGGL((clustercull_kernel<false, false, K>), grid, block, 0, stream, a);
-	}
-}
-
-// K = commands per wave per tile (tile = 4*K commands); chosen per context (NV_CC_K, default CC_K_DEFAULT)
-constexpr int CC_K_DEFAULT = 2;
-
-int launch_clustercull(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t gridBlocks, int k)
-{
-	switch (k)
-	{
-	case 1: launch_cc_k<1>(stream, a, late, soa, gridBlocks); break;
-	case 2: launch_cc_k<2>(stream, a, late, soa, gridBlocks); break;
-	case 3: launch_cc_k<3>(stream, a, late, soa, gridBlocks); break;
-	case 4: launch_cc_k<4>(stream, a, late, soa, gridBlocks); break;
-	default: launch_cc_k<CC_K_DEFAULT>(stream, a, late, soa, gridBlocks); break;
+			launch_cc<false, false>(stream, a, gridBlocks);
 	}
 	return (int)hipGetLastError();
 }
 
-uint32_t clustercull_max_tiles(uint32_t gridBlocks) { return (gridBlocks > NV_TASK_WGLIMIT / CC_TMAX ? gridBlocks : NV_TASK_WGLIMIT / CC_TMAX) + 1; }
-int clustercull_default_k() { return CC_K_DEFAULT; }
+uint32_t clustercull_max_tiles(uint32_t gridBlocks) { return (gridBlocks > NV_TASK_WGLIMIT / CC_TMAX ? gridBlocks : NV_TASK_WGLIMIT / CC_TMAX) + 2; }
 
 int launch_taskcull(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t gridBlocks)
 {

@@ -16,8 +16,7 @@
 namespace nv
 {
 
-int launch_clustercull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t gridBlocks, int k);
-int clustercull_default_k();
+int launch_clustercull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t gridBlocks);
 int launch_taskcull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t gridBlocks);
 int launch_probe(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
 int launch_soa_split(hipStream_t, const NvMeshlet*, uint32_t count, uint32_t padded, uint2* bounds, uint32_t* cones);
@@ -44,10 +43,10 @@ struct nv_context
 	uint2* soaBounds;
 	uint32_t* soaCones;
 	uint32_t soaCapacity;
-	// tuning knobs (environment, read once in nv_create): NV_CC_K in {1,2,4,8}, NV_DEBUG_MODE bit mask, NV_CC_BLOCKS_PER_CU
-	int ccK;
+	// tuning knobs (environment, read once in nv_create): NV_DEBUG_MODE bit mask, NV_CC_BLOCKS_PER_CU
 	uint32_t debugMode;
 	uint32_t ccBlocksPerCU;
+	float* timing; // NV_DEBUG_MODE bit 3: 8 x u64 stamps per wave of the last clustercull
 };
 
 namespace
@@ -138,10 +137,7 @@ int nv_create(nv_context** out_ctx, int device)
 		return (int)e;
 	}
 	ctx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-	ctx->ccK = nv::clustercull_default_k();
 	ctx->ccBlocksPerCU = 4;
-	if (const char* v = getenv("NV_CC_K"))
-		ctx->ccK = atoi(v);
 	if (const char* v = getenv("NV_DEBUG_MODE"))
 		ctx->debugMode = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_CC_BLOCKS_PER_CU"))
@@ -187,6 +183,8 @@ void nv_destroy(nv_context* ctx)
 		(void)hipFree(ctx->soaBounds);
 	if (ctx->soaCones)
 		(void)hipFree(ctx->soaCones);
+	if (ctx->timing)
+		(void)hipFree(ctx->timing);
 	delete ctx;
 }
 
@@ -327,7 +325,13 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	a.clusterIndices = d_clusterIndices;
 	a.clusterCount4 = d_clusterCount4;
 	a.debugMode = ctx->debugMode;
-	return nv::launch_clustercull((hipStream_t)stream, a, late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), ctx->ccK);
+	if (ctx->debugMode & 8u)
+	{
+		if (!ctx->timing)
+			(void)hipMalloc(&ctx->timing, (size_t)persistent_grid(ctx, ctx->ccBlocksPerCU) * 4 * 8 * sizeof(unsigned long long));
+		a.probeOut = ctx->timing;
+	}
+	return nv::launch_clustercull((hipStream_t)stream, a, late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU));
 }
 
 int nv_clustersubmit(nv_context* ctx, void* stream, uint32_t* d_clusterCount4, uint32_t* d_clusterIndices)
@@ -361,6 +365,17 @@ int nv_depthreduce(nv_context* ctx, void* stream, const float* d_depth, uint32_t
 		return NV_EINVAL;
 	DeviceGuard guard(ctx->device);
 	return nv::launch_depthreduce((hipStream_t)stream, d_depth, width, height, *pyramid);
+}
+
+// development aid (not part of the public header): copies the NV_DEBUG_MODE bit-3 wave stamps to the host
+int nv_debug_read_timing(nv_context* ctx, unsigned long long* out, uint32_t maxWaves)
+{
+	if (!ctx || !ctx->timing || !out)
+		return NV_EINVAL;
+	uint32_t waves = persistent_grid(ctx, ctx->ccBlocksPerCU) * 4;
+	if (waves > maxWaves)
+		waves = maxWaves;
+	return (int)hipMemcpy(out, ctx->timing, (size_t)waves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
 }
 
 int nv_pack_counts(nv_context* ctx, void* stream, const uint32_t* d_countA, const uint32_t* d_countB,

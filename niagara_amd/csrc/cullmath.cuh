@@ -93,11 +93,12 @@ NV_DEV f3 sphere_center(const NvCullData& cd, f3 local, f3 q, float qw, float sc
 // drawcull.comp.glsl:77-82 / clustercull.comp.glsl:103-108
 NV_DEV bool frustum_test(const NvCullData& cd, f3 c, float r)
 {
-	bool vis = true;
-	vis = vis && c.z * cd.frustum[1] - __builtin_fabsf(c.x) * cd.frustum[0] > -r;
-	vis = vis && c.z * cd.frustum[3] - __builtin_fabsf(c.y) * cd.frustum[2] > -r;
-	vis = vis && c.z + r > cd.znear && c.z - r < cd.zfar;
-	return vis;
+	// all four comparisons are evaluated (they are side-effect free), then ANDed: no exec-mask branching
+	const bool sx = c.z * cd.frustum[1] - __builtin_fabsf(c.x) * cd.frustum[0] > -r;
+	const bool sy = c.z * cd.frustum[3] - __builtin_fabsf(c.y) * cd.frustum[2] > -r;
+	const bool zn = c.z + r > cd.znear;
+	const bool zf = c.z - r < cd.zfar;
+	return (sx & sy) & (zn & zf);
 }
 
 // math.h:41-44 with camera_position = 0

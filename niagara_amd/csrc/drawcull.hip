@@ -126,7 +126,7 @@ __global__ __launch_bounds__(DC_THREADS) void drawcull_kernel(DrawArgs a)
 	__shared__ uint32_t s_flags[DC_TMAX];
 	__shared__ uint32_t s_old[DC_TMAX];
 	__shared__ uint32_t s_part[DC_WAVES];
-	__shared__ uint32_t s_base;
+	__shared__ uint32_t s_scratch[16];
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
@@ -167,27 +167,20 @@ __global__ __launch_bounds__(DC_THREADS) void drawcull_kernel(DrawArgs a)
 		if (lane == 0)
 			s_part[wave] = waveSum;
 		__syncthreads();
-		if (wave == 0)
-		{
-			uint32_t aggregate = 0;
+		uint32_t aggregate = 0;
 #pragma unroll
-			for (int w = 0; w < DC_WAVES; ++w)
-				aggregate += s_part[w];
-			uint32_t exclusive = lookback_exclusive(a.state, a.ctl, tile, epoch, aggregate, base0);
-			if (lane == 0)
-			{
-				s_base = exclusive;
-				if (tile == numTiles - 1)
-				{
-					a.count4[0] = exclusive + aggregate;
-					advance_epoch(a.ctl, epoch);
-				}
-			}
+		for (int w = 0; w < DC_WAVES; ++w)
+			aggregate += s_part[w];
+		const uint32_t exclusive = lookback_exclusive(a.state, a.ctl, tile, epoch, aggregate, base0, s_scratch);
+		if (tid == 0 && tile == numTiles - 1)
+		{
+			a.count4[0] = exclusive + aggregate;
+			advance_epoch(a.ctl, epoch);
 		}
-		__syncthreads();
+		__syncthreads(); // s_part is reused by the emit scan
 
 		// ---- phase 4: ordered emit, 256 draws per step
-		uint32_t running = s_base;
+		uint32_t running = exclusive;
 		for (uint32_t c0 = 0; c0 < n; c0 += DC_THREADS)
 		{
 			const uint32_t c = c0 + tid;

@@ -63,32 +63,42 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 	return v;
 }
 
-// Called by all 64 lanes of ONE wave with wave-uniform arguments.  Publishes this tile's aggregate, looks back
-// for the exclusive prefix, publishes the inclusive prefix and returns the exclusive prefix.
+// Called by ALL threads of a 256-thread workgroup (4 waves) with workgroup-uniform arguments; `scratch` is 16 words
+// of LDS.  Publishes this tile's aggregate, looks back for the exclusive prefix over a 256-tile window per round
+// (wave w inspects tiles tile-1-64w-lane), publishes the inclusive prefix and returns the exclusive prefix to every
+// thread.  With one tile per workgroup and ~1024 tiles all finishing together, the chain resolves in <= 4 rounds.
 // base0 = value of the count word before the pass (what the first atomicAdd of the reference would return).
 __device__ __forceinline__ uint32_t lookback_exclusive(uint64_t* __restrict__ state, OrderCtl* __restrict__ ctl, uint32_t tile,
-                                                       uint32_t epoch, uint32_t aggregate, uint32_t base0)
+                                                       uint32_t epoch, uint32_t aggregate, uint32_t base0, uint32_t* scratch)
 {
-	const uint32_t lane = __lane_id();
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
 
 	if (tile == 0)
 	{
-		if (lane == 0)
+		if (threadIdx.x == 0)
 			__hip_atomic_store(&state[0], pack_state(epoch, ST_PREFIX, base0 + aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		return base0;
 	}
 
-	if (lane == 0)
+	if (threadIdx.x == 0)
 		__hip_atomic_store(&state[tile], pack_state(epoch, ST_AGGREGATE, aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
+	enum : uint32_t
+	{
+		W_CONTINUE = 0, // 64 aggregates, no prefix: add them and keep looking further back
+		W_DONE = 1,     // a prefix was found with nothing unpublished before it
+		W_BLOCKED = 2   // an unpublished tile stands before the first prefix (or there is no prefix): poll again
+	};
+
 	uint32_t exclusive = 0;
-	int64_t look = (int64_t)tile - 1; // nearest predecessor handled by lane 0
+	int64_t look = (int64_t)tile - 1; // nearest predecessor = lane 0 of wave 0
 	uint32_t spins = 0;
 
 	for (;;)
 	{
-		int64_t idx = look - (int64_t)lane;
-		uint32_t status = ST_PREFIX, value = 0; // lanes before tile 0 contribute nothing
+		const int64_t idx = look - (int64_t)(wave * 64u + lane);
+		uint32_t status = ST_PREFIX, value = 0; // positions before tile 0 contribute nothing
 		if (idx >= 0)
 		{
 			uint64_t w = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -97,36 +107,66 @@ __device__ __forceinline__ uint32_t lookback_exclusive(uint64_t* __restrict__ st
 			value = (uint32_t)w;
 		}
 
-		uint64_t prefixMask = __ballot(status == ST_PREFIX);
-		uint64_t invalidMask = __ballot(status == ST_INVALID);
-
+		const uint64_t prefixMask = __ballot(status == ST_PREFIX);
+		const uint64_t invalidMask = __ballot(status == ST_INVALID);
+		uint32_t verdict, partial;
 		if (prefixMask != 0)
 		{
-			uint32_t p = (uint32_t)__builtin_ctzll(prefixMask);
-			uint64_t upto = p == 63 ? ~0ull : ((1ull << (p + 1)) - 1);
-			if ((invalidMask & upto) == 0)
+			const uint32_t p = (uint32_t)__builtin_ctzll(prefixMask);
+			const uint64_t upto = p == 63 ? ~0ull : ((1ull << (p + 1)) - 1);
+			verdict = (invalidMask & upto) == 0 ? (uint32_t)W_DONE : (uint32_t)W_BLOCKED;
+			partial = wave_sum_u32(lane <= p ? value : 0u);
+		}
+		else
+		{
+			verdict = invalidMask == 0 ? (uint32_t)W_CONTINUE : (uint32_t)W_BLOCKED;
+			partial = wave_sum_u32(value);
+		}
+
+		__syncthreads(); // scratch free (previous round's readers are done)
+		if (lane == 0)
+		{
+			scratch[wave] = verdict;
+			scratch[4 + wave] = partial;
+		}
+		__syncthreads();
+
+		// every thread folds the four sub-windows nearest-first
+		uint32_t sum = 0, outcome = W_CONTINUE;
+#pragma unroll
+		for (int w = 0; w < 4; ++w)
+		{
+			if (outcome == W_CONTINUE)
 			{
-				exclusive += wave_sum_u32(lane <= p ? value : 0u);
-				break;
+				const uint32_t v = scratch[w];
+				if (v != W_BLOCKED)
+					sum += scratch[4 + w];
+				outcome = v;
 			}
 		}
-		else if (invalidMask == 0)
+
+		if (outcome == W_DONE)
 		{
-			exclusive += wave_sum_u32(value);
-			look -= 64;
+			exclusive += sum;
+			break;
+		}
+		if (outcome == W_CONTINUE)
+		{
+			exclusive += sum;
+			look -= 256;
 			continue;
 		}
 
 		if (++spins > NV_SPIN_LIMIT)
 		{
-			if (lane == 0)
+			if (threadIdx.x == 0)
 				__hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			break;
 		}
 		__builtin_amdgcn_s_sleep(2);
 	}
 
-	if (lane == 0)
+	if (threadIdx.x == 0)
 		__hip_atomic_store(&state[tile], pack_state(epoch, ST_PREFIX, exclusive + aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	return exclusive;
 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, through gpurun): bash tools_profile.sh <tag> [ENV=VAL ...]
+# usage (on the GPU box, through gpurun): bash tools/profile.sh <tag> [ENV=VAL ...]
 # kernel-trace stats + separate PMC passes of bench.py; summaries land in gpurun_out/prof_<tag>/
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}

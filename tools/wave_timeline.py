@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""wave_timeline.py — development aid: per-wave s_memtime stamps of one clustercull launch (NV_DEBUG_MODE=8).
+
+stamps: 0 kernel entry · 1 segment (commands+draws) loaded · 2 ring filled (issue only) · 3 first ring wait passed ·
+4 cull loop done · 5 after tile-total barrier · 6 look-back done · 7 scatter done
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+os.environ["NV_DEBUG_MODE"] = str(8 | int(os.environ.get("NV_DEBUG_MODE", "0")))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from niagara_amd import host, synth  # noqa: E402
+from niagara_amd import pipeline as P  # noqa: E402
+from niagara_amd._lib import lib  # noqa: E402
+
+ctx = P.Context(0)
+dev = ctx.device
+draws, meshlets, commands, n = synth.cluster_scene(15625, 10)
+cd = host.build_cull_data(draw_count=len(draws), cullingEnabled=1, clusterBackfaceEnabled=1)
+db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+ctx.upload_meshlets(mlb, len(meshlets))
+dccb = torch.from_numpy(synth.count4_for(n).view(np.int32).copy()).to(dev)
+cib = torch.zeros(n * 64 + 256, dtype=torch.int32, device=dev)
+ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+for _ in range(5):
+    ccb.zero_()
+    ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
+torch.cuda.synchronize()
+waves = 256 * int(os.environ.get("NV_CC_BLOCKS_PER_CU", "4")) * 4
+out = np.zeros((waves, 8), np.uint64)
+lib.nv_debug_read_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+rc = lib.nv_debug_read_timing(ctx.h, out.ctypes.data_as(C.c_void_p), waves)
+assert rc == 0, rc
+t = out.astype(np.int64)
+t0 = t[:, 0].min()
+rel = (t - t0)
+names = ["entry", "segment loaded", "ring issued", "first data", "cull loop done", "after barrier", "look-back done", "scatter done"]
+print("s_memtime ticks relative to the earliest wave entry (min / median / max over %d waves)" % waves)
+for i, nm in enumerate(names):
+    col = rel[:, i]
+    print("%-16s %9d %9d %9d" % (nm, col.min(), np.median(col), col.max()))
+d = np.diff(rel, axis=1)
+print("per-wave phase durations (median):", dict(zip(names[1:], np.median(d, axis=0).astype(int))))
+for i, nm in enumerate(names[1:]):
+    col = d[:, i]
+    print("%-16s p0 %7d p10 %7d p50 %7d p90 %7d p99 %7d p100 %7d" % ((nm,) + tuple(np.percentile(col, [0, 10, 50, 90, 99, 100]).astype(int))))
+tot = rel[:, 7] - rel[:, 0]
+print("entry->end      ", np.percentile(tot, [0, 10, 50, 90, 99, 100]).astype(int))
+busy = rel[:, 4] - rel[:, 0]
+print("entry->loop done", np.percentile(busy, [0, 10, 50, 90, 99, 100]).astype(int))
