@@ -86,13 +86,9 @@ def main():
         ctx.upload_meshlets(mlb, copies * n_meshlets)
     torch.cuda.synchronize()
 
-    def step(i, ev=None):
+    def step(i):
         ccb[0:1].zero_()
-        if ev is not None:
-            ev[0].record()
         ctx.clustercull(cd, 0, dcbs[i % copies], dccb, db, mlb, None, None, cib, ccb)
-        if ev is not None:
-            ev[1].record()
         if world > 1:
             ctx.pack_counts(None, dccb, ccb, counts)
             dist.all_reduce(counts)
@@ -104,15 +100,18 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
 
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # per-kernel HIP events are recorded by the library on the launch stream (nv_profile_*), inside the timed region
+    ctx.profile(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i, events[i])
+        step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile(False)
     ctx.status()
 
     visible = int(ccb[0].item())
@@ -124,12 +123,17 @@ def main():
     else:
         total_visible = visible
 
-    kernel_ms = sorted(a.elapsed_time(b) for a, b in events)
-    kernel_avg_s = (sum(kernel_ms) / len(kernel_ms)) * 1e-3
-    kernel_med_s = kernel_ms[len(kernel_ms) // 2] * 1e-3
+    cull_ms, cull_n = prof["cluster_cull"]
+    scat_ms, scat_n = prof["cluster_scatter"]
+    kernel_avg_s = cull_ms / max(1, cull_n) * 1e-3      # dominant kernel: cluster_mask_kernel
+    scatter_avg_s = scat_ms / max(1, scat_n) * 1e-3
 
-    # algorithmic bytes per launch: 12 cull bytes per meshlet + (20 + 48) per command + 4 per survivor + 4
-    algo_bytes = n_meshlets * (24 if args.aos else 12) + n_cmd * 68 + visible * 4 + 4
+    # algorithmic bytes.  Whole pass: 12 cull bytes per meshlet + (20 + 48) per command + 4 per survivor
+    # + 4.  The dominant kernel moves the first two terms plus its 8-byte ballot per command; the survivors' 4 bytes
+    # belong to the scatter kernel.
+    per_meshlet = 24 if args.aos else 12
+    pass_bytes = n_meshlets * per_meshlet + n_cmd * 68 + visible * 4 + 4
+    algo_bytes = n_meshlets * per_meshlet + n_cmd * 68 + n_cmd * 8
     achieved = algo_bytes / kernel_avg_s / 1e9
 
     if rank == 0:
@@ -152,8 +156,11 @@ def main():
                        "input_copies_rotated": copies, "meshlet_layout": "AoS24" if args.aos else "SoA12",
                        "visible_per_gpu": visible, "visible_total": total_visible, "sharding": "commands x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "clustercull_kernel", "kernel_avg_us": kernel_avg_s * 1e6,
-                         "kernel_median_us": kernel_med_s * 1e6, "algorithmic_bytes": algo_bytes},
+                         "traffic": None, "kernel": "cluster_mask_kernel", "kernel_avg_us": kernel_avg_s * 1e6,
+                         "algorithmic_bytes": algo_bytes, "launches_timed": cull_n,
+                         "scatter_kernel_avg_us": scatter_avg_s * 1e6,
+                         "pass_algorithmic_bytes": pass_bytes,
+                         "pass_frac": pass_bytes / (kernel_avg_s + scatter_avg_s) / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, cd, draws, meshlets, n_cmd, visible)

@@ -10,6 +10,18 @@
 namespace nv
 {
 
+// Per-tile survivor counts handed from the cull kernel to the scatter kernel (clustercull.hip).  Two banks: a pass adds
+// into counts[parity] and clears counts[parity ^ 1] for the next one, so nothing is memset between passes and a
+// captured hipGraph replays correctly.
+constexpr uint32_t CC_MAX_SCATTER_TILES = 512;
+struct ClusterCounts
+{
+	uint32_t parity;   // read by the cull kernel; flipped by one thread of the scatter kernel
+	uint32_t k2parity; // the parity of the running pass, written by the cull kernel for the scatter kernel
+	uint32_t pad[30];
+	uint32_t counts[2][CC_MAX_SCATTER_TILES];
+};
+
 struct ClusterArgs
 {
 	NvCullData cd;
@@ -24,6 +36,9 @@ struct ClusterArgs
 	uint32_t* __restrict__ clusterIndices;
 	uint32_t* __restrict__ clusterCount4;
 	uint32_t* __restrict__ payloadCounts; // taskcull only
+	uint64_t* __restrict__ masks; // scratch: one 64-bit ballot per task command
+	ClusterCounts* __restrict__ tileCounts;
+	uint32_t scatterTiles; // grid of the scatter kernel (<= CC_MAX_SCATTER_TILES)
 	uint64_t* __restrict__ state;
 	OrderCtl* __restrict__ ctl;
 	uint32_t stateCapacity;

@@ -8,11 +8,10 @@
 //     through the vector memory path: bounds (4 x fp16, 8 B/lane = 512 B/wave) and cone (4 x s8, 4 B/lane), both
 //     perfectly coalesced from the SoA mirror built by nv_upload_meshlets (the 24-B AoS records are read in place
 //     when no mirror exists);
-//   * a workgroup (4 waves) owns a TILE of 4*K consecutive commands; each wave issues the loads of its K commands
-//     up front (K*2 independent vector loads in flight per lane), then runs the tests; a command's result is one
-//     64-bit ballot held in SGPRs — no LDS staging of survivors;
-//   * survivors are appended in command-major, lane-minor order through ordered.cuh (chained scan across tiles),
-//     1 ticket + 2 eight-byte publishes per 256*K meshlets instead of 1 global atomic per survivor;
+//   * a wave walks its commands with a ring of CC_D commands' meshlet loads in flight (counted vmcnt waits); a
+//     command's result is one 64-bit ballot — no per-survivor atomics, no LDS staging of survivors;
+//   * survivors are appended in command-major, lane-minor order by a second small kernel through ordered.cuh
+//     (chained scan across <= 256 workgroups), instead of 1 global atomic per survivor;
 //   * visibility bits (late pass) are updated with <= 3 word-level atomics per wave built from the ballots
 //     instead of one atomicOr/atomicAnd per lane (clustercull.comp.glsl:125-131);
 //   * tests are pure predicates ANDed together, so the cheap frustum test runs first and the cone / HiZ tests are
@@ -212,15 +211,20 @@ NV_DEV uint32_t indirect_command_count(const ClusterArgs& a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// ordered cluster append (clustercull.comp.glsl)
+// ordered cluster append (clustercull.comp.glsl) = two launches on the stream:
 //
-// Static tiles: the grid is a fixed, co-resident set of G workgroups (context.hip sizes it to 4 per CU); tile t covers
-// commands [t*T, (t+1)*T) with T = ceil(numCmds / G) (device-computed from the indirect words, clamped to CC_TMAX),
-// so a pass is ONE tile per workgroup and the chained scan runs once per workgroup at the tail, after its whole
-// range has been culled: phase 1 cull -> 64-bit ballots in LDS, phase 2 tile total, phase 3 look-back across tiles,
-// phase 4 ordered scatter from the LDS ballots.  No tickets, no per-tile atomics.
-constexpr uint32_t CC_TMAX = 1024; // commands per tile: 8 KiB of ballots in LDS
-constexpr int CC_D = 6;            // ring slots per wave: CC_D - 1 commands' meshlet loads in flight behind the one being tested
+//   K1 cluster_mask_kernel    cull every command -> one 64-bit ballot per command in a scratch array (8 B/command).
+//                             A pure map, so work is dealt out for BALANCE, not for order: commands are cut into chunks
+//                             of CC_CHUNK and wave w takes chunks w, w+W, w+2W, ...  (a tile-per-workgroup assignment
+//                             measured 2.5x spread between the fastest and slowest wave, because the commands of a
+//                             visible draw run the cone test on top of the frustum test and visible draws cluster).
+//   K2 cluster_scatter_kernel one workgroup per CU owns a contiguous range of commands, sums its ballots' popcounts,
+//                             runs the chained scan across the (<= 256, co-resident) workgroups — one 256-wide
+//                             look-back round — and scatters the IDs in command-major, lane-minor order.
+//
+// The ballots cost 8 B per 64 meshlets of extra traffic (1 %), the extra launch boundary ~2 us.
+constexpr uint32_t CC_CHUNK = 4; // consecutive commands per dealt chunk
+constexpr int CC_D = 6;          // ring slots per wave: CC_D - 1 commands' meshlet loads in flight behind the one being tested
 
 // lane l of a wave holds the l-th command of the wave's current 64-command segment (one coalesced 1280-B read
 // instead of 64 dependent scalar loads) and the MeshDraw it points at; fields are broadcast with v_readlane as the
@@ -305,220 +309,302 @@ NV_DEV void ring_wait(RingSlot& s)
 		asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.bounds), "+v"(s.cone) : "i"(YOUNGER * 2) : "memory");
 }
 
-template <bool LATE, bool SOA, bool BITS>
-__global__ __launch_bounds__(CC_THREADS) void clustercull_kernel(ClusterArgs a)
+// commands per scatter tile: the same function of the indirect words in both kernels
+NV_DEV uint32_t scatter_tile_commands(uint32_t numCmds, uint32_t tiles)
 {
-	__shared__ uint64_t s_mask[CC_TMAX];
+	uint32_t T = ((numCmds + tiles - 1) / tiles + CC_THREADS - 1) / CC_THREADS * CC_THREADS;
+	return T ? T : CC_THREADS;
+}
+
+// wave w's c-th command (c counts through the wave's chunks in order)
+NV_DEV uint32_t dealt_command(uint32_t w, uint32_t W, uint32_t c)
+{
+	return ((c / CC_CHUNK) * W + w) * CC_CHUNK + c % CC_CHUNK;
+}
+
+template <bool LATE, bool SOA, bool BITS>
+__global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
+{
+	__shared__ uint64_t s_mask[CC_WAVES][64];
+
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t W = gridDim.x * CC_WAVES;
+	const uint32_t w = blockIdx.x * CC_WAVES + wave;
+
+	const uint32_t numCmds = indirect_command_count(a);
+	const uint32_t numChunks = (numCmds + CC_CHUNK - 1) / CC_CHUNK;
+	const uint32_t myChunks = w < numChunks ? (numChunks - w + W - 1) / W : 0u;
+	const uint32_t myCmds = myChunks * CC_CHUNK; // the last chunk of the pass may run past numCmds: guarded below
+	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles);
+	const uint32_t bank = __hip_atomic_load(&a.tileCounts->parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
+	if (w == 0 && lane == 0)
+		__hip_atomic_store(&a.tileCounts->k2parity, bank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+	// debugMode bit 3: per-wave s_memtime stamps into probeOut (tools/wave_timeline.py); never set in production
+	const bool dbgTime = (a.debugMode & 8u) && a.probeOut;
+	unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.probeOut) + (size_t)w * 8;
+#define NV_STAMP(i) do { if (dbgTime && lane == 0) stamps[i] = __builtin_readcyclecounter(); } while (0)
+	NV_STAMP(0);
+
+	for (uint32_t seg = 0; seg < myCmds; seg += 64)
+	{
+		const uint32_t cnt = myCmds - seg < 64u ? myCmds - seg : 64u;
+
+		// lane l holds the wave's (seg + l)-th command and the MeshDraw it points at
+		const uint32_t myIdx = dealt_command(w, W, seg + lane);
+		SegmentRegs r = {};
+		if (lane < cnt && myIdx < numCmds)
+		{
+			const uint32_t* p = reinterpret_cast<const uint32_t*>(a.commands + myIdx);
+			r.drawId = p[0];
+			r.taskOffset = p[1];
+			r.taskCount = p[2];
+			r.lateDrawVisibility = p[3];
+			r.meshletVisibilityOffset = p[4];
+			if (r.taskCount)
+			{
+				const float4* d = reinterpret_cast<const float4*>(a.draws + r.drawId);
+				r.d0 = d[0];
+				r.d1 = d[1];
+			}
+		}
+		NV_STAMP(1);
+
+		uint32_t curDraw = ~0u;
+		DrawUniform du = {};
+
+		// one command: fields by v_readlane, draw constants re-read only when the draw changes
+		auto run_command = [&](uint32_t c, const LaneData& cur) -> uint64_t
+		{
+			const NvMeshTaskCommand cmd = segment_command(r, c);
+			uint64_t m = 0;
+			if (cmd.taskCount)
+			{
+				if (cmd.drawId != curDraw) // a draw's task commands are consecutive: usually a hit
+				{
+					curDraw = cmd.drawId;
+					du = segment_draw(r, c);
+				}
+				m = cull_command<LATE, BITS>(a, cmd, du, cur, lane);
+			}
+			if (lane == 0)
+				s_mask[wave][c] = m;
+			return m;
+		};
+
+		if (SOA)
+		{
+			// make sure hipcc has waited for its own segment loads before the first uncounted load is issued
+			asm volatile("" : "+v"(r.d0.x), "+v"(r.d1.x), "+v"(r.taskOffset), "+v"(r.meshletVisibilityOffset));
+
+			// indices past the segment are clamped to its last command: redundant but unconditional loads
+			RingSlot ring[CC_D];
+#pragma unroll
+			for (int k = 0; k < CC_D; ++k)
+			{
+				const uint32_t c = (uint32_t)k < cnt ? k : cnt - 1;
+				ring_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, c), __builtin_amdgcn_readlane(r.taskCount, c),
+				                 __builtin_amdgcn_readlane(r.meshletVisibilityOffset, c), lane, 0);
+			}
+			NV_STAMP(2);
+			for (uint32_t i = 0; i < cnt; i += CC_D)
+			{
+#pragma unroll
+				for (int k = 0; k < CC_D; ++k)
+				{
+					const uint32_t c = i + k;
+					ring_wait<BITS, CC_D - 1>(ring[k]);
+					if (i == 0 && k == 0)
+						NV_STAMP(3);
+					uint64_t m = 0;
+					if (c < cnt)
+					{
+						LaneData cur;
+						cur.b0 = (uint32_t)ring[k].bounds;
+						cur.b1 = (uint32_t)(ring[k].bounds >> 32);
+						cur.cone = ring[k].cone;
+						cur.mvbWord = ring[k].mvbWord;
+						m = run_command(c, cur);
+					}
+					const uint32_t cn = c + CC_D < cnt ? c + CC_D : cnt - 1;
+					ring_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, cn), __builtin_amdgcn_readlane(r.taskCount, cn),
+					                 __builtin_amdgcn_readlane(r.meshletVisibilityOffset, cn), lane, m);
+				}
+			}
+			// drain: nothing of the ring may be in flight when the registers are reused
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		else
+		{
+			// AoS records read in place: compiler-scheduled loads, one command ahead
+			LaneData nxt = load_lane<false>(a, __builtin_amdgcn_readlane(r.taskOffset, 0), __builtin_amdgcn_readlane(r.taskCount, 0), lane);
+			if (BITS)
+				nxt.mvbWord = load_mvb_word(a, __builtin_amdgcn_readlane(r.meshletVisibilityOffset, 0), __builtin_amdgcn_readlane(r.taskCount, 0), lane);
+			for (uint32_t c = 0; c < cnt; ++c)
+			{
+				const LaneData cur = nxt;
+				const uint32_t cn = c + 1 < cnt ? c + 1 : cnt - 1;
+				nxt = load_lane<false>(a, __builtin_amdgcn_readlane(r.taskOffset, cn), __builtin_amdgcn_readlane(r.taskCount, cn), lane);
+				if (BITS)
+					nxt.mvbWord = load_mvb_word(a, __builtin_amdgcn_readlane(r.meshletVisibilityOffset, cn), __builtin_amdgcn_readlane(r.taskCount, cn), lane);
+				run_command(c, cur);
+			}
+		}
+		NV_STAMP(4);
+
+		// the segment's ballots leave through LDS: one 8-B store per lane (32-B runs per chunk), after the ring has
+		// drained so that no store sits between counted loads
+		if (lane < cnt && myIdx < numCmds)
+		{
+			const uint64_t m = s_mask[wave][lane];
+			a.masks[myIdx] = m;
+			// survivors per scatter tile: fire-and-forget adds, only from commands that have survivors
+			if (m)
+				atomicAdd(&a.tileCounts->counts[bank][myIdx / T2], (uint32_t)__builtin_popcountll(m));
+		}
+	}
+	NV_STAMP(5);
+#undef NV_STAMP
+}
+
+// K2: contiguous ranges, ordered scatter.  Tile t's append base = count word + survivors of tiles < t, which the cull
+// kernel has already accumulated per tile: no workgroup waits on another, the kernel is a handful of parallel loads,
+// one LDS reduction and the stores.
+template <int DUMMY>
+__global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs a)
+{
 	__shared__ uint32_t s_part[CC_WAVES];
-	__shared__ uint32_t s_scratch[16];
+	__shared__ uint32_t s_sum[CC_WAVES];
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const uint32_t G = gridDim.x;
 
 	const uint32_t numCmds = indirect_command_count(a);
-	uint32_t T = (numCmds + G - 1) / G;
-	T = T < 1 ? 1 : (T > CC_TMAX ? CC_TMAX : T);
-	const uint32_t numTiles = (numCmds + T - 1) / T;
-	const uint32_t epoch = load_epoch(a.ctl);
+	const uint32_t T = scatter_tile_commands(numCmds, a.scatterTiles);
+	const uint32_t numTiles = (numCmds + T - 1) / T; // <= gridDim.x
+	const uint32_t tile = blockIdx.x;
+	const bool dbgNoScatter = a.debugMode & 4u; // experiments only
+
+	// Everything below was written by the cull kernel, i.e. before this launch: plain loads, all issued together.
+	// Both banks of tile counts are read speculatively so that no load waits for the parity word.
+	const uint32_t k2parity = a.tileCounts->k2parity;
 	const uint32_t base0 = a.clusterCount4[0];
-	const bool dbgNoScan = a.debugMode & 1u, dbgNoScatter = a.debugMode & 4u; // experiments only
-	// debugMode bit 3: per-wave s_memtime stamps into probeOut (tools/wave_timeline.py); never set in production
-	const bool dbgTime = (a.debugMode & 8u) && a.probeOut;
-	unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.probeOut) + (size_t)(blockIdx.x * CC_WAVES + wave) * 8;
-#define NV_STAMP(i) do { if (dbgTime && lane == 0) stamps[i] = __builtin_readcyclecounter(); } while (0)
-	NV_STAMP(0);
-
-	for (uint32_t tile = blockIdx.x; tile < numTiles; tile += G)
+	uint32_t cnt0[2] = { 0, 0 }, cnt1[2] = { 0, 0 }; // this thread's tiles tid and tid + 256, per bank
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
 	{
-		const uint32_t first = tile * T;
-		const uint32_t n = numCmds - first < T ? numCmds - first : T;
-
-		// ---- phase 1: each wave walks a contiguous quarter of the tile, CC_D commands' meshlet loads in flight
-		const uint32_t cw = (n + CC_WAVES - 1) / CC_WAVES;
-		const uint32_t wbeg = wave * cw < n ? wave * cw : n;
-		const uint32_t wend = wbeg + cw < n ? wbeg + cw : n;
-		uint32_t waveCount = 0;
-
-		for (uint32_t seg = wbeg; seg < wend; seg += 64)
+		const uint32_t i = j * CC_THREADS + tid;
+		if (i < numTiles)
 		{
-			const uint32_t cnt = wend - seg < 64u ? wend - seg : 64u;
-
-			SegmentRegs r = {};
-			if (lane < cnt)
-			{
-				const uint32_t* p = reinterpret_cast<const uint32_t*>(a.commands + first + seg + lane);
-				r.drawId = p[0];
-				r.taskOffset = p[1];
-				r.taskCount = p[2];
-				r.lateDrawVisibility = p[3];
-				r.meshletVisibilityOffset = p[4];
-				if (r.taskCount)
-				{
-					const float4* d = reinterpret_cast<const float4*>(a.draws + r.drawId);
-					r.d0 = d[0];
-					r.d1 = d[1];
-				}
-			}
-
-			uint32_t curDraw = ~0u;
-			DrawUniform du = {};
-			NV_STAMP(1);
-
-			// body of one command, shared by both load paths
-			auto run_command = [&](uint32_t c, const LaneData& cur) -> uint64_t
-			{
-				const NvMeshTaskCommand cmd = segment_command(r, c);
-				uint64_t m = 0;
-				if (cmd.taskCount)
-				{
-					if (cmd.drawId != curDraw) // a draw's task commands are consecutive: usually a hit
-					{
-						curDraw = cmd.drawId;
-						du = segment_draw(r, c);
-					}
-					m = cull_command<LATE, BITS>(a, cmd, du, cur, lane);
-				}
-				if (lane == 0)
-					s_mask[seg + c] = m;
-				waveCount += (uint32_t)__builtin_popcountll(m);
-				return m;
-			};
-
-			if (SOA)
-			{
-				// make sure hipcc has waited for its own segment loads before the first uncounted load is issued
-				asm volatile("" : "+v"(r.d0.x), "+v"(r.d1.x), "+v"(r.taskOffset), "+v"(r.meshletVisibilityOffset));
-
-				// indices past the segment are clamped to its last command: redundant but unconditional loads
-				RingSlot ring[CC_D];
-#pragma unroll
-				for (int k = 0; k < CC_D; ++k)
-				{
-					const uint32_t c = (uint32_t)k < cnt ? k : cnt - 1;
-					ring_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, c), __builtin_amdgcn_readlane(r.taskCount, c),
-					                 __builtin_amdgcn_readlane(r.meshletVisibilityOffset, c), lane, 0);
-				}
-				NV_STAMP(2);
-				for (uint32_t i = 0; i < cnt; i += CC_D)
-				{
-#pragma unroll
-					for (int k = 0; k < CC_D; ++k)
-					{
-						const uint32_t c = i + k;
-						ring_wait<BITS, CC_D - 1>(ring[k]);
-						if (i == 0 && k == 0)
-							NV_STAMP(3);
-						uint64_t m = 0;
-						if (c < cnt)
-						{
-							LaneData cur;
-							cur.b0 = (uint32_t)ring[k].bounds;
-							cur.b1 = (uint32_t)(ring[k].bounds >> 32);
-							cur.cone = ring[k].cone;
-							cur.mvbWord = ring[k].mvbWord;
-							m = run_command(c, cur);
-						}
-						const uint32_t cn = c + CC_D < cnt ? c + CC_D : cnt - 1;
-						ring_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, cn), __builtin_amdgcn_readlane(r.taskCount, cn),
-						                 __builtin_amdgcn_readlane(r.meshletVisibilityOffset, cn), lane, m);
-					}
-				}
-				// drain: nothing of the ring may be in flight when the registers are reused
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			}
-			else
-			{
-				// AoS records read in place: compiler-scheduled loads, one command ahead
-				LaneData nxt = load_lane<false>(a, __builtin_amdgcn_readlane(r.taskOffset, 0), __builtin_amdgcn_readlane(r.taskCount, 0), lane);
-				if (BITS)
-					nxt.mvbWord = load_mvb_word(a, __builtin_amdgcn_readlane(r.meshletVisibilityOffset, 0), __builtin_amdgcn_readlane(r.taskCount, 0), lane);
-				for (uint32_t c = 0; c < cnt; ++c)
-				{
-					const LaneData cur = nxt;
-					const uint32_t cn = c + 1 < cnt ? c + 1 : cnt - 1;
-					nxt = load_lane<false>(a, __builtin_amdgcn_readlane(r.taskOffset, cn), __builtin_amdgcn_readlane(r.taskCount, cn), lane);
-					if (BITS)
-						nxt.mvbWord = load_mvb_word(a, __builtin_amdgcn_readlane(r.meshletVisibilityOffset, cn), __builtin_amdgcn_readlane(r.taskCount, cn), lane);
-					run_command(c, cur);
-				}
-			}
+			cnt0[j] = a.tileCounts->counts[0][i];
+			cnt1[j] = a.tileCounts->counts[1][i];
 		}
+	}
+	const uint32_t first = tile * T;
+	const uint32_t n = tile < numTiles ? (numCmds - first < T ? numCmds - first : T) : 0u;
+	constexpr int CC_KEEP = 4; // this tile's ballots stay in registers for the usual T <= 1024
+	uint64_t kept[CC_KEEP];
+#pragma unroll
+	for (int j = 0; j < CC_KEEP; ++j)
+	{
+		const uint32_t c = j * CC_THREADS + tid;
+		kept[j] = c < n ? a.masks[first + c] : 0ull;
+	}
 
-		// ---- phase 2 + 3: tile total, chained scan across tiles
-		NV_STAMP(4);
-		if (lane == 0)
-			s_part[wave] = waveCount;
+	const uint32_t bank = k2parity & 1u;
+	// every workgroup clears its entries of the other bank for the next pass; one thread flips the parity the next
+	// cull kernel will read (this pass reads k2parity only)
+	for (uint32_t i = tile * CC_THREADS + tid; i < CC_MAX_SCATTER_TILES; i += gridDim.x * CC_THREADS)
+		a.tileCounts->counts[bank ^ 1u][i] = 0;
+	if (tile == 0 && tid == 0)
+		a.tileCounts->parity = bank ^ 1u;
+	if (tile >= numTiles)
+		return;
+
+	uint32_t before = 0, all = 0;
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		const uint32_t i = j * CC_THREADS + tid;
+		const uint32_t v = bank ? cnt1[j] : cnt0[j];
+		all += v;
+		before += i < tile ? v : 0u;
+	}
+	const uint32_t wBefore = wave_sum_u32(before), wAll = wave_sum_u32(all);
+	if (lane == 0)
+	{
+		s_part[wave] = wBefore;
+		s_sum[wave] = wAll;
+	}
+	__syncthreads();
+	uint32_t exclusive = base0, total = base0;
+#pragma unroll
+	for (int w = 0; w < CC_WAVES; ++w)
+	{
+		exclusive += s_part[w];
+		total += s_sum[w];
+	}
+	if (tid == 0 && tile == numTiles - 1)
+		a.clusterCount4[0] = total; // what the chain of atomicAdds leaves in clusterCount
+	__syncthreads(); // s_part is reused below
+
+	// ---- ordered scatter, 256 commands per step: one command per lane for the scan, one command per iteration for
+	// the (coalesced) stores; clustercull.comp.glsl:137-138 drops entries past CLUSTER_LIMIT
+	uint32_t running = exclusive;
+	for (uint32_t c0 = 0, step = 0; c0 < n; c0 += CC_THREADS, ++step)
+	{
+		const uint32_t c = c0 + tid;
+		uint64_t m;
+		switch (step) // static register indexing for the kept ballots
+		{
+		case 0: m = kept[0]; break;
+		case 1: m = kept[1]; break;
+		case 2: m = kept[2]; break;
+		case 3: m = kept[3]; break;
+		default: m = c < n ? a.masks[first + c] : 0ull; break;
+		}
+		const uint32_t pc = (uint32_t)__builtin_popcountll(m);
+		uint32_t incl = pc;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1)
+		{
+			uint32_t t = __shfl_up(incl, o, 64);
+			if ((int)lane >= o)
+				incl += t;
+		}
+		__syncthreads(); // previous step's s_part readers are done
+		if (lane == 63)
+			s_part[wave] = incl;
 		__syncthreads();
-		NV_STAMP(5);
-		uint32_t aggregate = 0;
+		uint32_t waveBase = running;
 #pragma unroll
 		for (int w = 0; w < CC_WAVES; ++w)
-			aggregate += s_part[w];
-		const uint32_t exclusive = dbgNoScan ? 0u : lookback_exclusive(a.state, a.ctl, tile, epoch, aggregate, base0, s_scratch);
-		if (tid == 0 && tile == numTiles - 1)
 		{
-			a.clusterCount4[0] = exclusive + aggregate; // what the chain of atomicAdds leaves in clusterCount
-			advance_epoch(a.ctl, epoch);                 // every tile has published: nobody polls any more
+			uint32_t p = s_part[w];
+			waveBase += w < (int)wave ? p : 0u;
+			running += p;
 		}
-		__syncthreads(); // s_part is reused by the scatter
+		const uint32_t excl = waveBase + incl - pc;
 
-		NV_STAMP(6);
-		// ---- phase 4: ordered scatter, 256 commands per step, one command per lane for the scan and one command
-		// per iteration for the (coalesced) stores; clustercull.comp.glsl:137-138 drops entries past CLUSTER_LIMIT
-		uint32_t running = exclusive;
-		for (uint32_t c0 = 0; c0 < n; c0 += CC_THREADS)
+		uint64_t owners = dbgNoScatter ? 0ull : __ballot(pc != 0);
+		while (owners)
 		{
-			const uint32_t c = c0 + tid;
-			const uint64_t m = c < n ? s_mask[c] : 0ull;
-			const uint32_t pc = (uint32_t)__builtin_popcountll(m);
-			uint32_t incl = pc;
-#pragma unroll
-			for (int o = 1; o < 64; o <<= 1)
+			const int src = __builtin_ctzll(owners);
+			owners &= owners - 1;
+			const uint32_t mlo = __builtin_amdgcn_readlane((uint32_t)m, src);
+			const uint32_t mhi = __builtin_amdgcn_readlane((uint32_t)(m >> 32), src);
+			const uint32_t off = __builtin_amdgcn_readlane(excl, src);
+			const uint64_t ms = ((uint64_t)mhi << 32) | mlo;
+			if (ms >> lane & 1ull)
 			{
-				uint32_t t = __shfl_up(incl, o, 64);
-				if ((int)lane >= o)
-					incl += t;
-			}
-			__syncthreads(); // previous step's s_part readers are done
-			if (lane == 63)
-				s_part[wave] = incl;
-			__syncthreads();
-			uint32_t waveBase = running;
-#pragma unroll
-			for (int w = 0; w < CC_WAVES; ++w)
-			{
-				uint32_t p = s_part[w];
-				waveBase += w < (int)wave ? p : 0u;
-				running += p;
-			}
-			const uint32_t excl = waveBase + incl - pc;
-
-			uint64_t owners = dbgNoScatter ? 0ull : __ballot(pc != 0);
-			while (owners)
-			{
-				const int src = __builtin_ctzll(owners);
-				owners &= owners - 1;
-				const uint32_t mlo = __builtin_amdgcn_readlane((uint32_t)m, src);
-				const uint32_t mhi = __builtin_amdgcn_readlane((uint32_t)(m >> 32), src);
-				const uint32_t off = __builtin_amdgcn_readlane(excl, src);
-				const uint64_t ms = ((uint64_t)mhi << 32) | mlo;
-				if (ms >> lane & 1ull)
-				{
-					uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-					uint32_t index = off + rank;
-					if (index < NV_CLUSTER_LIMIT)
-						a.clusterIndices[index] = (first + c0 + wave * 64 + src) | (lane << 24);
-				}
+				uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+				uint32_t index = off + rank;
+				if (index < NV_CLUSTER_LIMIT)
+					a.clusterIndices[index] = (first + c0 + wave * 64 + src) | (lane << 24);
 			}
 		}
-		__syncthreads(); // s_mask is rewritten by the next tile
-		NV_STAMP(7);
-
-		if (tile == numTiles - 1 && ((epoch + 1) & 0x3fffffffu) == 0)
-			for (uint32_t i = tid; i < a.stateCapacity; i += CC_THREADS) // epoch wrapped: drop 2^30-launch-old tags
-				a.state[i] = 0;
 	}
 }
 
@@ -637,31 +723,40 @@ static void launch_cc(hipStream_t stream, const ClusterArgs& a, uint32_t gridBlo
 {
 	dim3 grid(gridBlocks), block(CC_THREADS);
 	if (a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0)
-		hipLaunchKernelGGL((clustercull_kernel<LATE, SOA, true>), grid, block, 0, stream, a);
+		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, true>), grid, block, 0, stream, a);
 	else
-		hipLaunchKernelGGL((clustercull_kernel<LATE, SOA, false>), grid, block, 0, stream, a);
+		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, false>), grid, block, 0, stream, a);
 }
 
-int launch_clustercull(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t gridBlocks)
+// any grid size (pure map)
+int launch_cluster_mask(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t maskBlocks)
 {
 	if (late)
 	{
 		if (soa)
-			launch_cc<true, true>(stream, a, gridBlocks);
+			launch_cc<true, true>(stream, a, maskBlocks);
 		else
-			launch_cc<true, false>(stream, a, gridBlocks);
+			launch_cc<true, false>(stream, a, maskBlocks);
 	}
 	else
 	{
 		if (soa)
-			launch_cc<false, true>(stream, a, gridBlocks);
+			launch_cc<false, true>(stream, a, maskBlocks);
 		else
-			launch_cc<false, false>(stream, a, gridBlocks);
+			launch_cc<false, false>(stream, a, maskBlocks);
 	}
 	return (int)hipGetLastError();
 }
 
-uint32_t clustercull_max_tiles(uint32_t gridBlocks) { return (gridBlocks > NV_TASK_WGLIMIT / CC_TMAX ? gridBlocks : NV_TASK_WGLIMIT / CC_TMAX) + 2; }
+// scatterBlocks workgroups wait on each other: the grid must be co-resident (context.hip launches one per CU)
+int launch_cluster_scatter(hipStream_t stream, const ClusterArgs& a, uint32_t scatterBlocks)
+{
+	hipLaunchKernelGGL((cluster_scatter_kernel<0>), dim3(scatterBlocks), dim3(CC_THREADS), 0, stream, a);
+	return (int)hipGetLastError();
+}
+
+uint32_t clustercull_max_tiles(uint32_t scatterBlocks) { return scatterBlocks + 2; }
+size_t clustercull_mask_bytes() { return (size_t)(NV_TASK_WGLIMIT + 64) * sizeof(uint64_t); }
 
 int launch_taskcull(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t gridBlocks)
 {

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <new>
+#include <vector>
 #include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
@@ -16,7 +17,9 @@
 namespace nv
 {
 
-int launch_clustercull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t gridBlocks);
+int launch_cluster_mask(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t maskBlocks);
+int launch_cluster_scatter(hipStream_t, const ClusterArgs&, uint32_t scatterBlocks);
+size_t clustercull_mask_bytes();
 int launch_taskcull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t gridBlocks);
 int launch_probe(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
 int launch_soa_split(hipStream_t, const NvMeshlet*, uint32_t count, uint32_t padded, uint2* bounds, uint32_t* cones);
@@ -30,6 +33,12 @@ int launch_depthreduce(hipStream_t, const float* depth, uint32_t w, uint32_t h, 
 
 } // namespace nv
 
+struct ProfRecord
+{
+	int slot;
+	hipEvent_t begin, end;
+};
+
 struct nv_context
 {
 	int device;
@@ -37,6 +46,8 @@ struct nv_context
 	nv::OrderCtl* ctl;
 	uint64_t* state;
 	uint32_t stateCapacity;
+	uint64_t* masks; // per-command ballots between the two clustercull launches
+	nv::ClusterCounts* tileCounts;
 	// SoA mirror of the meshlet cull bytes
 	const NvMeshlet* mirroredFrom;
 	uint32_t mirroredCount;
@@ -46,6 +57,9 @@ struct nv_context
 	// tuning knobs (environment, read once in nv_create): NV_DEBUG_MODE bit mask, NV_CC_BLOCKS_PER_CU
 	uint32_t debugMode;
 	uint32_t ccBlocksPerCU;
+	// nv_profile_*: event pairs recorded on the launch stream, drained by nv_profile_read
+	int profiling;
+	std::vector<ProfRecord>* prof;
 	float* timing; // NV_DEBUG_MODE bit 3: 8 x u64 stamps per wave of the last clustercull
 };
 
@@ -69,6 +83,24 @@ struct DeviceGuard
 };
 
 uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// profiling: returns an event recorded on `stream` now, or nullptr when profiling is off
+hipEvent_t prof_mark(nv_context* ctx, hipStream_t stream)
+{
+	if (!ctx->profiling)
+		return nullptr;
+	hipEvent_t e = nullptr;
+	if (hipEventCreate(&e) != hipSuccess)
+		return nullptr;
+	(void)hipEventRecord(e, stream);
+	return e;
+}
+
+void prof_push(nv_context* ctx, int slot, hipEvent_t b, hipEvent_t e)
+{
+	if (b && e && ctx->prof)
+		ctx->prof->push_back(ProfRecord{ slot, b, e });
+}
 
 NvPyramidDesc null_pyramid()
 {
@@ -97,6 +129,13 @@ int ensure_state(nv_context* ctx, uint32_t tiles)
 		return (int)e;
 	ctx->stateCapacity = tiles;
 	return NV_OK;
+}
+
+// one scatter workgroup per CU, capped by the per-tile count table
+uint32_t scatter_grid(const nv_context* ctx)
+{
+	uint32_t g = (uint32_t)ctx->numCUs;
+	return g > nv::CC_MAX_SCATTER_TILES ? nv::CC_MAX_SCATTER_TILES : g;
 }
 
 // co-resident grid of the ordered passes (ordered.cuh): blocksPerCU workgroups of 256 threads per CU
@@ -137,11 +176,11 @@ int nv_create(nv_context** out_ctx, int device)
 		return (int)e;
 	}
 	ctx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-	ctx->ccBlocksPerCU = 4;
+	ctx->ccBlocksPerCU = 6;
 	if (const char* v = getenv("NV_DEBUG_MODE"))
 		ctx->debugMode = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_CC_BLOCKS_PER_CU"))
-		ctx->ccBlocksPerCU = (uint32_t)atoi(v) ? (uint32_t)atoi(v) : 4;
+		ctx->ccBlocksPerCU = (uint32_t)atoi(v) ? (uint32_t)atoi(v) : 6;
 
 	e = hipMalloc(&ctx->ctl, sizeof(nv::OrderCtl));
 	if (e == hipSuccess)
@@ -157,8 +196,14 @@ int nv_create(nv_context** out_ctx, int device)
 		return e == hipErrorOutOfMemory ? NV_ENOMEM : (int)e;
 	}
 
+	if (hipMalloc(&ctx->masks, nv::clustercull_mask_bytes()) != hipSuccess || hipMalloc(&ctx->tileCounts, sizeof(nv::ClusterCounts)) != hipSuccess ||
+	    hipMemset(ctx->tileCounts, 0, sizeof(nv::ClusterCounts)) != hipSuccess)
+	{
+		nv_destroy(ctx);
+		return NV_ENOMEM;
+	}
 	// one granule per tile of the largest pass
-	uint32_t tiles = nv::clustercull_max_tiles(persistent_grid(ctx, ctx->ccBlocksPerCU));
+	uint32_t tiles = nv::clustercull_max_tiles(persistent_grid(ctx, 4));
 	int rc = ensure_state(ctx, tiles < (1u << 16) ? (1u << 16) : tiles);
 	if (rc != NV_OK)
 	{
@@ -179,12 +224,17 @@ void nv_destroy(nv_context* ctx)
 		(void)hipFree(ctx->ctl);
 	if (ctx->state)
 		(void)hipFree(ctx->state);
+	if (ctx->masks)
+		(void)hipFree(ctx->masks);
+	if (ctx->tileCounts)
+		(void)hipFree(ctx->tileCounts);
 	if (ctx->soaBounds)
 		(void)hipFree(ctx->soaBounds);
 	if (ctx->soaCones)
 		(void)hipFree(ctx->soaCones);
 	if (ctx->timing)
 		(void)hipFree(ctx->timing);
+	delete ctx->prof;
 	delete ctx;
 }
 
@@ -208,9 +258,67 @@ int nv_status(nv_context* ctx, void* stream)
 		init.epoch = 1;
 		(void)hipMemcpy(ctx->ctl, &init, sizeof(init), hipMemcpyHostToDevice);
 		(void)hipMemset(ctx->state, 0, (size_t)ctx->stateCapacity * sizeof(uint64_t));
+		(void)hipMemset(ctx->tileCounts, 0, sizeof(nv::ClusterCounts));
 		return NV_ESTATE;
 	}
 	return NV_OK;
+}
+
+int nv_profile_enable(nv_context* ctx, int enabled)
+{
+	if (!ctx)
+		return NV_EINVAL;
+	if (!ctx->prof)
+		ctx->prof = new (std::nothrow) std::vector<ProfRecord>();
+	if (!ctx->prof)
+		return NV_ENOMEM;
+	ctx->profiling = enabled ? 1 : 0;
+	return NV_OK;
+}
+
+int nv_profile_read(nv_context* ctx, float out_ms[NV_PROF_SLOTS], uint32_t out_count[NV_PROF_SLOTS])
+{
+	if (!ctx || !out_ms || !out_count)
+		return NV_EINVAL;
+	for (int i = 0; i < NV_PROF_SLOTS; ++i)
+	{
+		out_ms[i] = 0.0f;
+		out_count[i] = 0;
+	}
+	if (!ctx->prof)
+		return NV_OK;
+	DeviceGuard guard(ctx->device);
+	int rc = NV_OK;
+	for (ProfRecord& r : *ctx->prof)
+	{
+		float ms = 0.0f;
+		hipError_t e = hipEventSynchronize(r.end);
+		if (e == hipSuccess)
+			e = hipEventElapsedTime(&ms, r.begin, r.end);
+		if (e == hipSuccess && r.slot >= 0 && r.slot < NV_PROF_SLOTS)
+		{
+			out_ms[r.slot] += ms;
+			out_count[r.slot] += 1;
+		}
+		else if (e != hipSuccess)
+			rc = (int)e;
+	}
+	// events are shared between adjacent records (end of one = begin of the next): destroy each once
+	std::vector<hipEvent_t> seen;
+	for (ProfRecord& r : *ctx->prof)
+		for (hipEvent_t ev : { r.begin, r.end })
+		{
+			bool dup = false;
+			for (hipEvent_t s : seen)
+				dup = dup || s == ev;
+			if (!dup)
+			{
+				seen.push_back(ev);
+				(void)hipEventDestroy(ev);
+			}
+		}
+	ctx->prof->clear();
+	return rc;
 }
 
 int nv_upload_meshlets(nv_context* ctx, void* stream, const NvMeshlet* d_meshlets, uint32_t meshletCount)
@@ -272,7 +380,10 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 	a.state = ctx->state;
 	a.ctl = ctx->ctl;
 	a.stateCapacity = ctx->stateCapacity;
-	return nv::launch_drawcull((hipStream_t)stream, a, late, task, grid);
+	hipEvent_t e0 = prof_mark(ctx, (hipStream_t)stream);
+	rc = nv::launch_drawcull((hipStream_t)stream, a, late, task, grid);
+	prof_push(ctx, NV_PROF_DRAWCULL, e0, prof_mark(ctx, (hipStream_t)stream));
+	return rc;
 }
 
 int nv_tasksubmit(nv_context* ctx, void* stream, uint32_t* d_count4, NvMeshTaskCommand* d_commands)
@@ -304,6 +415,9 @@ static int fill_cluster_args(nv_context* ctx, nv::ClusterArgs& a, const NvCullDa
 	a.soaBounds = soa ? ctx->soaBounds : nullptr;
 	a.soaCones = soa ? ctx->soaCones : nullptr;
 	a.mvb = d_meshletVisibility;
+	a.masks = ctx->masks;
+	a.tileCounts = ctx->tileCounts;
+	a.scatterTiles = scatter_grid(ctx);
 	a.state = ctx->state;
 	a.ctl = ctx->ctl;
 	a.stateCapacity = ctx->stateCapacity;
@@ -331,7 +445,17 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 			(void)hipMalloc(&ctx->timing, (size_t)persistent_grid(ctx, ctx->ccBlocksPerCU) * 4 * 8 * sizeof(unsigned long long));
 		a.probeOut = ctx->timing;
 	}
-	return nv::launch_clustercull((hipStream_t)stream, a, late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU));
+	// two pure maps: the cull kernel also accumulates survivors per scatter tile, so no workgroup waits on another
+	hipStream_t s = (hipStream_t)stream;
+	hipEvent_t e0 = prof_mark(ctx, s);
+	rc = nv::launch_cluster_mask(s, a, late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU));
+	hipEvent_t e1 = prof_mark(ctx, s);
+	if (rc == 0 && !(ctx->debugMode & 16u)) // bit 4 (experiments): ballots only
+		rc = nv::launch_cluster_scatter(s, a, a.scatterTiles);
+	hipEvent_t e2 = prof_mark(ctx, s);
+	prof_push(ctx, NV_PROF_CLUSTER_CULL, e0, e1);
+	prof_push(ctx, NV_PROF_CLUSTER_SCATTER, e1 ? e1 : nullptr, e2);
+	return rc;
 }
 
 int nv_clustersubmit(nv_context* ctx, void* stream, uint32_t* d_clusterCount4, uint32_t* d_clusterIndices)
@@ -364,7 +488,10 @@ int nv_depthreduce(nv_context* ctx, void* stream, const float* d_depth, uint32_t
 	if (!ctx || !d_depth || !pyramid || !pyramid->d_base || !width || !height || !pyramid->levels || pyramid->levels > NV_MAX_MIPS)
 		return NV_EINVAL;
 	DeviceGuard guard(ctx->device);
-	return nv::launch_depthreduce((hipStream_t)stream, d_depth, width, height, *pyramid);
+	hipEvent_t e0 = prof_mark(ctx, (hipStream_t)stream);
+	int rc = nv::launch_depthreduce((hipStream_t)stream, d_depth, width, height, *pyramid);
+	prof_push(ctx, NV_PROF_DEPTHREDUCE, e0, prof_mark(ctx, (hipStream_t)stream));
+	return rc;
 }
 
 // development aid (not part of the public header): copies the NV_DEBUG_MODE bit-3 wave stamps to the host

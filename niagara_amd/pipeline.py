@@ -60,6 +60,16 @@ class Context:
     def status(self):
         check(lib.nv_status(self.h, _stream()), "nv_status")
 
+    def profile(self, enabled):
+        check(lib.nv_profile_enable(self.h, int(enabled)), "nv_profile_enable")
+
+    def profile_read(self):
+        """{slot: (total_ms, launches)} for cluster_cull, cluster_scatter, drawcull, depthreduce"""
+        ms, cnt = (C.c_float * 4)(), (C.c_uint32 * 4)()
+        check(lib.nv_profile_read(self.h, C.byref(ms), C.byref(cnt)), "nv_profile_read")
+        names = ("cluster_cull", "cluster_scatter", "drawcull", "depthreduce")
+        return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(names)}
+
     # ---- passes (argument order = descriptor order of the reference dispatches)
     def upload_meshlets(self, mlb, count):
         check(lib.nv_upload_meshlets(self.h, _stream(), _ptr(mlb), count), "nv_upload_meshlets")

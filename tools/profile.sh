@@ -30,6 +30,6 @@ for d in sorted(glob.glob(out + "/pmc*")):
         for row in csv.DictReader(open(f)):
             acc[row["Kernel_Name"][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, cs in acc.items():
-            if "clustercull" in k or "drawcull" in k or "reduce" in k:
+            if "cluster" in k or "drawcull" in k or "reduce" in k:
                 print(os.path.basename(d), k, {c: round(sum(v) / len(v), 1) for c, v in cs.items()}, "n=%d" % len(next(iter(cs.values()))))
 PY

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """wave_timeline.py — development aid: per-wave s_memtime stamps of one clustercull launch (NV_DEBUG_MODE=8).
 
-stamps: 0 kernel entry · 1 segment (commands+draws) loaded · 2 ring filled (issue only) · 3 first ring wait passed ·
-4 cull loop done · 5 after tile-total barrier · 6 look-back done · 7 scatter done
+stamps (cluster_mask_kernel, last segment of each wave): 0 kernel entry · 1 segment (commands+draws) loaded ·
+2 ring filled (issue only) · 3 first ring wait passed · 4 cull loop done · 5 ballots stored / wave end
 """
 import ctypes as C
 import os
@@ -31,15 +31,15 @@ for _ in range(5):
     ccb.zero_()
     ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
 torch.cuda.synchronize()
-waves = 256 * int(os.environ.get("NV_CC_BLOCKS_PER_CU", "4")) * 4
+waves = 256 * int(os.environ.get("NV_CC_BLOCKS_PER_CU", "6")) * 4
 out = np.zeros((waves, 8), np.uint64)
 lib.nv_debug_read_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 rc = lib.nv_debug_read_timing(ctx.h, out.ctypes.data_as(C.c_void_p), waves)
 assert rc == 0, rc
 t = out.astype(np.int64)
 t0 = t[:, 0].min()
-rel = (t - t0)
-names = ["entry", "segment loaded", "ring issued", "first data", "cull loop done", "after barrier", "look-back done", "scatter done"]
+rel = (t - t0)[:, :6]
+names = ["entry", "segment loaded", "ring issued", "first data", "cull loop done", "wave end"]
 print("s_memtime ticks relative to the earliest wave entry (min / median / max over %d waves)" % waves)
 for i, nm in enumerate(names):
     col = rel[:, i]
@@ -49,7 +49,12 @@ print("per-wave phase durations (median):", dict(zip(names[1:], np.median(d, axi
 for i, nm in enumerate(names[1:]):
     col = d[:, i]
     print("%-16s p0 %7d p10 %7d p50 %7d p90 %7d p99 %7d p100 %7d" % ((nm,) + tuple(np.percentile(col, [0, 10, 50, 90, 99, 100]).astype(int))))
-tot = rel[:, 7] - rel[:, 0]
+tot = rel[:, 5] - rel[:, 0]
 print("entry->end      ", np.percentile(tot, [0, 10, 50, 90, 99, 100]).astype(int))
 busy = rel[:, 4] - rel[:, 0]
 print("entry->loop done", np.percentile(busy, [0, 10, 50, 90, 99, 100]).astype(int))
+
+# per-workgroup span (stamps of one workgroup share an XCD clock): balance across workgroups
+blk = rel.reshape(-1, 4, 6)
+span = blk[:, :, 5].max(axis=1) - blk[:, :, 0].min(axis=1)
+print("per-workgroup span", np.percentile(span, [0, 10, 50, 90, 99, 100]).astype(int))
