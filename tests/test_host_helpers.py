@@ -1,0 +1,54 @@
+"""Host-side helpers of the C ABI (no GPU): bit-identical to the CPU oracle and, through it, to the reference's own
+host code (src/niagara.cpp:424-481,969-1020; src/resources.cpp:280-292)."""
+import numpy as np
+
+import oracle
+from niagara_amd import host, synth
+from niagara_amd import layouts as L
+
+
+def test_cull_data_matches_oracle_for_random_cameras():
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        pos = rng.uniform(-50, 50, 3)
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        vw, vh = int(rng.integers(64, 4097)), int(rng.integers(64, 4097))
+        kw = dict(cam_pos=pos, cam_quat=q, fovy=float(rng.uniform(0.3, 2.0)), znear=float(rng.uniform(0.01, 1)),
+                  draw_distance=float(rng.uniform(50, 500)), viewport=(vw, vh), pyramid=(host.previous_pow2(vw), host.previous_pow2(vh)),
+                  draw_count=int(rng.integers(0, 1 << 20)), lod_step=int(rng.integers(0, 4)))
+        assert host.build_cull_data(**kw).tobytes() == oracle.make_cull_data(**kw).tobytes()
+
+
+def test_default_camera_is_niagaras():
+    cd = host.build_cull_data()
+    assert (cd["view"][0] == np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, -1, 0, 0, 0, 0, 1], np.float32)).all()
+    assert cd["znear"][0] == np.float32(0.1) and cd["zfar"][0] == np.float32(200)
+
+
+def test_synthetic_scene_and_visibility_slots_match_oracle():
+    d1, d2 = host.synth_draws(5000, 7, 300.0), oracle.synth_draws(5000, 7, 300.0)
+    assert d1.tobytes() == d2.tobytes()
+    meshes, _ = synth.make_meshes(7, 5, 300)
+    d1["postPass"] = d2["postPass"] = (np.arange(5000) % 11 == 0)
+    assert host.assign_visibility_offsets(d1, meshes) == oracle.assign_visibility_offsets(d2, meshes)
+    assert d1.tobytes() == d2.tobytes()
+    # slot base = running sum of max-over-LODs meshletCount (src/niagara.cpp:1008-1016)
+    widest = np.array([m["lods"]["meshletCount"][:m["lodCount"]].max() for m in meshes])
+    assert (d1["meshletVisibilityOffset"] == np.r_[0, np.cumsum(widest[d1["meshIndex"]])[:-1]]).all()
+
+
+def test_pyramid_geometry():
+    for w, h in [(1024, 768), (4096, 4096), (1920, 1080), (2, 2), (3, 1), (1, 1)]:
+        d = host.pyramid_desc(w, h)
+        p = oracle.Pyramid(w, h)
+        assert (d.width, d.height, d.levels, d.totalTexels) == (p.width, p.height, p.levels, p.s.totalTexels)
+        assert list(d.mipOffset) == p.mip_offset
+    assert host.previous_pow2(4096) == 2048 and host.pyramid_desc(4096, 4096).levels == 12
+
+
+def test_count4_for_matches_tasksubmit():
+    for n in [0, 1, 63, 64, 65, 156250, L.TASK_WGLIMIT, L.TASK_WGLIMIT + 9]:
+        c4 = np.array([n, 0, 0, 0], np.uint32)
+        oracle.tasksubmit(c4, np.zeros(min(n, L.TASK_WGLIMIT) + 64, dtype=L.TASKCMD))
+        assert (synth.count4_for(n) == c4).all()
