@@ -196,6 +196,28 @@ NV_DEV uint64_t cull_command(const ClusterArgs& a, const NvMeshTaskCommand& cmd,
 	return __ballot(visible && !skip);
 }
 
+// late pass, whole command invisible: clear the visibility bits of its valid lanes (clustercull.comp.glsl:125-131 with
+// visible == false).  When the words were loaded (BITS) only bits that are still set are touched.
+template <bool BITS>
+NV_DEV void clear_visibility_bits(const ClusterArgs& a, const NvMeshTaskCommand& cmd, const LaneData& l, uint32_t lane)
+{
+	const bool valid = lane < cmd.taskCount;
+	const uint32_t mvi = lane + cmd.meshletVisibilityOffset;
+	const bool set = valid && (!BITS || (l.mvbWord >> (mvi & 31u) & 1u));
+	const uint64_t clrAll = __ballot(set);
+	if (clrAll == 0)
+		return;
+	const uint32_t off = cmd.meshletVisibilityOffset;
+	const uint32_t sh = off & 31u;
+	if (lane < 3)
+	{
+		int lo = 32 * (int)lane - (int)sh;
+		uint32_t clrw = lo >= 0 ? (lo < 64 ? (uint32_t)(clrAll >> lo) : 0u) : (uint32_t)(clrAll << (-lo));
+		if (clrw)
+			atomicAnd(a.mvb + (off >> 5) + lane, ~clrw);
+	}
+}
+
 NV_DEV uint32_t load_mvb_word(const ClusterArgs& a, uint32_t meshletVisibilityOffset, uint32_t taskCount, uint32_t lane)
 {
 	const uint32_t mvi = taskCount ? meshletVisibilityOffset + (lane < taskCount ? lane : 0u) : 0u;
@@ -224,7 +246,91 @@ NV_DEV uint32_t indirect_command_count(const ClusterArgs& a)
 //
 // The ballots cost 8 B per 64 meshlets of extra traffic (1 %), the extra launch boundary ~2 us.
 constexpr uint32_t CC_CHUNK = 4; // consecutive commands per dealt chunk
-constexpr int CC_D = 6;          // ring slots per wave: CC_D - 1 commands' meshlet loads in flight behind the one being tested
+constexpr int CC_DA = 8;         // ring slots of the filter pass: CC_DA - 1 commands' bounds in flight behind the one being filtered
+constexpr int CC_DB = 3;         // ring slots of the exact pass
+
+// ---- conservative frustum filter (exactness-preserving early-out)
+// The reference's sphere transform costs ~58 un-fused fp32 operations per meshlet and must be reproduced bit for bit
+// wherever a decision depends on it.  But most commands lie entirely outside the frustum, and THAT can be proven with
+// a much cheaper computation: per draw, the whole chain  view * (rotateQuat(v, q) * scale + position)  is one affine
+// map  c = M v + b  (9 FMAs per meshlet), and the distance between this approximation and the reference's rounded
+// result is bounded by  E = K u (alpha * max|v_i| + beta)  with  alpha = ||V||_inf,row * |s| * (1 + 2 Qa (Qa + |qw|)),
+// beta = ||V||_inf,row * max|p_i| + max|V3_i|,  Qa = |qx|+|qy|+|qz|,  u = 2^-24  (standard forward error analysis:
+// every intermediate of either evaluation is bounded by the same expression with absolute values; the reference
+// chain is <= 13 roundings deep, the approximation <= 8 including the roundings inside M and b; K = 48 leaves > 2x
+// slack).  Each frustum predicate of the reference has the form  g > -r  (or  z + r > znear,  z - r < zfar)  with
+// coefficients |f| <= 1, so its margin moves by at most 4E when evaluated on the approximation.  A lane is dropped
+// only when some margin is below -4E, i.e. when the reference's own test is certainly false; NaNs and infinities
+// fail that comparison and fall through.  If any valid lane of the wave is not certainly out, the wave runs the
+// exact path for all lanes — results are identical to the unfiltered kernel (tests/test_gpu_parity.py compares both
+// against the oracle, including adversarial meshlets placed on the planes).
+struct FilterDraw
+{
+	float m[9];  // M, row-major
+	float b[3];
+	float aK, bK; // 4 K u alpha, 4 K u beta (+ an absolute floor)
+	float scale;
+};
+
+NV_DEV FilterDraw make_filter(const NvCullData& cd, const DrawUniform& u)
+{
+	const float x = u.q.x, y = u.q.y, z = u.q.z, w = u.qw, s = u.scale;
+	// R = (1 - 2|q_xyz|^2) I + 2 q q^T + 2 w [q]x  (valid for any q, unit or not) — same map as rotateQuat
+	float R[9];
+	R[0] = 1.0f - 2.0f * (y * y + z * z);
+	R[1] = 2.0f * (x * y - w * z);
+	R[2] = 2.0f * (x * z + w * y);
+	R[3] = 2.0f * (x * y + w * z);
+	R[4] = 1.0f - 2.0f * (x * x + z * z);
+	R[5] = 2.0f * (y * z - w * x);
+	R[6] = 2.0f * (x * z - w * y);
+	R[7] = 2.0f * (y * z + w * x);
+	R[8] = 1.0f - 2.0f * (x * x + y * y);
+	FilterDraw f;
+	const float* V = cd.view; // column-major: V(r,k) = V[4k + r]
+#pragma unroll
+	for (int r = 0; r < 3; ++r)
+	{
+#pragma unroll
+		for (int c = 0; c < 3; ++c)
+			f.m[3 * r + c] = s * (V[r] * R[c] + V[4 + r] * R[3 + c] + V[8 + r] * R[6 + c]);
+		f.b[r] = V[r] * u.pos.x + V[4 + r] * u.pos.y + V[8 + r] * u.pos.z + V[12 + r];
+	}
+	const float Qa = __builtin_fabsf(x) + __builtin_fabsf(y) + __builtin_fabsf(z);
+	const float rotAbs = 1.0f + 2.0f * Qa * (Qa + __builtin_fabsf(w));
+	float Vn = 0.0f, V3n = 0.0f;
+#pragma unroll
+	for (int r = 0; r < 3; ++r)
+	{
+		Vn = __builtin_fmaxf(Vn, __builtin_fabsf(V[r]) + __builtin_fabsf(V[4 + r]) + __builtin_fabsf(V[8 + r]));
+		V3n = __builtin_fmaxf(V3n, __builtin_fabsf(V[12 + r]));
+	}
+	const float pn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(u.pos.x), __builtin_fabsf(u.pos.y)), __builtin_fabsf(u.pos.z));
+	const float alpha = Vn * __builtin_fabsf(s) * rotAbs;
+	const float beta = Vn * pn + V3n;
+	const float k4u = 4.0f * 48.0f * 5.9604644775390625e-8f * 1.001f; // 4 K u, rounded up
+	f.aK = k4u * alpha;
+	f.bK = k4u * beta + 1e-30f;
+	f.scale = s;
+	return f;
+}
+
+// true for lanes whose sphere is certainly outside the frustum (see above); never true on NaN
+NV_DEV bool certainly_outside(const NvCullData& cd, const FilterDraw& f, const LaneData& l)
+{
+	const float vx = half_bits_to_float(l.b0 & 0xffffu), vy = half_bits_to_float(l.b0 >> 16), vz = half_bits_to_float(l.b1 & 0xffffu);
+	const float nu = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(vx), __builtin_fabsf(vy)), __builtin_fabsf(vz));
+	const float cx = __builtin_fmaf(f.m[0], vx, __builtin_fmaf(f.m[1], vy, __builtin_fmaf(f.m[2], vz, f.b[0])));
+	const float cy = __builtin_fmaf(f.m[3], vx, __builtin_fmaf(f.m[4], vy, __builtin_fmaf(f.m[5], vz, f.b[1])));
+	const float cz = __builtin_fmaf(f.m[6], vx, __builtin_fmaf(f.m[7], vy, __builtin_fmaf(f.m[8], vz, f.b[2])));
+	const float r = half_bits_to_float(l.b1 >> 16) * f.scale;
+	const float T = __builtin_fmaf(f.aK, nu, f.bK);
+	const float g1 = __builtin_fmaf(cz, cd.frustum[1], -(__builtin_fabsf(cx) * cd.frustum[0])) + r;
+	const float g2 = __builtin_fmaf(cz, cd.frustum[3], -(__builtin_fabsf(cy) * cd.frustum[2])) + r;
+	const float gn = (cz + r) - cd.znear;
+	const float gf = cd.zfar - (cz - r);
+	return (g1 < -T) | (g2 < -T) | (gn < -T) | (gf < -T);
+}
 
 // lane l of a wave holds the l-th command of the wave's current 64-command segment (one coalesced 1280-B read
 // instead of 64 dependent scalar loads) and the MeshDraw it points at; fields are broadcast with v_readlane as the
@@ -233,6 +339,7 @@ struct SegmentRegs
 {
 	uint32_t drawId, taskOffset, taskCount, lateDrawVisibility, meshletVisibilityOffset;
 	float4 d0, d1; // position.xyz, scale | orientation.xyzw of draws[drawId]
+	FilterDraw f;  // the frustum filter of that draw, derived lane-parallel (64 draws per ~130 VALU instructions)
 };
 
 NV_DEV NvMeshTaskCommand segment_command(const SegmentRegs& r, uint32_t c)
@@ -247,6 +354,31 @@ NV_DEV NvMeshTaskCommand segment_command(const SegmentRegs& r, uint32_t c)
 }
 
 NV_DEV float readlane_f(float v, uint32_t c) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), c)); }
+
+NV_DEV FilterDraw segment_filter(const SegmentRegs& r, uint32_t c)
+{
+	FilterDraw f;
+#pragma unroll
+	for (int i = 0; i < 9; ++i)
+		f.m[i] = readlane_f(r.f.m[i], c);
+#pragma unroll
+	for (int i = 0; i < 3; ++i)
+		f.b[i] = readlane_f(r.f.b[i], c);
+	f.aK = readlane_f(r.f.aK, c);
+	f.bK = readlane_f(r.f.bK, c);
+	f.scale = readlane_f(r.f.scale, c);
+	return f;
+}
+
+NV_DEV DrawUniform lane_draw(const SegmentRegs& r)
+{
+	DrawUniform u;
+	u.pos = { r.d0.x, r.d0.y, r.d0.z };
+	u.scale = r.d0.w;
+	u.q = { r.d1.x, r.d1.y, r.d1.z };
+	u.qw = r.d1.w;
+	return u;
+}
 
 NV_DEV DrawUniform segment_draw(const SegmentRegs& r, uint32_t c)
 {
@@ -269,18 +401,80 @@ NV_DEV DrawUniform segment_draw(const SegmentRegs& r, uint32_t c)
 //   * VMEM operations hipcc issues itself in between (HiZ texels, visibility-bit atomics) are younger than the slot
 //     being waited for and are consumed before the next ring issue (the issue statement takes the command's ballot as
 //     an operand), so they can only make a wait stricter, never too weak.
-struct RingSlot
+// ring A (filter pass): the 8 bounds bytes per meshlet (+ the visibility word when BITS)
+struct SlotA
 {
 	uint64_t bounds; // center.xy | center.z, radius (4 x fp16)
+	uint32_t mvbWord;
+};
+
+// ring B (exact pass over the surviving commands): bounds + cone (+ visibility word)
+struct SlotB
+{
+	uint64_t bounds;
 	uint32_t cone;
 	uint32_t mvbWord;
 };
 
+NV_DEV uint32_t lane_meshlet(uint32_t taskOffset, uint32_t taskCount, uint32_t lane)
+{
+	return (taskCount ? taskOffset : 0u) + (lane < taskCount ? lane : 0u);
+}
+
 template <bool BITS>
-NV_DEV void ring_issue(RingSlot& s, const ClusterArgs& a, uint32_t taskOffset, uint32_t taskCount, uint32_t mvo, uint32_t lane, uint64_t order)
+NV_DEV void ringA_issue(SlotA& s, const ClusterArgs& a, uint32_t taskOffset, uint32_t taskCount, uint32_t mvo, uint32_t lane, uint64_t order)
 {
 	const uint32_t li = lane < taskCount ? lane : 0u;
-	const uint32_t mi = (taskCount ? taskOffset : 0u) + li;
+	const uint32_t off8 = lane_meshlet(taskOffset, taskCount, lane) * 8u;
+	if (BITS)
+	{
+		const uint32_t offw = taskCount ? ((mvo + li) >> 5) * 4u : 0u;
+		asm volatile("global_load_dwordx2 %0, %2, %3\n\tglobal_load_dword %1, %4, %5 sc1"
+		             : "=&v"(s.bounds), "=&v"(s.mvbWord)
+		             : "v"(off8), "s"(a.soaBounds), "v"(offw), "s"(a.mvb), "s"(order)
+		             : "memory");
+	}
+	else
+	{
+		asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(s.bounds) : "v"(off8), "s"(a.soaBounds), "s"(order) : "memory");
+		s.mvbWord = 0;
+	}
+}
+
+template <bool BITS, int YOUNGER>
+NV_DEV void ringA_wait(SlotA& s)
+{
+	if (BITS)
+		asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.bounds), "+v"(s.mvbWord) : "i"(YOUNGER * 2) : "memory");
+	else
+		asm volatile("s_waitcnt vmcnt(%1)" : "+v"(s.bounds) : "i"(YOUNGER) : "memory");
+}
+
+// ring P (filter pass without visibility bits): one 16-B load per lane = the bounds of this command's meshlet and of the
+// meshlet 64 further on, i.e. of the NEXT command when the two are consecutive chunks of one draw's LOD range
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct SlotP
+{
+	u32x4 v;
+};
+
+NV_DEV void ringP_issue(SlotP& s, const ClusterArgs& a, uint32_t taskOffset, uint32_t taskCount, uint32_t lane, uint64_t order)
+{
+	const uint32_t off16 = lane_meshlet(taskOffset, taskCount, lane) * 16u;
+	asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(s.v) : "v"(off16), "s"(a.soaBounds2), "s"(order) : "memory");
+}
+
+template <int YOUNGER>
+NV_DEV void ringP_wait(SlotP& s)
+{
+	asm volatile("s_waitcnt vmcnt(%1)" : "+v"(s.v) : "i"(YOUNGER) : "memory");
+}
+
+template <bool BITS>
+NV_DEV void ringB_issue(SlotB& s, const ClusterArgs& a, uint32_t taskOffset, uint32_t taskCount, uint32_t mvo, uint32_t lane, uint64_t order)
+{
+	const uint32_t li = lane < taskCount ? lane : 0u;
+	const uint32_t mi = lane_meshlet(taskOffset, taskCount, lane);
 	const uint32_t off8 = mi * 8u, off4 = mi * 4u;
 	if (BITS)
 	{
@@ -301,7 +495,7 @@ NV_DEV void ring_issue(RingSlot& s, const ClusterArgs& a, uint32_t taskOffset, u
 }
 
 template <bool BITS, int YOUNGER>
-NV_DEV void ring_wait(RingSlot& s)
+NV_DEV void ringB_wait(SlotB& s)
 {
 	if (BITS)
 		asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s.bounds), "+v"(s.cone), "+v"(s.mvbWord) : "i"(YOUNGER * 3) : "memory");
@@ -369,75 +563,210 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 				r.d1 = d[1];
 			}
 		}
+		r.f = make_filter(a.cd, lane_draw(r)); // lane-parallel: one filter per command of the segment
 		NV_STAMP(1);
 
-		uint32_t curDraw = ~0u;
-		DrawUniform du = {};
-
-		// one command: fields by v_readlane, draw constants re-read only when the draw changes
-		auto run_command = [&](uint32_t c, const LaneData& cur) -> uint64_t
-		{
-			const NvMeshTaskCommand cmd = segment_command(r, c);
-			uint64_t m = 0;
-			if (cmd.taskCount)
-			{
-				if (cmd.drawId != curDraw) // a draw's task commands are consecutive: usually a hit
-				{
-					curDraw = cmd.drawId;
-					du = segment_draw(r, c);
-				}
-				m = cull_command<LATE, BITS>(a, cmd, du, cur, lane);
-			}
-			if (lane == 0)
-				s_mask[wave][c] = m;
-			return m;
-		};
+		const bool useFilter = !(a.debugMode & 32u);   // bit 5 (experiments): every valid command goes to the exact pass
+		const bool streamOnly = (a.debugMode & 64u) != 0; // bit 6 (experiments): no arithmetic at all
+		const bool updateBits = LATE && a.cd.clusterOcclusionEnabled == 1;
 
 		if (SOA)
 		{
-			// make sure hipcc has waited for its own segment loads before the first uncounted load is issued
-			asm volatile("" : "+v"(r.d0.x), "+v"(r.d1.x), "+v"(r.taskOffset), "+v"(r.meshletVisibilityOffset));
+			// hipcc must have waited for its own segment loads before the first uncounted load is issued
+			asm volatile("" : "+v"(r.f.m[0]), "+v"(r.f.b[0]), "+v"(r.f.aK), "+v"(r.taskOffset), "+v"(r.meshletVisibilityOffset), "+v"(r.taskCount));
 
-			// indices past the segment are clamped to its last command: redundant but unconditional loads
-			RingSlot ring[CC_D];
-#pragma unroll
-			for (int k = 0; k < CC_D; ++k)
+			// ---- pass A: stream the 8 bounds bytes of every command through the conservative frustum filter.
+			// Commands with no possible survivor are finished here (ballot 0); the rest are queued in candMask.
+			uint64_t candMask = 0;
+			uint32_t curDraw = ~0u;
+			FilterDraw fd = {};
+
+			// one command through the filter; returns the ballot of lanes that may survive
+			auto filter_command = [&](uint32_t c, uint32_t b0, uint32_t b1, uint32_t mvbWord) -> uint64_t
 			{
-				const uint32_t c = (uint32_t)k < cnt ? k : cnt - 1;
-				ring_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, c), __builtin_amdgcn_readlane(r.taskCount, c),
-				                 __builtin_amdgcn_readlane(r.meshletVisibilityOffset, c), lane, 0);
-			}
-			NV_STAMP(2);
-			for (uint32_t i = 0; i < cnt; i += CC_D)
-			{
-#pragma unroll
-				for (int k = 0; k < CC_D; ++k)
+				const NvMeshTaskCommand cmd = segment_command(r, c);
+				uint64_t any = 0;
+				if (!streamOnly && cmd.taskCount)
 				{
-					const uint32_t c = i + k;
-					ring_wait<BITS, CC_D - 1>(ring[k]);
-					if (i == 0 && k == 0)
-						NV_STAMP(3);
-					uint64_t m = 0;
-					if (c < cnt)
+					if (cmd.drawId != curDraw) // a draw's task commands are consecutive: usually a hit
 					{
-						LaneData cur;
-						cur.b0 = (uint32_t)ring[k].bounds;
-						cur.b1 = (uint32_t)(ring[k].bounds >> 32);
-						cur.cone = ring[k].cone;
-						cur.mvbWord = ring[k].mvbWord;
-						m = run_command(c, cur);
+						curDraw = cmd.drawId;
+						fd = segment_filter(r, c);
 					}
-					const uint32_t cn = c + CC_D < cnt ? c + CC_D : cnt - 1;
-					ring_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, cn), __builtin_amdgcn_readlane(r.taskCount, cn),
-					                 __builtin_amdgcn_readlane(r.meshletVisibilityOffset, cn), lane, m);
+					LaneData cur = { b0, b1, 0u, mvbWord };
+					bool candidate = lane < cmd.taskCount;
+					if (BITS && !LATE) // early pass: only last frame's visible clusters (clustercull.comp.glsl:91-92)
+						candidate = candidate && (mvbWord >> ((lane + cmd.meshletVisibilityOffset) & 31u) & 1u);
+					if (useFilter)
+						candidate = candidate && !certainly_outside(a.cd, fd, cur);
+					any = __ballot(candidate);
+					if (any == 0 && updateBits) // every valid lane is invisible (clustercull.comp.glsl:129-130)
+						clear_visibility_bits<BITS>(a, cmd, cur, lane);
+				}
+				if (any)
+					candMask |= 1ull << c;
+				else if (lane == 0)
+					s_mask[wave][c] = 0;
+				return any;
+			};
+
+			if (!BITS)
+			{
+				// paired stream: a load serves command c and, when c+1 is the next 64 meshlets of the same draw, c+1 too
+				auto pairs_with_next = [&](uint32_t c) -> bool
+				{
+					if (c + 1 >= cnt)
+						return false;
+					return __builtin_amdgcn_readlane(r.taskCount, c) == 64 && __builtin_amdgcn_readlane(r.taskCount, c + 1) != 0 &&
+					       __builtin_amdgcn_readlane(r.taskOffset, c + 1) == __builtin_amdgcn_readlane(r.taskOffset, c) + 64 &&
+					       __builtin_amdgcn_readlane(r.drawId, c + 1) == __builtin_amdgcn_readlane(r.drawId, c);
+				};
+				SlotP ring[CC_DA];
+				uint32_t first[CC_DA];
+				bool paired[CC_DA];
+				uint32_t ic = 0; // next command not yet covered by an issued load
+				auto issue = [&](int k, uint64_t order)
+				{
+					uint32_t c = cnt - 1; // past the end: redundant but unconditional load of the last command
+					first[k] = ~0u;
+					paired[k] = false;
+					if (ic < cnt)
+					{
+						c = ic;
+						first[k] = c;
+						paired[k] = pairs_with_next(c);
+						ic += paired[k] ? 2u : 1u;
+					}
+					ringP_issue(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, c), __builtin_amdgcn_readlane(r.taskCount, c), lane, order);
+				};
+#pragma unroll
+				for (int k = 0; k < CC_DA; ++k)
+					issue(k, 0);
+				NV_STAMP(2);
+				for (bool more = true; more;)
+				{
+					more = false;
+#pragma unroll
+					for (int k = 0; k < CC_DA; ++k)
+					{
+						ringP_wait<CC_DA - 1>(ring[k]);
+						uint64_t any = 0;
+						if (first[k] != ~0u)
+						{
+							any = filter_command(first[k], ring[k].v.x, ring[k].v.y, 0u);
+							if (paired[k])
+								any |= filter_command(first[k] + 1, ring[k].v.z, ring[k].v.w, 0u);
+						}
+						issue(k, any);
+						more = more || first[k] != ~0u;
+					}
 				}
 			}
-			// drain: nothing of the ring may be in flight when the registers are reused
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			else
+			{
+				SlotA ring[CC_DA];
+#pragma unroll
+				for (int k = 0; k < CC_DA; ++k)
+				{
+					const uint32_t c = (uint32_t)k < cnt ? k : cnt - 1; // clamped: redundant but unconditional loads
+					ringA_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, c), __builtin_amdgcn_readlane(r.taskCount, c),
+					                  __builtin_amdgcn_readlane(r.meshletVisibilityOffset, c), lane, 0);
+				}
+				NV_STAMP(2);
+				for (uint32_t i = 0; i < cnt; i += CC_DA)
+				{
+#pragma unroll
+					for (int k = 0; k < CC_DA; ++k)
+					{
+						const uint32_t c = i + k;
+						ringA_wait<BITS, CC_DA - 1>(ring[k]);
+						uint64_t any = 0;
+						if (c < cnt)
+							any = filter_command(c, (uint32_t)ring[k].bounds, (uint32_t)(ring[k].bounds >> 32), ring[k].mvbWord);
+						const uint32_t cn = c + CC_DA < cnt ? c + CC_DA : cnt - 1;
+						ringA_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, cn), __builtin_amdgcn_readlane(r.taskCount, cn),
+						                  __builtin_amdgcn_readlane(r.meshletVisibilityOffset, cn), lane, any);
+					}
+				}
+			}
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // drain: the rings' registers are reused below
+			NV_STAMP(3);
+
+			// ---- pass B: exact tests (reference arithmetic) for the commands that can have survivors, bounds + cone
+			if (candMask)
+			{
+				uint32_t curDraw = ~0u;
+				DrawUniform du = {};
+				uint64_t pending = candMask; // commands not yet issued into the ring
+				uint32_t cIssued[CC_DB];
+				SlotB ring[CC_DB];
+				uint32_t last = (uint32_t)__builtin_ctzll(candMask);
+#pragma unroll
+				for (int k = 0; k < CC_DB; ++k)
+				{
+					if (pending)
+					{
+						last = (uint32_t)__builtin_ctzll(pending);
+						pending &= pending - 1;
+						cIssued[k] = last;
+					}
+					else
+						cIssued[k] = ~0u; // nothing left: the slot re-reads the last command and is ignored
+					ringB_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, last), __builtin_amdgcn_readlane(r.taskCount, last),
+					                  __builtin_amdgcn_readlane(r.meshletVisibilityOffset, last), lane, 0);
+				}
+				for (bool more = true; more;)
+				{
+					more = false;
+#pragma unroll
+					for (int k = 0; k < CC_DB; ++k)
+					{
+						ringB_wait<BITS, CC_DB - 1>(ring[k]);
+						const uint32_t c = cIssued[k];
+						uint64_t m = 0;
+						if (c != ~0u)
+						{
+							const NvMeshTaskCommand cmd = segment_command(r, c);
+							if (cmd.drawId != curDraw)
+							{
+								curDraw = cmd.drawId;
+								du = segment_draw(r, c);
+							}
+							LaneData cur;
+							cur.b0 = (uint32_t)ring[k].bounds;
+							cur.b1 = (uint32_t)(ring[k].bounds >> 32);
+							cur.cone = ring[k].cone;
+							cur.mvbWord = ring[k].mvbWord;
+							m = cull_command<LATE, BITS>(a, cmd, du, cur, lane);
+							if (lane == 0)
+								s_mask[wave][c] = m;
+						}
+						if (pending)
+						{
+							last = (uint32_t)__builtin_ctzll(pending);
+							pending &= pending - 1;
+							cIssued[k] = last;
+							more = true;
+						}
+						else
+							cIssued[k] = ~0u;
+						ringB_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, last), __builtin_amdgcn_readlane(r.taskCount, last),
+						                  __builtin_amdgcn_readlane(r.meshletVisibilityOffset, last), lane, m);
+					}
+					// slots issued in this round still hold commands: one more round consumes them
+					if (!more)
+#pragma unroll
+						for (int k = 0; k < CC_DB; ++k)
+							more = more || cIssued[k] != ~0u;
+				}
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			}
 		}
 		else
 		{
-			// AoS records read in place: compiler-scheduled loads, one command ahead
+			// AoS records read in place (no mirror registered): compiler-scheduled loads, one command ahead
+			uint32_t curDraw = ~0u;
+			DrawUniform du = {};
 			LaneData nxt = load_lane<false>(a, __builtin_amdgcn_readlane(r.taskOffset, 0), __builtin_amdgcn_readlane(r.taskCount, 0), lane);
 			if (BITS)
 				nxt.mvbWord = load_mvb_word(a, __builtin_amdgcn_readlane(r.meshletVisibilityOffset, 0), __builtin_amdgcn_readlane(r.taskCount, 0), lane);
@@ -448,7 +777,19 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 				nxt = load_lane<false>(a, __builtin_amdgcn_readlane(r.taskOffset, cn), __builtin_amdgcn_readlane(r.taskCount, cn), lane);
 				if (BITS)
 					nxt.mvbWord = load_mvb_word(a, __builtin_amdgcn_readlane(r.meshletVisibilityOffset, cn), __builtin_amdgcn_readlane(r.taskCount, cn), lane);
-				run_command(c, cur);
+				const NvMeshTaskCommand cmd = segment_command(r, c);
+				uint64_t m = 0;
+				if (cmd.taskCount)
+				{
+					if (cmd.drawId != curDraw)
+					{
+						curDraw = cmd.drawId;
+						du = segment_draw(r, c);
+					}
+					m = cull_command<LATE, BITS>(a, cmd, du, cur, lane);
+				}
+				if (lane == 0)
+					s_mask[wave][c] = m;
 			}
 		}
 		NV_STAMP(4);
@@ -697,12 +1038,12 @@ __global__ __launch_bounds__(CC_THREADS) void probe_kernel(ClusterArgs a)
 // ---------------------------------------------------------------------------------------------------------------
 // SoA mirror of the 12 cull bytes (nv_upload_meshlets)
 __global__ __launch_bounds__(256) void soa_split_kernel(const NvMeshlet* __restrict__ meshlets, uint32_t count, uint32_t padded,
-                                                       uint2* __restrict__ bounds, uint32_t* __restrict__ cones)
+                                                       uint2* __restrict__ bounds, uint4* __restrict__ bounds2, uint32_t* __restrict__ cones)
 {
 	uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= padded)
 		return;
-	uint2 b = make_uint2(0, 0);
+	uint2 b = make_uint2(0, 0), b64 = make_uint2(0, 0);
 	uint32_t c = 0;
 	if (i < count)
 	{
@@ -711,7 +1052,14 @@ __global__ __launch_bounds__(256) void soa_split_kernel(const NvMeshlet* __restr
 		b.y = p[1];
 		c = p[2];
 	}
+	if (i + 64 < count)
+	{
+		const uint32_t* p = reinterpret_cast<const uint32_t*>(meshlets + i + 64);
+		b64.x = p[0];
+		b64.y = p[1];
+	}
 	bounds[i] = b;
+	bounds2[i] = make_uint4(b.x, b.y, b64.x, b64.y);
 	cones[i] = c;
 }
 
@@ -788,9 +1136,9 @@ int launch_probe(hipStream_t stream, const ClusterArgs& a, bool soa, uint32_t gr
 	return (int)hipGetLastError();
 }
 
-int launch_soa_split(hipStream_t stream, const NvMeshlet* meshlets, uint32_t count, uint32_t padded, uint2* bounds, uint32_t* cones)
+int launch_soa_split(hipStream_t stream, const NvMeshlet* meshlets, uint32_t count, uint32_t padded, uint2* bounds, uint4* bounds2, uint32_t* cones)
 {
-	hipLaunchKernelGGL(soa_split_kernel, dim3((padded + 255) / 256), dim3(256), 0, stream, meshlets, count, padded, bounds, cones);
+	hipLaunchKernelGGL(soa_split_kernel, dim3((padded + 255) / 256), dim3(256), 0, stream, meshlets, count, padded, bounds, bounds2, cones);
 	return (int)hipGetLastError();
 }
 

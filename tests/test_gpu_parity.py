@@ -350,3 +350,104 @@ def test_graph_replay_is_safe(ctx):
             assert total == int(cc4_o[0])
             assert (G.host_u32(cib)[:total] == cib_o[:total]).all()
     ctx.status()
+
+
+def _compare_cluster_pass(ctx, draws, meshlets, commands, n, cd, late, mvb0, pyr, gp, soa=True):
+    """one clustercull pass, HIP vs oracle: count, IDs and visibility words"""
+    dev = ctx.device
+    c4 = synth.count4_for(n)
+    cib_o, cc4_o = np.zeros(len(commands) * 64 + 256, np.uint32), np.zeros(4, np.uint32)
+    mvb_o = None if mvb0 is None else mvb0.copy()
+    oracle.clustercull(cd, late, commands, c4, draws, meshlets, mvb_o, pyr, cib_o, cc4_o)
+    db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+    if soa:
+        ctx.upload_meshlets(mlb, len(meshlets))
+    d_mvb = None if mvb0 is None else torch.from_numpy(mvb0.view(np.int32).copy()).to(dev)
+    dccb = torch.from_numpy(c4.view(np.int32).copy()).to(dev)
+    cib = torch.zeros(len(commands) * 64 + 256, dtype=torch.int32, device=dev)
+    ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+    ctx.clustercull(cd, late, dcb, dccb, db, mlb, d_mvb, None if gp is None else gp.desc, cib, ccb)
+    total = int(cc4_o[0])
+    assert int(ccb[0].item()) == total
+    assert (G.host_u32(cib)[:total] == cib_o[:total]).all()
+    if mvb0 is not None:
+        assert (G.host_u32(d_mvb) == mvb_o).all()
+    ctx.status()
+    return total
+
+
+@pytest.mark.parametrize("soa", [True, False])
+def test_cluster_pass_flag_and_postpass_matrix(ctx, soa):
+    """clustercull over clusterOcclusion x backface x postPass x LATE, incl. the postPass != 0 late pass that updates
+    visibility bits without reading them (clustercull.comp.glsl:84,125)"""
+    rng = np.random.default_rng(91)
+    draws, meshlets, commands, n, cd = _cluster_inputs(500, 6, seed=8)
+    draws["position"] *= np.float32(0.2)  # bring a good share of the draws into view
+    commands["lateDrawVisibility"][:n] = rng.integers(0, 2, n)
+    slots = n * 64
+    mvb0 = rng.integers(0, 2 ** 32, slots // 32 + 3, dtype=np.uint64).astype(np.uint32)
+    pyr = oracle.Pyramid(256, 192)
+    depth = make_scene(seed=3)["depth"]
+    oracle.depthreduce(depth, pyr)
+    gp = P.DepthPyramid(ctx.device, 256, 192)
+    ctx.depthreduce(torch.from_numpy(depth).to(ctx.device), 256, 192, gp.desc)
+    cd["pyramidWidth"], cd["pyramidHeight"] = pyr.width, pyr.height
+    seen = 0
+    for late in (0, 1):
+        for coe in (0, 1):
+            for cbe in (0, 1):
+                for post in (0, 1):
+                    c = cd.copy()
+                    c["clusterOcclusionEnabled"], c["clusterBackfaceEnabled"], c["postPass"] = coe, cbe, post
+                    seen += _compare_cluster_pass(ctx, draws, meshlets, commands, n, c, late, mvb0, pyr, gp, soa)
+    assert seen > 1000
+
+
+def test_frustum_filter_is_exact_on_the_planes(ctx):
+    """adversarial input for the conservative frustum filter: meshlet spheres placed so that their exact margins sit
+    within a few ulps of every frustum / near / far threshold, plus NaN / inf / huge / zero-radius records.  The filtered
+    kernel must still return exactly the oracle's list."""
+    rng = np.random.default_rng(123)
+    n_draws, cpd = 400, 4
+    draws = host.synth_draws(n_draws, 1, 60.0)
+    cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, clusterBackfaceEnabled=0, draw_distance=80.0)
+    commands = synth.make_task_commands(n_draws, cpd)
+    n = n_draws * cpd
+    meshlets = synth.make_meshlets(n * 64, seed=9)
+    f = cd["frustum"][0]
+    # put every draw ON a plane: choose a target view-space point on the plane and move the draw there
+    for i in range(n_draws):
+        z = np.float32(rng.uniform(2, 70))
+        kind = i % 6
+        if kind == 0:      # x side planes: z*f1 - |x|*f0 = 0
+            x = z * f[1] / f[0] * (1 if i % 12 < 6 else -1)
+            y = np.float32(rng.uniform(-0.3, 0.3)) * z
+        elif kind == 1:    # y planes
+            y = z * f[3] / f[2] * (1 if i % 12 < 6 else -1)
+            x = np.float32(rng.uniform(-0.3, 0.3)) * z
+        elif kind == 2:    # near plane
+            x, y, z = 0.0, 0.0, np.float32(0.1)
+        elif kind == 3:    # far plane
+            x, y, z = 0.0, 0.0, np.float32(80.0)
+        else:              # generic
+            x, y = np.float32(rng.uniform(-1, 1)) * z, np.float32(rng.uniform(-1, 1)) * z
+        draws["position"][i] = (x, y, -z)  # camera at the origin looking down -z: view z = -world z
+        draws["scale"][i] = np.float32(rng.choice([1e-3, 0.5, 1.0, 3.0]))
+    # meshlet centres tiny, radii spanning 0 .. small so that spheres straddle the planes at the ulp level
+    c = (rng.normal(size=(n * 64, 3)) * 10 ** rng.uniform(-6, -1, (n * 64, 1))).astype(np.float16)
+    meshlets["center"] = c.view(np.uint16)
+    r = (10 ** rng.uniform(-7, -1, n * 64)).astype(np.float16)
+    r[::17] = 0
+    meshlets["radius"] = r.view(np.uint16)
+    # poison: NaN / inf / max-half centres and radii
+    bad = rng.integers(0, n * 64, 200)
+    meshlets["center"][bad[:50], 0] = 0x7e00  # NaN
+    meshlets["center"][bad[50:100], 1] = 0x7c00  # +inf
+    meshlets["radius"][bad[100:150]] = 0x7bff  # 65504
+    meshlets["radius"][bad[150:]] = 0xfc00  # -inf
+    total = _compare_cluster_pass(ctx, draws, meshlets, commands, n, cd, 0, None, None, None)
+    assert 0.02 * n * 64 < total < 0.98 * n * 64
+    # a non-unit, large quaternion and a huge position must not break the bound either
+    draws["orientation"] *= np.float32(7.5)
+    draws["position"][::5] *= np.float32(1e6)
+    _compare_cluster_pass(ctx, draws, meshlets, commands, n, cd, 0, None, None, None)

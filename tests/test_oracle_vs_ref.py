@@ -240,3 +240,30 @@ def test_depthreduce_pow2_and_ragged_sizes(size):
     R.depthreduce(depth, pr)
     assert po.levels == pr.levels and po.data.tobytes() == pr.data.tobytes()
     assert po.level(po.levels - 1).shape == (1, 1)
+
+
+def test_cluster_pass_postpass_matrix():
+    """clustercull with postPass != 0 (bits are updated but not read) and every cluster flag, oracle vs reference shader"""
+    from niagara_amd import host, synth
+    rng = np.random.default_rng(91)
+    draws, meshlets, commands, n = synth.cluster_scene(200, 5, seed=8)
+    draws["position"] *= np.float32(0.2)
+    commands["lateDrawVisibility"][:n] = rng.integers(0, 2, n)
+    cd = host.build_cull_data(draw_count=len(draws), cullingEnabled=1, pyramid=(128, 128))
+    mvb0 = rng.integers(0, 2 ** 32, n * 2 + 3, dtype=np.uint64).astype(np.uint32)
+    pyr = oracle.Pyramid(256, 192)
+    oracle.depthreduce(make_scene(seed=3)["depth"], pyr)
+    c4 = synth.count4_for(n)
+    for late in (0, 1):
+        for coe in (0, 1):
+            for cbe in (0, 1):
+                for post in (0, 1):
+                    c = cd.copy()
+                    c["clusterOcclusionEnabled"], c["clusterBackfaceEnabled"], c["postPass"] = coe, cbe, post
+                    outs = []
+                    for impl in (oracle, R):
+                        cib, cc4, mvb = np.zeros(len(commands) * 64 + 256, np.uint32), np.zeros(4, np.uint32), mvb0.copy()
+                        impl.clustercull(c, late, commands, c4, draws, meshlets, mvb, pyr, cib, cc4)
+                        outs.append((cib, cc4, mvb))
+                    for a, b in zip(*outs):
+                        assert a.tobytes() == b.tobytes(), (late, coe, cbe, post)

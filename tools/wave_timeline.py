@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """wave_timeline.py — development aid: per-wave s_memtime stamps of one clustercull launch (NV_DEBUG_MODE=8).
 
-stamps (cluster_mask_kernel, last segment of each wave): 0 kernel entry · 1 segment (commands+draws) loaded ·
-2 ring filled (issue only) · 3 first ring wait passed · 4 cull loop done · 5 ballots stored / wave end
+stamps (cluster_mask_kernel, last segment of each wave): 0 kernel entry · 1 segment loaded (commands, draws) and the
+lane-parallel filters derived · 2 filter ring filled (issue only) · 3 pass A (filter stream) done · 4 pass B (exact tests
+of the surviving commands) done · 5 ballots stored / wave end
 """
 import ctypes as C
 import os
@@ -39,7 +40,7 @@ assert rc == 0, rc
 t = out.astype(np.int64)
 t0 = t[:, 0].min()
 rel = (t - t0)[:, :6]
-names = ["entry", "segment loaded", "ring issued", "first data", "cull loop done", "wave end"]
+names = ["entry", "segment+filters ready", "ring A issued", "pass A done", "pass B done", "wave end"]
 print("s_memtime ticks relative to the earliest wave entry (min / median / max over %d waves)" % waves)
 for i, nm in enumerate(names):
     col = rel[:, i]
