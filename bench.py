@@ -87,7 +87,7 @@ def main():
     torch.cuda.synchronize()
 
     def step(i):
-        ccb[0:1].zero_()
+        ctx.reset_count(ccb)  # the caller's vkCmdFillBuffer(ccb, 0, 4, 0)
         ctx.clustercull(cd, 0, dcbs[i % copies], dccb, db, mlb, None, None, cib, ccb)
         if world > 1:
             ctx.pack_counts(None, dccb, ccb, counts)

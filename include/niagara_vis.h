@@ -201,6 +201,10 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
                 const NvMeshDraw* d_draws, const NvMesh* d_meshes, void* d_commands, uint32_t* d_count4,
                 uint32_t* d_drawVisibility, const NvPyramidDesc* pyramid);
 
+/* vkCmdFillBuffer(dccb / ccb, 0, 4, 0) in front of a pass (src/niagara.cpp:1541,1586): zeroes word 0 of one or two count
+ * buffers (either may be NULL).  The passes themselves never clear a counter. */
+int nv_reset_count(nv_context* ctx, void* stream, uint32_t* d_count4a, uint32_t* d_count4b);
+
 /* tasksubmit.comp.glsl:27-47; dispatch at src/niagara.cpp:1563-1568 */
 int nv_tasksubmit(nv_context* ctx, void* stream, uint32_t* d_count4, NvMeshTaskCommand* d_commands);
 

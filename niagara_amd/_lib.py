@@ -43,6 +43,7 @@ _SIGS = {
     "nv_profile_read": (_i, [_vp, C.POINTER(C.c_float * 4), C.POINTER(C.c_uint32 * 4)]),
     "nv_upload_meshlets": (_i, [_vp, _vp, _vp, _u32]),
     "nv_drawcull": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(PyramidDesc)]),
+    "nv_reset_count": (_i, [_vp, _vp, _vp, _vp]),
     "nv_tasksubmit": (_i, [_vp, _vp, _vp, _vp]),
     "nv_clustercull": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(PyramidDesc), _vp, _vp]),
     "nv_clustersubmit": (_i, [_vp, _vp, _vp, _vp]),

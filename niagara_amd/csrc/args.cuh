@@ -31,7 +31,6 @@ struct ClusterArgs
 	const NvMeshDraw* __restrict__ draws;
 	const NvMeshlet* __restrict__ meshlets; // AoS (used when soaBounds == nullptr)
 	const uint2* __restrict__ soaBounds;
-	const uint4* __restrict__ soaBounds2; // {bounds[i], bounds[i + 64]}: one 16-B load serves two consecutive commands
 	const uint32_t* __restrict__ soaCones;
 	uint32_t* __restrict__ mvb;
 	uint32_t* __restrict__ clusterIndices;

@@ -353,6 +353,12 @@ NV_DEV NvMeshTaskCommand segment_command(const SegmentRegs& r, uint32_t c)
 	return cmd;
 }
 
+// vec[lane c] = val (wave-uniform val and c)
+NV_DEV uint32_t writelane_u32(uint32_t vec, uint32_t val, uint32_t c)
+{
+	return (threadIdx.x & 63u) == c ? val : vec;
+}
+
 NV_DEV float readlane_f(float v, uint32_t c) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), c)); }
 
 NV_DEV FilterDraw segment_filter(const SegmentRegs& r, uint32_t c)
@@ -421,14 +427,12 @@ NV_DEV uint32_t lane_meshlet(uint32_t taskOffset, uint32_t taskCount, uint32_t l
 	return (taskCount ? taskOffset : 0u) + (lane < taskCount ? lane : 0u);
 }
 
+// off8 = byte offset of this lane's bounds record; offw = byte offset of its visibility word (BITS)
 template <bool BITS>
-NV_DEV void ringA_issue(SlotA& s, const ClusterArgs& a, uint32_t taskOffset, uint32_t taskCount, uint32_t mvo, uint32_t lane, uint64_t order)
+NV_DEV void ringA_issue(SlotA& s, const ClusterArgs& a, uint32_t off8, uint32_t offw, uint64_t order)
 {
-	const uint32_t li = lane < taskCount ? lane : 0u;
-	const uint32_t off8 = lane_meshlet(taskOffset, taskCount, lane) * 8u;
 	if (BITS)
 	{
-		const uint32_t offw = taskCount ? ((mvo + li) >> 5) * 4u : 0u;
 		asm volatile("global_load_dwordx2 %0, %2, %3\n\tglobal_load_dword %1, %4, %5 sc1"
 		             : "=&v"(s.bounds), "=&v"(s.mvbWord)
 		             : "v"(off8), "s"(a.soaBounds), "v"(offw), "s"(a.mvb), "s"(order)
@@ -450,25 +454,7 @@ NV_DEV void ringA_wait(SlotA& s)
 		asm volatile("s_waitcnt vmcnt(%1)" : "+v"(s.bounds) : "i"(YOUNGER) : "memory");
 }
 
-// ring P (filter pass without visibility bits): one 16-B load per lane = the bounds of this command's meshlet and of the
-// meshlet 64 further on, i.e. of the NEXT command when the two are consecutive chunks of one draw's LOD range
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-struct SlotP
-{
-	u32x4 v;
-};
-
-NV_DEV void ringP_issue(SlotP& s, const ClusterArgs& a, uint32_t taskOffset, uint32_t taskCount, uint32_t lane, uint64_t order)
-{
-	const uint32_t off16 = lane_meshlet(taskOffset, taskCount, lane) * 16u;
-	asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(s.v) : "v"(off16), "s"(a.soaBounds2), "s"(order) : "memory");
-}
-
-template <int YOUNGER>
-NV_DEV void ringP_wait(SlotP& s)
-{
-	asm volatile("s_waitcnt vmcnt(%1)" : "+v"(s.v) : "i"(YOUNGER) : "memory");
-}
 
 template <bool BITS>
 NV_DEV void ringB_issue(SlotB& s, const ClusterArgs& a, uint32_t taskOffset, uint32_t taskCount, uint32_t mvo, uint32_t lane, uint64_t order)
@@ -519,8 +505,6 @@ NV_DEV uint32_t dealt_command(uint32_t w, uint32_t W, uint32_t c)
 template <bool LATE, bool SOA, bool BITS>
 __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 {
-	__shared__ uint64_t s_mask[CC_WAVES][64];
-
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t W = gridDim.x * CC_WAVES;
@@ -545,7 +529,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 	{
 		const uint32_t cnt = myCmds - seg < 64u ? myCmds - seg : 64u;
 
-		// lane l holds the wave's (seg + l)-th command and the MeshDraw it points at
+		// lane l holds the wave's (seg + l)-th command and (below) the MeshDraw it points at
 		const uint32_t myIdx = dealt_command(w, W, seg + lane);
 		SegmentRegs r = {};
 		if (lane < cnt && myIdx < numCmds)
@@ -556,122 +540,116 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 			r.taskCount = p[2];
 			r.lateDrawVisibility = p[3];
 			r.meshletVisibilityOffset = p[4];
+		}
+		if (!SOA)
+		{
 			if (r.taskCount)
 			{
 				const float4* d = reinterpret_cast<const float4*>(a.draws + r.drawId);
 				r.d0 = d[0];
 				r.d1 = d[1];
 			}
+			r.f = make_filter(a.cd, lane_draw(r)); // lane-parallel: one filter per command of the segment
 		}
-		r.f = make_filter(a.cd, lane_draw(r)); // lane-parallel: one filter per command of the segment
 		NV_STAMP(1);
+
+		// SOA path: the MeshDraw gather is issued uncounted, AHEAD of the filter ring's first loads, and waited for
+		// behind them (counted), so the dependent chain is commands -> {draws, first bounds} instead of
+		// commands -> draws -> filters -> first bounds.
+		u32x4 g0 = {}, g1 = {};
+		auto gather_issue = [&]()
+		{
+			const char* dp = reinterpret_cast<const char*>(a.draws + (r.taskCount ? r.drawId : 0u));
+			asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(g0), "=&v"(g1) : "v"(dp) : "memory");
+		};
+		auto gather_finish = [&]()
+		{
+			r.d0 = make_float4(__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w));
+			r.d1 = make_float4(__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z), __uint_as_float(g1.w));
+			r.f = make_filter(a.cd, lane_draw(r));
+		};
 
 		const bool useFilter = !(a.debugMode & 32u);   // bit 5 (experiments): every valid command goes to the exact pass
 		const bool streamOnly = (a.debugMode & 64u) != 0; // bit 6 (experiments): no arithmetic at all
 		const bool updateBits = LATE && a.cd.clusterOcclusionEnabled == 1;
+		uint32_t maskLo = 0, maskHi = 0; // lane c ends up holding the ballot of the segment's c-th command (v_writelane)
 
 		if (SOA)
 		{
 			// hipcc must have waited for its own segment loads before the first uncounted load is issued
-			asm volatile("" : "+v"(r.f.m[0]), "+v"(r.f.b[0]), "+v"(r.f.aK), "+v"(r.taskOffset), "+v"(r.meshletVisibilityOffset), "+v"(r.taskCount));
+			asm volatile("" : "+v"(r.drawId), "+v"(r.taskOffset), "+v"(r.meshletVisibilityOffset), "+v"(r.taskCount), "+v"(r.lateDrawVisibility));
+			gather_issue();
 
 			// ---- pass A: stream the 8 bounds bytes of every command through the conservative frustum filter.
 			// Commands with no possible survivor are finished here (ballot 0); the rest are queued in candMask.
+			// ---- per-segment scalar summaries (one ballot each) so that the walk needs no per-command v_readlane for
+			// control: which commands are full (64 meshlets), empty (dummy), or start a new draw
+			const uint64_t fullMask = __ballot(r.taskCount == 64u);
+			const uint64_t emptyMask = __ballot(r.taskCount == 0u);
+			const uint32_t prevDraw = __shfl_up(r.drawId, 1, 64);
+			const uint64_t changeMask = __ballot(lane == 0 || r.drawId != prevDraw) | 1ull;
+			const uint32_t base8 = (r.taskCount ? r.taskOffset : 0u) * 8u; // lane-parallel: byte offset of each command's bounds
+			const uint32_t lane8 = lane * 8u;
+
 			uint64_t candMask = 0;
-			uint32_t curDraw = ~0u;
 			FilterDraw fd = {};
+
+			auto issueA = [&](SlotA& slot, uint32_t c, uint64_t order)
+			{
+				uint32_t off8, offw = 0;
+				if (fullMask >> c & 1ull)
+					off8 = __builtin_amdgcn_readlane(base8, c) + lane8;
+				else
+				{
+					const uint32_t tc = __builtin_amdgcn_readlane(r.taskCount, c);
+					off8 = __builtin_amdgcn_readlane(base8, c) + (lane < tc ? lane8 : 0u);
+				}
+				if (BITS)
+				{
+					const uint32_t tc = __builtin_amdgcn_readlane(r.taskCount, c);
+					const uint32_t mvo = __builtin_amdgcn_readlane(r.meshletVisibilityOffset, c);
+					offw = tc ? ((mvo + (lane < tc ? lane : 0u)) >> 5) * 4u : 0u;
+				}
+				ringA_issue<BITS>(slot, a, off8, offw, order);
+			};
 
 			// one command through the filter; returns the ballot of lanes that may survive
 			auto filter_command = [&](uint32_t c, uint32_t b0, uint32_t b1, uint32_t mvbWord) -> uint64_t
 			{
-				const NvMeshTaskCommand cmd = segment_command(r, c);
-				uint64_t any = 0;
-				if (!streamOnly && cmd.taskCount)
+				if (streamOnly || (emptyMask >> c & 1ull))
+					return 0;
+				if (changeMask >> c & 1ull) // first command of a draw within this segment
+					fd = segment_filter(r, c);
+				const LaneData cur = { b0, b1, 0u, mvbWord };
+				bool candidate = true;
+				uint32_t tc = 64, mvo = 0;
+				if (!(fullMask >> c & 1ull))
 				{
-					if (cmd.drawId != curDraw) // a draw's task commands are consecutive: usually a hit
-					{
-						curDraw = cmd.drawId;
-						fd = segment_filter(r, c);
-					}
-					LaneData cur = { b0, b1, 0u, mvbWord };
-					bool candidate = lane < cmd.taskCount;
-					if (BITS && !LATE) // early pass: only last frame's visible clusters (clustercull.comp.glsl:91-92)
-						candidate = candidate && (mvbWord >> ((lane + cmd.meshletVisibilityOffset) & 31u) & 1u);
-					if (useFilter)
-						candidate = candidate && !certainly_outside(a.cd, fd, cur);
-					any = __ballot(candidate);
-					if (any == 0 && updateBits) // every valid lane is invisible (clustercull.comp.glsl:129-130)
-						clear_visibility_bits<BITS>(a, cmd, cur, lane);
+					tc = __builtin_amdgcn_readlane(r.taskCount, c);
+					candidate = lane < tc;
 				}
-				if (any)
-					candMask |= 1ull << c;
-				else if (lane == 0)
-					s_mask[wave][c] = 0;
+				if (BITS || updateBits)
+					mvo = __builtin_amdgcn_readlane(r.meshletVisibilityOffset, c);
+				if (BITS && !LATE) // early pass: only last frame's visible clusters (clustercull.comp.glsl:91-92)
+					candidate = candidate && (mvbWord >> ((lane + mvo) & 31u) & 1u);
+				if (useFilter)
+					candidate = candidate && !certainly_outside(a.cd, fd, cur);
+				const uint64_t any = __ballot(candidate);
+				if (any == 0 && updateBits) // every valid lane is invisible (clustercull.comp.glsl:129-130)
+				{
+					const NvMeshTaskCommand cmd = { 0u, 0u, tc, 0u, mvo };
+					clear_visibility_bits<BITS>(a, cmd, cur, lane);
+				}
 				return any;
 			};
 
-			if (!BITS)
-			{
-				// paired stream: a load serves command c and, when c+1 is the next 64 meshlets of the same draw, c+1 too
-				auto pairs_with_next = [&](uint32_t c) -> bool
-				{
-					if (c + 1 >= cnt)
-						return false;
-					return __builtin_amdgcn_readlane(r.taskCount, c) == 64 && __builtin_amdgcn_readlane(r.taskCount, c + 1) != 0 &&
-					       __builtin_amdgcn_readlane(r.taskOffset, c + 1) == __builtin_amdgcn_readlane(r.taskOffset, c) + 64 &&
-					       __builtin_amdgcn_readlane(r.drawId, c + 1) == __builtin_amdgcn_readlane(r.drawId, c);
-				};
-				SlotP ring[CC_DA];
-				uint32_t first[CC_DA];
-				bool paired[CC_DA];
-				uint32_t ic = 0; // next command not yet covered by an issued load
-				auto issue = [&](int k, uint64_t order)
-				{
-					uint32_t c = cnt - 1; // past the end: redundant but unconditional load of the last command
-					first[k] = ~0u;
-					paired[k] = false;
-					if (ic < cnt)
-					{
-						c = ic;
-						first[k] = c;
-						paired[k] = pairs_with_next(c);
-						ic += paired[k] ? 2u : 1u;
-					}
-					ringP_issue(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, c), __builtin_amdgcn_readlane(r.taskCount, c), lane, order);
-				};
-#pragma unroll
-				for (int k = 0; k < CC_DA; ++k)
-					issue(k, 0);
-				NV_STAMP(2);
-				for (bool more = true; more;)
-				{
-					more = false;
-#pragma unroll
-					for (int k = 0; k < CC_DA; ++k)
-					{
-						ringP_wait<CC_DA - 1>(ring[k]);
-						uint64_t any = 0;
-						if (first[k] != ~0u)
-						{
-							any = filter_command(first[k], ring[k].v.x, ring[k].v.y, 0u);
-							if (paired[k])
-								any |= filter_command(first[k] + 1, ring[k].v.z, ring[k].v.w, 0u);
-						}
-						issue(k, any);
-						more = more || first[k] != ~0u;
-					}
-				}
-			}
-			else
 			{
 				SlotA ring[CC_DA];
 #pragma unroll
 				for (int k = 0; k < CC_DA; ++k)
-				{
-					const uint32_t c = (uint32_t)k < cnt ? k : cnt - 1; // clamped: redundant but unconditional loads
-					ringA_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, c), __builtin_amdgcn_readlane(r.taskCount, c),
-					                  __builtin_amdgcn_readlane(r.meshletVisibilityOffset, c), lane, 0);
-				}
+					issueA(ring[k], (uint32_t)k < cnt ? k : cnt - 1, 0); // clamped: redundant but unconditional loads
+				asm volatile("s_waitcnt vmcnt(%2)" : "+v"(g0), "+v"(g1) : "i"(CC_DA * (BITS ? 2 : 1)) : "memory"); // the gather
+				gather_finish();
 				NV_STAMP(2);
 				for (uint32_t i = 0; i < cnt; i += CC_DA)
 				{
@@ -683,13 +661,13 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 						uint64_t any = 0;
 						if (c < cnt)
 							any = filter_command(c, (uint32_t)ring[k].bounds, (uint32_t)(ring[k].bounds >> 32), ring[k].mvbWord);
-						const uint32_t cn = c + CC_DA < cnt ? c + CC_DA : cnt - 1;
-						ringA_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, cn), __builtin_amdgcn_readlane(r.taskCount, cn),
-						                  __builtin_amdgcn_readlane(r.meshletVisibilityOffset, cn), lane, any);
+						if (any)
+							candMask |= 1ull << c;
+						issueA(ring[k], c + CC_DA < cnt ? c + CC_DA : cnt - 1, any);
 					}
 				}
 			}
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // drain: the rings' registers are reused below
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // drain: the ring's registers are reused below
 			NV_STAMP(3);
 
 			// ---- pass B: exact tests (reference arithmetic) for the commands that can have survivors, bounds + cone
@@ -738,8 +716,8 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 							cur.cone = ring[k].cone;
 							cur.mvbWord = ring[k].mvbWord;
 							m = cull_command<LATE, BITS>(a, cmd, du, cur, lane);
-							if (lane == 0)
-								s_mask[wave][c] = m;
+							maskLo = writelane_u32(maskLo, (uint32_t)m, c);
+							maskHi = writelane_u32(maskHi, (uint32_t)(m >> 32), c);
 						}
 						if (pending)
 						{
@@ -788,17 +766,17 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 					}
 					m = cull_command<LATE, BITS>(a, cmd, du, cur, lane);
 				}
-				if (lane == 0)
-					s_mask[wave][c] = m;
+				maskLo = writelane_u32(maskLo, (uint32_t)m, c);
+				maskHi = writelane_u32(maskHi, (uint32_t)(m >> 32), c);
 			}
 		}
 		NV_STAMP(4);
 
-		// the segment's ballots leave through LDS: one 8-B store per lane (32-B runs per chunk), after the ring has
-		// drained so that no store sits between counted loads
+		// the segment's ballots: one 8-B store per lane (32-B runs per chunk), after the rings have drained so that no
+		// store sits between counted loads
 		if (lane < cnt && myIdx < numCmds)
 		{
-			const uint64_t m = s_mask[wave][lane];
+			const uint64_t m = ((uint64_t)maskHi << 32) | maskLo;
 			a.masks[myIdx] = m;
 			// survivors per scatter tile: fire-and-forget adds, only from commands that have survivors
 			if (m)
@@ -811,12 +789,13 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 
 // K2: contiguous ranges, ordered scatter.  Tile t's append base = count word + survivors of tiles < t, which the cull
 // kernel has already accumulated per tile: no workgroup waits on another, the kernel is a handful of parallel loads,
-// one LDS reduction and the stores.
+// one scan and the stores.  Each lane owns 4 consecutive commands (32 B of ballots, two 16-B loads).
 template <int DUMMY>
 __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs a)
 {
 	__shared__ uint32_t s_part[CC_WAVES];
 	__shared__ uint32_t s_sum[CC_WAVES];
+	constexpr uint32_t PER_LANE = 4, STEP = CC_THREADS * PER_LANE;
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
@@ -845,13 +824,22 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs
 	}
 	const uint32_t first = tile * T;
 	const uint32_t n = tile < numTiles ? (numCmds - first < T ? numCmds - first : T) : 0u;
-	constexpr int CC_KEEP = 4; // this tile's ballots stay in registers for the usual T <= 1024
-	uint64_t kept[CC_KEEP];
-#pragma unroll
-	for (int j = 0; j < CC_KEEP; ++j)
+	// first step's ballots (the only step for the usual T <= 1024); the ballot array is padded, so the 16-B loads of
+	// a partially valid quad stay in range and are masked afterwards
+	uint64_t m4[PER_LANE];
 	{
-		const uint32_t c = j * CC_THREADS + tid;
-		kept[j] = c < n ? a.masks[first + c] : 0ull;
+		const uint32_t c = tid * PER_LANE;
+		const ulonglong2* src = reinterpret_cast<const ulonglong2*>(a.masks + first + c);
+		ulonglong2 lo = make_ulonglong2(0, 0), hi = make_ulonglong2(0, 0);
+		if (c < n)
+		{
+			lo = src[0];
+			hi = src[1];
+		}
+		m4[0] = c + 0 < n ? lo.x : 0ull;
+		m4[1] = c + 1 < n ? lo.y : 0ull;
+		m4[2] = c + 2 < n ? hi.x : 0ull;
+		m4[3] = c + 3 < n ? hi.y : 0ull;
 	}
 
 	const uint32_t bank = k2parity & 1u;
@@ -880,34 +868,35 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs
 		s_sum[wave] = wAll;
 	}
 	__syncthreads();
-	uint32_t exclusive = base0, total = base0;
+	uint32_t running = base0, total = base0;
 #pragma unroll
 	for (int w = 0; w < CC_WAVES; ++w)
 	{
-		exclusive += s_part[w];
+		running += s_part[w];
 		total += s_sum[w];
 	}
 	if (tid == 0 && tile == numTiles - 1)
 		a.clusterCount4[0] = total; // what the chain of atomicAdds leaves in clusterCount
-	__syncthreads(); // s_part is reused below
 
-	// ---- ordered scatter, 256 commands per step: one command per lane for the scan, one command per iteration for
-	// the (coalesced) stores; clustercull.comp.glsl:137-138 drops entries past CLUSTER_LIMIT
-	uint32_t running = exclusive;
-	for (uint32_t c0 = 0, step = 0; c0 < n; c0 += CC_THREADS, ++step)
+	// ---- ordered scatter, 1024 commands per step: one scan per step, then one command per iteration for the
+	// (coalesced) stores; clustercull.comp.glsl:137-138 drops entries past CLUSTER_LIMIT
+	for (uint32_t c0 = 0; c0 < n; c0 += STEP)
 	{
-		const uint32_t c = c0 + tid;
-		uint64_t m;
-		switch (step) // static register indexing for the kept ballots
+		if (c0)
 		{
-		case 0: m = kept[0]; break;
-		case 1: m = kept[1]; break;
-		case 2: m = kept[2]; break;
-		case 3: m = kept[3]; break;
-		default: m = c < n ? a.masks[first + c] : 0ull; break;
+			const uint32_t c = c0 + tid * PER_LANE;
+#pragma unroll
+			for (uint32_t j = 0; j < PER_LANE; ++j)
+				m4[j] = c + j < n ? a.masks[first + c + j] : 0ull;
 		}
-		const uint32_t pc = (uint32_t)__builtin_popcountll(m);
-		uint32_t incl = pc;
+		uint32_t pc[PER_LANE], mine = 0;
+#pragma unroll
+		for (uint32_t j = 0; j < PER_LANE; ++j)
+		{
+			pc[j] = (uint32_t)__builtin_popcountll(m4[j]);
+			mine += pc[j];
+		}
+		uint32_t incl = mine;
 #pragma unroll
 		for (int o = 1; o < 64; o <<= 1)
 		{
@@ -915,36 +904,40 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs
 			if ((int)lane >= o)
 				incl += t;
 		}
-		__syncthreads(); // previous step's s_part readers are done
+		__syncthreads(); // s_part free (prefix reduction / previous step's readers are done)
 		if (lane == 63)
 			s_part[wave] = incl;
 		__syncthreads();
-		uint32_t waveBase = running;
+		uint32_t excl = running + incl - mine;
 #pragma unroll
 		for (int w = 0; w < CC_WAVES; ++w)
 		{
 			uint32_t p = s_part[w];
-			waveBase += w < (int)wave ? p : 0u;
+			excl += w < (int)wave ? p : 0u;
 			running += p;
 		}
-		const uint32_t excl = waveBase + incl - pc;
 
-		uint64_t owners = dbgNoScatter ? 0ull : __ballot(pc != 0);
-		while (owners)
+#pragma unroll
+		for (uint32_t j = 0; j < PER_LANE; ++j)
 		{
-			const int src = __builtin_ctzll(owners);
-			owners &= owners - 1;
-			const uint32_t mlo = __builtin_amdgcn_readlane((uint32_t)m, src);
-			const uint32_t mhi = __builtin_amdgcn_readlane((uint32_t)(m >> 32), src);
-			const uint32_t off = __builtin_amdgcn_readlane(excl, src);
-			const uint64_t ms = ((uint64_t)mhi << 32) | mlo;
-			if (ms >> lane & 1ull)
+			uint64_t owners = dbgNoScatter ? 0ull : __ballot(pc[j] != 0);
+			while (owners)
 			{
-				uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-				uint32_t index = off + rank;
-				if (index < NV_CLUSTER_LIMIT)
-					a.clusterIndices[index] = (first + c0 + wave * 64 + src) | (lane << 24);
+				const int src = __builtin_ctzll(owners);
+				owners &= owners - 1;
+				const uint32_t mlo = __builtin_amdgcn_readlane((uint32_t)m4[j], src);
+				const uint32_t mhi = __builtin_amdgcn_readlane((uint32_t)(m4[j] >> 32), src);
+				const uint32_t off = __builtin_amdgcn_readlane(excl, src);
+				const uint64_t ms = ((uint64_t)mhi << 32) | mlo;
+				if (ms >> lane & 1ull)
+				{
+					uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+					uint32_t index = off + rank;
+					if (index < NV_CLUSTER_LIMIT)
+						a.clusterIndices[index] = (first + c0 + (wave * 64 + src) * PER_LANE + j) | (lane << 24);
+				}
 			}
+			excl += pc[j];
 		}
 	}
 }
@@ -1038,12 +1031,12 @@ __global__ __launch_bounds__(CC_THREADS) void probe_kernel(ClusterArgs a)
 // ---------------------------------------------------------------------------------------------------------------
 // SoA mirror of the 12 cull bytes (nv_upload_meshlets)
 __global__ __launch_bounds__(256) void soa_split_kernel(const NvMeshlet* __restrict__ meshlets, uint32_t count, uint32_t padded,
-                                                       uint2* __restrict__ bounds, uint4* __restrict__ bounds2, uint32_t* __restrict__ cones)
+                                                       uint2* __restrict__ bounds, uint32_t* __restrict__ cones)
 {
 	uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= padded)
 		return;
-	uint2 b = make_uint2(0, 0), b64 = make_uint2(0, 0);
+	uint2 b = make_uint2(0, 0);
 	uint32_t c = 0;
 	if (i < count)
 	{
@@ -1052,14 +1045,7 @@ __global__ __launch_bounds__(256) void soa_split_kernel(const NvMeshlet* __restr
 		b.y = p[1];
 		c = p[2];
 	}
-	if (i + 64 < count)
-	{
-		const uint32_t* p = reinterpret_cast<const uint32_t*>(meshlets + i + 64);
-		b64.x = p[0];
-		b64.y = p[1];
-	}
 	bounds[i] = b;
-	bounds2[i] = make_uint4(b.x, b.y, b64.x, b64.y);
 	cones[i] = c;
 }
 
@@ -1136,9 +1122,9 @@ int launch_probe(hipStream_t stream, const ClusterArgs& a, bool soa, uint32_t gr
 	return (int)hipGetLastError();
 }
 
-int launch_soa_split(hipStream_t stream, const NvMeshlet* meshlets, uint32_t count, uint32_t padded, uint2* bounds, uint4* bounds2, uint32_t* cones)
+int launch_soa_split(hipStream_t stream, const NvMeshlet* meshlets, uint32_t count, uint32_t padded, uint2* bounds, uint32_t* cones)
 {
-	hipLaunchKernelGGL(soa_split_kernel, dim3((padded + 255) / 256), dim3(256), 0, stream, meshlets, count, padded, bounds, bounds2, cones);
+	hipLaunchKernelGGL(soa_split_kernel, dim3((padded + 255) / 256), dim3(256), 0, stream, meshlets, count, padded, bounds, cones);
 	return (int)hipGetLastError();
 }
 

@@ -22,11 +22,12 @@ int launch_cluster_scatter(hipStream_t, const ClusterArgs&, uint32_t scatterBloc
 size_t clustercull_mask_bytes();
 int launch_taskcull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t gridBlocks);
 int launch_probe(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
-int launch_soa_split(hipStream_t, const NvMeshlet*, uint32_t count, uint32_t padded, uint2* bounds, uint4* bounds2, uint32_t* cones);
+int launch_soa_split(hipStream_t, const NvMeshlet*, uint32_t count, uint32_t padded, uint2* bounds, uint32_t* cones);
 uint32_t clustercull_max_tiles(uint32_t gridBlocks);
 int launch_drawcull(hipStream_t, const DrawArgs&, int late, int task, uint32_t gridBlocks);
 uint32_t drawcull_max_tiles(uint32_t drawCount, uint32_t gridBlocks);
 int launch_tasksubmit(hipStream_t, uint32_t* count4, NvMeshTaskCommand* commands);
+int launch_reset_count(hipStream_t, uint32_t* a, uint32_t* b);
 int launch_clustersubmit(hipStream_t, uint32_t* cc4, uint32_t* clusterIndices);
 int launch_pack_counts(hipStream_t, const uint32_t*, const uint32_t*, const uint32_t*, uint64_t*);
 int launch_depthreduce(hipStream_t, const float* depth, uint32_t w, uint32_t h, const NvPyramidDesc& pyr);
@@ -52,7 +53,6 @@ struct nv_context
 	const NvMeshlet* mirroredFrom;
 	uint32_t mirroredCount;
 	uint2* soaBounds;
-	uint4* soaBounds2;
 	uint32_t* soaCones;
 	uint32_t soaCapacity;
 	// tuning knobs (environment, read once in nv_create): NV_DEBUG_MODE bit mask, NV_CC_BLOCKS_PER_CU
@@ -231,8 +231,6 @@ void nv_destroy(nv_context* ctx)
 		(void)hipFree(ctx->tileCounts);
 	if (ctx->soaBounds)
 		(void)hipFree(ctx->soaBounds);
-	if (ctx->soaBounds2)
-		(void)hipFree(ctx->soaBounds2);
 	if (ctx->soaCones)
 		(void)hipFree(ctx->soaCones);
 	if (ctx->timing)
@@ -330,7 +328,7 @@ int nv_upload_meshlets(nv_context* ctx, void* stream, const NvMeshlet* d_meshlet
 		return NV_EINVAL;
 	DeviceGuard guard(ctx->device);
 	// one extra 64-entry block so that a command's 64-lane window never leaves the mirror
-	uint32_t padded = round_up(meshletCount, 64) + 128;
+	uint32_t padded = round_up(meshletCount, 64) + 64;
 	if (padded > ctx->soaCapacity)
 	{
 		hipError_t e = hipStreamSynchronize((hipStream_t)stream);
@@ -338,22 +336,18 @@ int nv_upload_meshlets(nv_context* ctx, void* stream, const NvMeshlet* d_meshlet
 			return (int)e;
 		if (ctx->soaBounds)
 			(void)hipFree(ctx->soaBounds);
-		if (ctx->soaBounds2)
-			(void)hipFree(ctx->soaBounds2);
 		if (ctx->soaCones)
 			(void)hipFree(ctx->soaCones);
 		ctx->soaBounds = nullptr;
-		ctx->soaBounds2 = nullptr;
 		ctx->soaCones = nullptr;
 		ctx->soaCapacity = 0;
 		ctx->mirroredFrom = nullptr;
 		if (hipMalloc(&ctx->soaBounds, (size_t)padded * sizeof(uint2)) != hipSuccess ||
-		    hipMalloc(&ctx->soaBounds2, (size_t)padded * sizeof(uint4)) != hipSuccess ||
 		    hipMalloc(&ctx->soaCones, (size_t)padded * sizeof(uint32_t)) != hipSuccess)
 			return NV_ENOMEM;
 		ctx->soaCapacity = padded;
 	}
-	int rc = nv::launch_soa_split((hipStream_t)stream, d_meshlets, meshletCount, padded, ctx->soaBounds, ctx->soaBounds2, ctx->soaCones);
+	int rc = nv::launch_soa_split((hipStream_t)stream, d_meshlets, meshletCount, padded, ctx->soaBounds, ctx->soaCones);
 	if (rc)
 		return rc;
 	ctx->mirroredFrom = d_meshlets;
@@ -393,6 +387,14 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 	return rc;
 }
 
+int nv_reset_count(nv_context* ctx, void* stream, uint32_t* d_count4a, uint32_t* d_count4b)
+{
+	if (!ctx || (!d_count4a && !d_count4b))
+		return NV_EINVAL;
+	DeviceGuard guard(ctx->device);
+	return nv::launch_reset_count((hipStream_t)stream, d_count4a, d_count4b);
+}
+
 int nv_tasksubmit(nv_context* ctx, void* stream, uint32_t* d_count4, NvMeshTaskCommand* d_commands)
 {
 	if (!ctx || !d_count4 || !d_commands)
@@ -420,7 +422,6 @@ static int fill_cluster_args(nv_context* ctx, nv::ClusterArgs& a, const NvCullDa
 	a.meshlets = d_meshlets;
 	const bool soa = ctx->mirroredFrom == d_meshlets && ctx->soaBounds;
 	a.soaBounds = soa ? ctx->soaBounds : nullptr;
-	a.soaBounds2 = soa ? ctx->soaBounds2 : nullptr;
 	a.soaCones = soa ? ctx->soaCones : nullptr;
 	a.mvb = d_meshletVisibility;
 	a.masks = ctx->masks;

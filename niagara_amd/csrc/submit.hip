@@ -61,6 +61,24 @@ __global__ void pack_counts_kernel(const uint32_t* a, const uint32_t* b, const u
 	}
 }
 
+// the HIP analogue of vkCmdFillBuffer(buffer, 0, 4, 0) in front of each pass (src/niagara.cpp:1541,1586)
+__global__ void reset_count_kernel(uint32_t* a, uint32_t* b)
+{
+	if (threadIdx.x == 0)
+	{
+		if (a)
+			a[0] = 0;
+		if (b)
+			b[0] = 0;
+	}
+}
+
+int launch_reset_count(hipStream_t stream, uint32_t* a, uint32_t* b)
+{
+	hipLaunchKernelGGL(reset_count_kernel, dim3(1), dim3(64), 0, stream, a, b);
+	return (int)hipGetLastError();
+}
+
 int launch_tasksubmit(hipStream_t stream, uint32_t* count4, NvMeshTaskCommand* commands)
 {
 	hipLaunchKernelGGL(tasksubmit_kernel, dim3(1), dim3(64), 0, stream, count4, commands);

@@ -78,6 +78,9 @@ class Context:
         check(lib.nv_drawcull(self.h, _stream(), C.c_void_p(cull.ctypes.data), int(late), int(task), _ptr(db), _ptr(mb), _ptr(dcb),
                               _ptr(dccb), _ptr(dvb), None if pyramid is None else C.byref(pyramid)), "nv_drawcull")
 
+    def reset_count(self, a, b=None):
+        check(lib.nv_reset_count(self.h, _stream(), _ptr(a), _ptr(b)), "nv_reset_count")
+
     def tasksubmit(self, dccb, dcb):
         check(lib.nv_tasksubmit(self.h, _stream(), _ptr(dccb), _ptr(dcb)), "nv_tasksubmit")
 
@@ -147,7 +150,7 @@ class VisibilityPipeline:
 
     # src/niagara.cpp:1530-1574
     def cull(self, cull_data, late, task=True, post_pass=0):
-        self.dccb[0:1].zero_()                                      # vkCmdFillBuffer(dccb, 0, 4, 0)  (:1541)
+        self.ctx.reset_count(self.dccb)                             # vkCmdFillBuffer(dccb, 0, 4, 0)  (:1541)
         pass_data = cull_data.copy()
         pass_data["clusterBackfaceEnabled"] = 1 if post_pass == 0 else 0   # (:1549)
         pass_data["postPass"] = post_pass
@@ -157,7 +160,7 @@ class VisibilityPipeline:
 
     # src/niagara.cpp:1582-1611 (cluster branch of render())
     def render_clusters(self, cull_data, late, post_pass=0):
-        self.ccb[0:1].zero_()                                       # vkCmdFillBuffer(ccb, 0, 4, 0)  (:1586)
+        self.ctx.reset_count(self.ccb)                              # vkCmdFillBuffer(ccb, 0, 4, 0)  (:1586)
         pass_data = cull_data.copy()
         pass_data["postPass"] = post_pass                           # (:1595-1596)
         self.ctx.clustercull(pass_data, late, self.dcb, self.dccb, self.db, self.mlb, self.mvb, self.pyramid.desc, self.cib, self.ccb)
