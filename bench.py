@@ -4,8 +4,8 @@
 Workload (config.workload = "config3A"): BASELINE.json configs[2] — synthetic 10 M meshlets (bistro scale), i.e.
 156 250 full MeshTaskCommands over 15 625 draws, per-meshlet cone + frustum cull (`clustercull`, LATE = 0,
 clusterBackfaceEnabled = 1) with ordered compaction of the visible IDs.  One "step" = one pass of the hot path over
-one batch: reset of the count word (the caller's vkCmdFillBuffer, src/niagara.cpp:1586) + nv_clustercull, with
-inputs resident in HBM.  Steps rotate over `--copies` distinct input sets so that every pass streams from HBM rather
+one batch: reset of the count word (the caller's vkCmdFillBuffer, src/niagara.cpp:1586; fused into the pass through
+NV_OPT_FUSED_COUNT_RESET unless --explicit-reset) + nv_clustercull, with inputs resident in HBM.  Steps rotate over `--copies` distinct input sets so that every pass streams from HBM rather
 than from the 256 MiB Infinity Cache.  N > 1: the pool shards by contiguous command ranges, every rank culls its own
 10 M meshlets (weak scaling) and the only collective is one all-reduce of the visible counts per step (RCCL).
 
@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=4.0)
     ap.add_argument("--aos", action="store_true", help="read the 24-B AoS meshlets in place (no SoA mirror)")
+    ap.add_argument("--explicit-reset", action="store_true",
+                    help="reference contract: zero the count word with a separate launch (nv_reset_count) instead of NV_OPT_FUSED_COUNT_RESET")
     return ap.parse_args()
 
 
@@ -72,6 +74,8 @@ def main():
     count4 = synth.count4_for(n_cmd)
 
     ctx = P.Context(local_rank)
+    if not args.explicit_reset:
+        ctx.set_option(P.NV_OPT_FUSED_COUNT_RESET, 1)  # the pass absorbs the caller's vkCmdFillBuffer(ccb, 0, 4, 0)
     db = P.to_device(draws, dev)
     mlb = torch.empty(copies * n_meshlets * L.MESHLET.itemsize, dtype=torch.uint8, device=dev)
     one = torch.from_numpy(meshlets.view(np.uint8).reshape(-1))
@@ -87,7 +91,8 @@ def main():
     torch.cuda.synchronize()
 
     def step(i):
-        ctx.reset_count(ccb)  # the caller's vkCmdFillBuffer(ccb, 0, 4, 0)
+        if args.explicit_reset:
+            ctx.reset_count(ccb)  # the caller's vkCmdFillBuffer(ccb, 0, 4, 0) as its own launch
         ctx.clustercull(cd, 0, dcbs[i % copies], dccb, db, mlb, None, None, cib, ccb)
         if world > 1:
             ctx.pack_counts(None, dccb, ccb, counts)
@@ -153,7 +158,7 @@ def main():
             "config": {"workload": "config3A: %d meshlets/GPU, %d task commands over %d draws, cone+frustum clustercull (LATE=0) + ordered compaction"
                                    % (n_meshlets, n_cmd, n_draws),
                        "meshlets_per_gpu": n_meshlets, "commands_per_gpu": n_cmd, "draws_per_gpu": n_draws,
-                       "input_copies_rotated": copies, "meshlet_layout": "AoS24" if args.aos else "SoA12",
+                       "input_copies_rotated": copies, "count_reset": "explicit launch" if args.explicit_reset else "fused (NV_OPT_FUSED_COUNT_RESET)", "meshlet_layout": "AoS24" if args.aos else "SoA12",
                        "visible_per_gpu": visible, "visible_total": total_visible, "sharding": "commands x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "cluster_mask_kernel", "kernel_avg_us": kernel_avg_s * 1e6,

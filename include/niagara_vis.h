@@ -183,6 +183,14 @@ int nv_status(nv_context* ctx, void* stream);
 int nv_profile_enable(nv_context* ctx, int enabled);
 int nv_profile_read(nv_context* ctx, float out_ms[NV_PROF_SLOTS], uint32_t out_count[NV_PROF_SLOTS]);
 
+/* ---- options ----
+ * NV_OPT_FUSED_COUNT_RESET (default 0): when 1, nv_drawcull and nv_clustercull start their append at index 0 whatever
+ * the count word holds, i.e. they absorb the caller's vkCmdFillBuffer(count, 0, 4, 0) (src/niagara.cpp:1541,1586) and
+ * the launch boundary that goes with it.  With 0 the reference contract holds: the append starts at the value found in
+ * the count word, which the caller zeroes (nv_reset_count or any memset). */
+#define NV_OPT_FUSED_COUNT_RESET 1
+int nv_set_option(nv_context* ctx, int option, int value);
+
 /* ---- scene upload hook (next to uploadBuffer(mlb), src/niagara.cpp:1055) ----
  * Builds the library-owned SoA mirror of the 12 cull bytes of every meshlet
  * (bounds: 4 x fp16 = 8 B, cone: 4 x s8 = 4 B).  nv_clustercull uses the mirror when

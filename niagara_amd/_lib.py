@@ -39,6 +39,7 @@ _SIGS = {
     "nv_destroy": (None, [_vp]),
     "nv_version": (C.c_char_p, []),
     "nv_status": (_i, [_vp, _vp]),
+    "nv_set_option": (_i, [_vp, _i, _i]),
     "nv_profile_enable": (_i, [_vp, _i]),
     "nv_profile_read": (_i, [_vp, C.POINTER(C.c_float * 4), C.POINTER(C.c_uint32 * 4)]),
     "nv_upload_meshlets": (_i, [_vp, _vp, _vp, _u32]),

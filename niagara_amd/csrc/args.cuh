@@ -45,6 +45,7 @@ struct ClusterArgs
 	uint32_t commandCountOverride; // probe/taskcull: explicit command count (0 = use count4[1]*64)
 	float* __restrict__ probeOut;
 	uint32_t debugMode; // tuning experiments only (NV_DEBUG_MODE); 0 in production
+	uint32_t fusedReset; // NV_OPT_FUSED_COUNT_RESET
 };
 
 struct DrawArgs
@@ -59,6 +60,7 @@ struct DrawArgs
 	uint64_t* state;
 	OrderCtl* ctl;
 	uint32_t stateCapacity;
+	uint32_t fusedReset; // NV_OPT_FUSED_COUNT_RESET
 };
 
 } // namespace nv

@@ -653,6 +653,19 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 				NV_STAMP(2);
 				for (uint32_t i = 0; i < cnt; i += CC_DA)
 				{
+					// The SIMD arbitrates oldest-first, which lets the oldest resident workgroup run ahead and leaves
+					// the youngest to finish alone at single-wave issue rate.  Rotating the priority with the
+					// workgroup index evens the progress of the waves that share a SIMD (speed only).
+					if (!(a.debugMode & 256u)) // bit 8 (experiments) turns the rotation off
+					{
+						switch ((blockIdx.x + i / CC_DA) & 3u)
+						{
+						case 0: __builtin_amdgcn_s_setprio(0); break;
+						case 1: __builtin_amdgcn_s_setprio(1); break;
+						case 2: __builtin_amdgcn_s_setprio(2); break;
+						default: __builtin_amdgcn_s_setprio(3); break;
+						}
+					}
 #pragma unroll
 					for (int k = 0; k < CC_DA; ++k)
 					{
@@ -810,7 +823,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs
 	// Everything below was written by the cull kernel, i.e. before this launch: plain loads, all issued together.
 	// Both banks of tile counts are read speculatively so that no load waits for the parity word.
 	const uint32_t k2parity = a.tileCounts->k2parity;
-	const uint32_t base0 = a.clusterCount4[0];
+	const uint32_t base0 = a.fusedReset ? 0u : a.clusterCount4[0];
 	uint32_t cnt0[2] = { 0, 0 }, cnt1[2] = { 0, 0 }; // this thread's tiles tid and tid + 256, per bank
 #pragma unroll
 	for (int j = 0; j < 2; ++j)

@@ -58,6 +58,7 @@ struct nv_context
 	// tuning knobs (environment, read once in nv_create): NV_DEBUG_MODE bit mask, NV_CC_BLOCKS_PER_CU
 	uint32_t debugMode;
 	uint32_t ccBlocksPerCU;
+	uint32_t fusedReset;
 	// nv_profile_*: event pairs recorded on the launch stream, drained by nv_profile_read
 	int profiling;
 	std::vector<ProfRecord>* prof;
@@ -265,6 +266,20 @@ int nv_status(nv_context* ctx, void* stream)
 	return NV_OK;
 }
 
+int nv_set_option(nv_context* ctx, int option, int value)
+{
+	if (!ctx)
+		return NV_EINVAL;
+	switch (option)
+	{
+	case NV_OPT_FUSED_COUNT_RESET:
+		ctx->fusedReset = value ? 1u : 0u;
+		return NV_OK;
+	default:
+		return NV_EINVAL;
+	}
+}
+
 int nv_profile_enable(nv_context* ctx, int enabled)
 {
 	if (!ctx)
@@ -381,6 +396,7 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 	a.state = ctx->state;
 	a.ctl = ctx->ctl;
 	a.stateCapacity = ctx->stateCapacity;
+	a.fusedReset = ctx->fusedReset;
 	hipEvent_t e0 = prof_mark(ctx, (hipStream_t)stream);
 	rc = nv::launch_drawcull((hipStream_t)stream, a, late, task, grid);
 	prof_push(ctx, NV_PROF_DRAWCULL, e0, prof_mark(ctx, (hipStream_t)stream));
@@ -448,6 +464,7 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	a.clusterIndices = d_clusterIndices;
 	a.clusterCount4 = d_clusterCount4;
 	a.debugMode = ctx->debugMode;
+	a.fusedReset = ctx->fusedReset;
 	if (ctx->debugMode & 8u)
 	{
 		if (!ctx->timing)

@@ -138,28 +138,40 @@ __global__ __launch_bounds__(DC_THREADS) void drawcull_kernel(DrawArgs a)
 	T = T < DC_THREADS ? DC_THREADS : (T > DC_TMAX ? DC_TMAX : T);
 	const uint32_t numTiles = (drawCount + T - 1) / T;
 	const uint32_t epoch = load_epoch(a.ctl);
-	const uint32_t base0 = a.count4[0];
+	const uint32_t base0 = a.fusedReset ? 0u : a.count4[0];
 
 	for (uint32_t tile = blockIdx.x; tile < numTiles; tile += G)
 	{
 		const uint32_t first = tile * T;
 		const uint32_t n = drawCount - first < T ? drawCount - first : T;
 
-		// ---- phase 1: one draw per lane per step; the next step's 52 bytes are in flight during the tests
+		// ---- phase 1: one draw per lane per step, four steps' records (4 x 52 bytes per lane) requested before any of
+		// them is used.  Indices past the tile are clamped, not branched, so that the loads are unconditional and the
+		// compiler can count them (s_waitcnt vmcnt(N)) instead of draining after each one.
 		uint32_t threadSum = 0;
-		DrawLoad cur = {}, nxt = {};
-		if (tid < n)
-			cur = load_draw_record(a, first + tid);
-		for (uint32_t c = tid; c < n; c += DC_THREADS)
+		constexpr int DC_BATCH = 4;
+		for (uint32_t c0 = 0; c0 < n; c0 += DC_THREADS * DC_BATCH)
 		{
-			if (c + DC_THREADS < n)
-				nxt = load_draw_record(a, first + c + DC_THREADS);
-			DrawResult res = decide_draw<LATE, TASK>(a, first + c, cur.d0, cur.d1, cur.d2, cur.oldVis);
-			s_count[c] = res.count;
-			s_flags[c] = res.lodWord;
-			s_old[c] = cur.oldVis;
-			threadSum += res.count;
-			cur = nxt;
+			DrawLoad ld[DC_BATCH];
+#pragma unroll
+			for (int j = 0; j < DC_BATCH; ++j)
+			{
+				const uint32_t c = c0 + j * DC_THREADS + tid;
+				ld[j] = load_draw_record(a, first + (c < n ? c : n - 1));
+			}
+#pragma unroll
+			for (int j = 0; j < DC_BATCH; ++j)
+			{
+				const uint32_t c = c0 + j * DC_THREADS + tid;
+				if (c < n)
+				{
+					DrawResult res = decide_draw<LATE, TASK>(a, first + c, ld[j].d0, ld[j].d1, ld[j].d2, ld[j].oldVis);
+					s_count[c] = res.count;
+					s_flags[c] = res.lodWord;
+					s_old[c] = ld[j].oldVis;
+					threadSum += res.count;
+				}
+			}
 		}
 
 		// ---- phase 2 + 3

@@ -35,6 +35,9 @@ def from_device(t, dtype, count=None):
     return out[:count] if count is not None else out
 
 
+NV_OPT_FUSED_COUNT_RESET = 1
+
+
 class Context:
     """one nv_context per device; not re-entrant (one stream at a time)"""
 
@@ -59,6 +62,9 @@ class Context:
 
     def status(self):
         check(lib.nv_status(self.h, _stream()), "nv_status")
+
+    def set_option(self, option, value):
+        check(lib.nv_set_option(self.h, int(option), int(value)), "nv_set_option")
 
     def profile(self, enabled):
         check(lib.nv_profile_enable(self.h, int(enabled)), "nv_profile_enable")

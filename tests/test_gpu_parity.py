@@ -451,3 +451,30 @@ def test_frustum_filter_is_exact_on_the_planes(ctx):
     draws["orientation"] *= np.float32(7.5)
     draws["position"][::5] *= np.float32(1e6)
     _compare_cluster_pass(ctx, draws, meshlets, commands, n, cd, 0, None, None, None)
+
+
+def test_fused_count_reset_option(ctx):
+    """NV_OPT_FUSED_COUNT_RESET: the pass starts its append at 0 whatever the count word holds; without it the append
+    starts at the value found there (atomicAdd semantics)"""
+    draws, meshlets, commands, n, cd = _cluster_inputs(800, 5, seed=4)
+    draws["position"] *= np.float32(0.2)
+    dev = ctx.device
+    c4 = synth.count4_for(n)
+    cib_o, cc4_o = np.zeros(len(commands) * 64 + 256, np.uint32), np.zeros(4, np.uint32)
+    oracle.clustercull(cd, 0, commands, c4, draws, meshlets, None, None, cib_o, cc4_o)
+    total = int(cc4_o[0])
+    db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+    ctx.upload_meshlets(mlb, len(meshlets))
+    dccb = torch.from_numpy(c4.view(np.int32).copy()).to(dev)
+    cib = torch.zeros(len(commands) * 64 + 256, dtype=torch.int32, device=dev)
+    ccb = torch.tensor([7, 0, 0, 0], dtype=torch.int32, device=dev)
+    ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
+    assert int(ccb[0].item()) == total + 7 and (G.host_u32(cib)[7:7 + total] == cib_o[:total]).all()
+    ctx.set_option(P.NV_OPT_FUSED_COUNT_RESET, 1)
+    try:
+        ccb[0] = 12345
+        ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
+        assert int(ccb[0].item()) == total and (G.host_u32(cib)[:total] == cib_o[:total]).all()
+    finally:
+        ctx.set_option(P.NV_OPT_FUSED_COUNT_RESET, 0)
+    ctx.status()

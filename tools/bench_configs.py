@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench_configs.py — the other BASELINE.json configs (2, 3B, 4, roofline size), one JSON line each.
+
+Not the driver's bench (that is bench.py = config 3A); these numbers feed DESIGN.md.  Per-kernel times come from the
+library's HIP events on the launch stream (nv_profile_*), median over `--iters` launches, inputs rotated so that every
+launch is cache-cold where the working set would otherwise fit the 256 MiB Infinity Cache.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from niagara_amd import host, synth  # noqa: E402
+from niagara_amd import layouts as L  # noqa: E402
+from niagara_amd import pipeline as P  # noqa: E402
+
+HBM = 8000.0
+
+
+def timed(ctx, fn, iters, slot):
+    for i in range(3):
+        fn(i)
+    torch.cuda.synchronize()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for i in range(iters):
+        fn(i)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / iters
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    ms, n = prof[slot]
+    return wall * 1e6, ms / max(1, n) * 1e3, prof
+
+
+def config2(ctx, iters, n_draws=1_000_000, copies=6):
+    """1 M MeshDraw spheres, frustum cull + LOD + ordered compaction: drawcull<LATE=0,TASK=0>"""
+    dev = ctx.device
+    meshes, _ = synth.make_meshes(1, 8, 1 << 12)
+    meshes["center"] = (-0.016, -0.028, -0.034)
+    meshes["radius"] = 0.598  # kitten sphere (tests/golden/kitten_bounds.json)
+    draws = host.synth_draws(n_draws, 1, 300.0)
+    host.assign_visibility_offsets(draws, meshes)
+    cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, lodEnabled=1)
+    mb = P.to_device(meshes, dev)
+    dbs = [P.to_device(draws, dev) for _ in range(copies)]
+    dvbs = [torch.ones(n_draws, dtype=torch.int32, device=dev) for _ in range(copies)]
+    dcb = torch.zeros(n_draws * 24 + 64, dtype=torch.uint8, device=dev)
+    dccb = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    def step(i):
+        ctx.reset_count(dccb)
+        ctx.drawcull(cd, 0, 0, dbs[i % copies], mb, dcb, dccb, dvbs[i % copies], None)
+
+    wall, k_us, _ = timed(ctx, step, iters, "drawcull")
+    v = int(dccb[0].item())
+    algo = n_draws * 52 + v * 24 + 208 + 4
+    return dict(config="2: 1M draws, drawcull<0,0>", draws=n_draws, visible=v, kernel_us=k_us, step_us=wall, draws_per_s=n_draws / (k_us * 1e-6),
+                algorithmic_bytes=algo, achieved_GBs=algo / k_us / 1e3, frac=algo / k_us / 1e3 / HBM)
+
+
+def config3b(ctx, iters, n_draws=15625 * 4):
+    """contract path: drawcull<0,TASK> (LOD on, 64 meshes x 4 LODs) -> tasksubmit -> clustercull<0>"""
+    dev = ctx.device
+    meshes, total = synth.make_meshes(64, 4, 640)
+    meshlets = synth.make_meshlets(total)
+    draws = host.synth_draws(n_draws, 64, 300.0)
+    slots, _ = host.assign_visibility_offsets(draws, meshes)
+    cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, lodEnabled=1, clusterBackfaceEnabled=1)
+    cd["cullingEnabled"] = 0  # every draw emits commands: the cluster pass sees the whole pool
+    pipe = P.VisibilityPipeline(meshes, meshlets, draws, (1024, 768), ctx=ctx, task_capacity=n_draws * 10 + 64, cluster_capacity=1 << 22)
+    pipe.dvb.fill_(1)
+
+    def step(i):
+        pipe.cull(cd, late=False, task=True)
+        pipe.render_clusters(cd, late=False)
+
+    wall, k_us, prof = timed(ctx, step, iters, "cluster_cull")
+    cmds = int(pipe.dccb[0].item())
+    tested = int((P.from_device(pipe.dcb, L.TASKCMD)[:cmds]["taskCount"]).sum())
+    return dict(config="3B: drawcull<0,1> -> tasksubmit -> clustercull<0>", draws=n_draws, task_commands=cmds, meshlets_tested=tested,
+                visible=int(pipe.ccb[0].item()), step_us=wall, cluster_cull_us=k_us, cluster_scatter_us=prof["cluster_scatter"][0] / max(1, prof["cluster_scatter"][1]) * 1e3,
+                drawcull_us=prof["drawcull"][0] / max(1, prof["drawcull"][1]) * 1e3, meshlets_per_s=tested / (wall * 1e-6))
+
+
+def config4(ctx, iters, size=4096, n_draws=15625, cpd=10):
+    """two-phase HiZ: 4096^2 depth -> 2048^2 x 12 pyramid, then clustercull<LATE=1> with cluster occlusion over 10 M meshlets"""
+    dev = ctx.device
+    depth = torch.from_numpy(synth.make_depth(size, size)).to(dev)
+    pyr = P.DepthPyramid(dev, size, size)
+
+    def build(i):
+        ctx.depthreduce(depth, size, size, pyr.desc)
+
+    wall_p, k_p, _ = timed(ctx, build, iters, "depthreduce")
+    pyr_bytes = 4 * size * size + pyr.desc.totalTexels * 4
+    draws, meshlets, commands, n = synth.cluster_scene(n_draws, cpd)
+    cd = host.build_cull_data(draw_count=n_draws, viewport=(size, size), pyramid=(pyr.width, pyr.height), cullingEnabled=1, clusterBackfaceEnabled=1,
+                              clusterOcclusionEnabled=1, occlusionEnabled=1)
+    rng = np.random.default_rng(7)
+    commands["lateDrawVisibility"][:n] = rng.integers(0, 2, n)
+    db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+    ctx.upload_meshlets(mlb, len(meshlets))
+    dccb = torch.from_numpy(synth.count4_for(n).view(np.int32).copy()).to(dev)
+    mvb0 = torch.from_numpy(rng.integers(0, 2 ** 32, n * 2 + 4, dtype=np.uint64).astype(np.uint32).view(np.int32)).to(dev)
+    mvb = mvb0.clone()
+    cib = torch.zeros(n * 64 + 256, dtype=torch.int32, device=dev)
+    ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    def late(i):
+        mvb.copy_(mvb0)
+        ctx.reset_count(ccb)
+        ctx.clustercull(cd, 1, dcb, dccb, db, mlb, mvb, pyr.desc, cib, ccb)
+
+    wall_c, k_c, prof = timed(ctx, late, iters, "cluster_cull")
+    m = n * 64
+    algo = m * 12 + n * 68 + n * 8 + m // 4
+    return dict(config="4: 4096^2 depth pyramid + 10M-meshlet late clustercull with HiZ", pyramid_us=k_p, pyramid_bytes=pyr_bytes,
+                pyramid_GBs=pyr_bytes / k_p / 1e3, pyramid_frac=pyr_bytes / k_p / 1e3 / HBM, texels_per_s=size * size / (k_p * 1e-6),
+                late_cull_us=k_c, late_scatter_us=prof["cluster_scatter"][0] / max(1, prof["cluster_scatter"][1]) * 1e3, late_visible=int(ccb[0].item()),
+                late_algorithmic_bytes=algo, late_frac=algo / k_c / 1e3 / HBM, meshlets_per_s=m / ((k_c + prof["cluster_scatter"][0] / max(1, prof["cluster_scatter"][1]) * 1e3) * 1e-6))
+
+
+def roofline_size(ctx, iters, n_draws=156250, cpd=10, aos=False):
+    """config 3A x 10 (100 M meshlets, 1.2 GB of cull bytes): HBM, not launch latency or the Infinity Cache, is the bound"""
+    dev = ctx.device
+    draws, meshlets, commands, n = synth.cluster_scene(n_draws, cpd)
+    cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, clusterBackfaceEnabled=1)
+    db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+    if not aos:
+        ctx.upload_meshlets(mlb, len(meshlets))
+    dccb = torch.from_numpy(synth.count4_for(n).view(np.int32).copy()).to(dev)
+    cib = torch.zeros(min(n * 64, L.CLUSTER_LIMIT) + 256, dtype=torch.int32, device=dev)
+    ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    def step(i):
+        ctx.reset_count(ccb)
+        ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
+
+    wall, k_us, prof = timed(ctx, step, iters, "cluster_cull")
+    m = n * 64
+    algo = m * (24 if aos else 12) + n * 76
+    return dict(config="3A x10 (%s)" % ("AoS in place" if aos else "SoA mirror"), meshlets=m, visible=int(ccb[0].item()), cull_us=k_us,
+                scatter_us=prof["cluster_scatter"][0] / max(1, prof["cluster_scatter"][1]) * 1e3, step_us=wall, algorithmic_bytes=algo,
+                achieved_GBs=algo / k_us / 1e3, frac=algo / k_us / 1e3 / HBM, meshlets_per_s=m / (wall * 1e-6))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    ctx = P.Context(0)
+    runs = {"2": lambda: config2(ctx, a.iters), "3b": lambda: config3b(ctx, a.iters), "4": lambda: config4(ctx, a.iters),
+            "big": lambda: roofline_size(ctx, max(5, a.iters // 3)), "big_aos": lambda: roofline_size(P.Context(0), max(5, a.iters // 3), aos=True)}
+    for k, fn in runs.items():
+        if a.only and k not in a.only.split(","):
+            continue
+        print(json.dumps(fn()), flush=True)
+    ctx.status()
+    ctx.close()
