@@ -105,8 +105,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
 
-    # per-kernel HIP events are recorded by the library on the launch stream (nv_profile_*), inside the timed region
-    ctx.profile(True)
+    # ---- timed region: exactly `steps` passes, no instrumentation
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -115,6 +114,16 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+
+    # ---- roofline leg: the same `steps` passes again with the library's HIP events bracketing each kernel on the
+    # launch stream (nv_profile_*).  It is a separate loop because an event record is itself a barrier packet: three
+    # records per pass serialise the launches and cost ~10 us per pass, which would deflate `value` by ~25 %.
+    ctx.profile(True)
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    profiled = time.perf_counter() - t1
     prof = ctx.profile_read()
     ctx.profile(False)
     ctx.status()
@@ -130,7 +139,7 @@ def main():
 
     cull_ms, cull_n = prof["cluster_cull"]
     scat_ms, scat_n = prof["cluster_scatter"]
-    kernel_avg_s = cull_ms / max(1, cull_n) * 1e-3      # dominant kernel: cluster_mask_kernel
+    kernel_avg_s = max(cull_ms / max(1, cull_n) * 1e-3, 1e-9)      # dominant kernel: cluster_mask_kernel
     scatter_avg_s = scat_ms / max(1, scat_n) * 1e-3
 
     # algorithmic bytes.  Whole pass: 12 cull bytes per meshlet + (20 + 48) per command + 4 per survivor
@@ -163,7 +172,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "cluster_mask_kernel", "kernel_avg_us": kernel_avg_s * 1e6,
                          "algorithmic_bytes": algo_bytes, "launches_timed": cull_n,
-                         "scatter_kernel_avg_us": scatter_avg_s * 1e6,
+                         "scatter_kernel_avg_us": scatter_avg_s * 1e6, "ms_per_step_with_events": profiled / args.steps * 1e3,
                          "pass_algorithmic_bytes": pass_bytes,
                          "pass_frac": pass_bytes / (kernel_avg_s + scatter_avg_s) / 1e9 / HBM_PEAK_GBS},
         }
