@@ -198,6 +198,11 @@ int nv_set_option(nv_context* ctx, int option, int value);
  * records directly otherwise. */
 int nv_upload_meshlets(nv_context* ctx, void* stream, const NvMeshlet* d_meshlets, uint32_t meshletCount);
 
+/* Upload hook next to uploadBuffer(mb) (src/niagara.cpp:1049): registers the Mesh table's pointer and size.  nv_drawcull
+ * stages a registered table of <= 64 meshes in LDS (every draw reads its mesh's bounds, LOD errors and LOD range);
+ * unregistered or larger tables are gathered from global memory.  The table is only read at pass time. */
+int nv_upload_meshes(nv_context* ctx, void* stream, const NvMesh* d_meshes, uint32_t meshCount);
+
 /* ---- the passes ---- */
 
 /* drawcull.comp.glsl:54-156; dispatch at src/niagara.cpp:1548-1556.
@@ -233,6 +238,25 @@ int nv_taskcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
                 const NvMeshTaskCommand* d_commands, const uint32_t* d_count4, const NvMeshDraw* d_draws,
                 const NvMeshlet* d_meshlets, uint32_t* d_meshletVisibility, const NvPyramidDesc* pyramid,
                 uint32_t* d_payloads, uint32_t* d_payloadCounts);
+
+/* ---- downstream decode ----
+ * What the mesh stage does with the lists before it touches a vertex (src/shaders/meshlet.mesh.glsl:91-116): the indirect
+ * grid {16, Y, 16} written by nv_clustersubmit is walked as index = x + 256 y + 16 z, the entry is decoded
+ * (~0 = padding -> no outputs; else command = ci & 0xffffff, meshlet = command.taskOffset + (ci >> 24)) and the meshlet
+ * header is read.  One 32-byte record per index in [0, 256 Y) and three 64-bit totals (accumulated: zero them first). */
+typedef struct NvClusterRecord
+{
+	uint32_t drawId;       /* ~0 for a padding entry */
+	uint32_t meshletIndex; /* mi */
+	uint32_t vertexCount, triangleCount; /* SetMeshOutputsEXT arguments */
+	uint32_t vertexOffset; /* = dataOffset */
+	uint32_t indexOffset;  /* dataOffset + (shortRefs ? (vertexCount + 1) / 2 : vertexCount) */
+	uint32_t baseVertex;
+	uint32_t shortRefs;
+} NvClusterRecord;
+int nv_cluster_expand(nv_context* ctx, void* stream, const NvMeshTaskCommand* d_commands, const NvMeshlet* d_meshlets,
+                      const uint32_t* d_clusterIndices, const uint32_t* d_clusterCount4, NvClusterRecord* d_records,
+                      uint32_t recordCapacity, uint64_t* d_totals3 /* clusters, vertices, triangles */);
 
 /* depthreduce.comp.glsl:14-22 + the level loop at src/niagara.cpp:1703-1733.
  * d_depth is the width x height fp32 depth target (reverse-Z, far = 0). */

@@ -43,12 +43,14 @@ _SIGS = {
     "nv_profile_enable": (_i, [_vp, _i]),
     "nv_profile_read": (_i, [_vp, C.POINTER(C.c_float * 4), C.POINTER(C.c_uint32 * 4)]),
     "nv_upload_meshlets": (_i, [_vp, _vp, _vp, _u32]),
+    "nv_upload_meshes": (_i, [_vp, _vp, _vp, _u32]),
     "nv_drawcull": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(PyramidDesc)]),
     "nv_reset_count": (_i, [_vp, _vp, _vp, _vp]),
     "nv_tasksubmit": (_i, [_vp, _vp, _vp, _vp]),
     "nv_clustercull": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(PyramidDesc), _vp, _vp]),
     "nv_clustersubmit": (_i, [_vp, _vp, _vp, _vp]),
     "nv_taskcull": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(PyramidDesc), _vp, _vp]),
+    "nv_cluster_expand": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "nv_depthreduce": (_i, [_vp, _vp, _vp, _u32, _u32, C.POINTER(PyramidDesc)]),
     "nv_previous_pow2": (_u32, [_u32]),
     "nv_image_mip_levels": (_u32, [_u32, _u32]),

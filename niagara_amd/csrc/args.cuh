@@ -61,6 +61,7 @@ struct DrawArgs
 	OrderCtl* ctl;
 	uint32_t stateCapacity;
 	uint32_t fusedReset; // NV_OPT_FUSED_COUNT_RESET
+	uint32_t meshCount;  // > 0 when nv_upload_meshes registered `meshes`: the table may be staged in LDS
 };
 
 } // namespace nv

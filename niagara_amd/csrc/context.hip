@@ -28,6 +28,8 @@ int launch_drawcull(hipStream_t, const DrawArgs&, int late, int task, uint32_t g
 uint32_t drawcull_max_tiles(uint32_t drawCount, uint32_t gridBlocks);
 int launch_tasksubmit(hipStream_t, uint32_t* count4, NvMeshTaskCommand* commands);
 int launch_reset_count(hipStream_t, uint32_t* a, uint32_t* b);
+int launch_cluster_expand(hipStream_t, const NvMeshTaskCommand*, const NvMeshlet*, const uint32_t* clusterIndices, const uint32_t* cc4,
+                          NvClusterRecord* records, uint32_t capacity, uint64_t* totals, uint32_t gridBlocks);
 int launch_clustersubmit(hipStream_t, uint32_t* cc4, uint32_t* clusterIndices);
 int launch_pack_counts(hipStream_t, const uint32_t*, const uint32_t*, const uint32_t*, uint64_t*);
 int launch_depthreduce(hipStream_t, const float* depth, uint32_t w, uint32_t h, const NvPyramidDesc& pyr);
@@ -55,6 +57,9 @@ struct nv_context
 	uint2* soaBounds;
 	uint32_t* soaCones;
 	uint32_t soaCapacity;
+	// Mesh table registered by nv_upload_meshes (pointer identity + count): lets drawcull stage it in LDS
+	const NvMesh* meshesFrom;
+	uint32_t meshCount;
 	// tuning knobs (environment, read once in nv_create): NV_DEBUG_MODE bit mask, NV_CC_BLOCKS_PER_CU
 	uint32_t debugMode;
 	uint32_t ccBlocksPerCU;
@@ -370,6 +375,16 @@ int nv_upload_meshlets(nv_context* ctx, void* stream, const NvMeshlet* d_meshlet
 	return NV_OK;
 }
 
+int nv_upload_meshes(nv_context* ctx, void* stream, const NvMesh* d_meshes, uint32_t meshCount)
+{
+	(void)stream;
+	if (!ctx || (!d_meshes && meshCount))
+		return NV_EINVAL;
+	ctx->meshesFrom = d_meshes;
+	ctx->meshCount = meshCount;
+	return NV_OK;
+}
+
 int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late, int task, const NvMeshDraw* d_draws,
                 const NvMesh* d_meshes, void* d_commands, uint32_t* d_count4, uint32_t* d_drawVisibility,
                 const NvPyramidDesc* pyramid)
@@ -397,6 +412,7 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 	a.ctl = ctx->ctl;
 	a.stateCapacity = ctx->stateCapacity;
 	a.fusedReset = ctx->fusedReset;
+	a.meshCount = ctx->meshesFrom == d_meshes ? ctx->meshCount : 0u;
 	hipEvent_t e0 = prof_mark(ctx, (hipStream_t)stream);
 	rc = nv::launch_drawcull((hipStream_t)stream, a, late, task, grid);
 	prof_push(ctx, NV_PROF_DRAWCULL, e0, prof_mark(ctx, (hipStream_t)stream));
@@ -506,6 +522,17 @@ int nv_taskcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 	a.clusterIndices = d_payloads;
 	a.payloadCounts = d_payloadCounts;
 	return nv::launch_taskcull((hipStream_t)stream, a, late, a.soaBounds != nullptr, (uint32_t)ctx->numCUs * 8);
+}
+
+int nv_cluster_expand(nv_context* ctx, void* stream, const NvMeshTaskCommand* d_commands, const NvMeshlet* d_meshlets,
+                      const uint32_t* d_clusterIndices, const uint32_t* d_clusterCount4, NvClusterRecord* d_records,
+                      uint32_t recordCapacity, uint64_t* d_totals3)
+{
+	if (!ctx || !d_commands || !d_meshlets || !d_clusterIndices || !d_clusterCount4 || !d_totals3 || (!d_records && recordCapacity))
+		return NV_EINVAL;
+	DeviceGuard guard(ctx->device);
+	return nv::launch_cluster_expand((hipStream_t)stream, d_commands, d_meshlets, d_clusterIndices, d_clusterCount4, d_records, recordCapacity,
+	                                 d_totals3, (uint32_t)ctx->numCUs * 8);
 }
 
 int nv_depthreduce(nv_context* ctx, void* stream, const float* d_depth, uint32_t width, uint32_t height,

@@ -20,7 +20,8 @@ namespace nv
 
 constexpr int DC_WAVES = 4;
 constexpr int DC_THREADS = DC_WAVES * 64;
-constexpr uint32_t DC_TMAX = 2048; // draws per tile: 3 x 8 KiB of per-draw results in LDS
+constexpr uint32_t DC_TMAX = 1024;    // draws per tile: 5 x 4 KiB of per-draw results in LDS
+constexpr uint32_t DC_MESH_LDS = 64;  // meshes staged in LDS (13 KiB) when the table is registered and small enough
 
 
 struct DrawResult
@@ -44,7 +45,7 @@ NV_DEV uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
 
 // drawcull.comp.glsl:56-118 + :154-155 for one draw
 template <bool LATE, bool TASK>
-NV_DEV DrawResult decide_draw(const DrawArgs& a, uint32_t di, const float4& d0, const float4& d1, const uint4& d2, uint32_t oldVis)
+NV_DEV DrawResult decide_draw(const DrawArgs& a, const char* meshBase, uint32_t di, const float4& d0, const float4& d1, const uint4& d2, uint32_t oldVis)
 {
 	const NvCullData& cd = a.cd;
 	DrawResult res = { 0, 0, oldVis };
@@ -55,7 +56,7 @@ NV_DEV DrawResult decide_draw(const DrawArgs& a, uint32_t di, const float4& d0, 
 		return res;
 
 	const uint32_t meshIndex = d2.x;
-	const char* mesh = reinterpret_cast<const char*>(a.meshes + meshIndex);
+	const char* mesh = meshBase + (size_t)meshIndex * sizeof(NvMesh);
 	const float4 cr = *reinterpret_cast<const float4*>(mesh); // center.xyz, radius
 
 	f3 q = { d1.x, d1.y, d1.z };
@@ -119,12 +120,17 @@ NV_DEV DrawLoad load_draw_record(const DrawArgs& a, uint32_t di)
 
 // Static tiles, one per workgroup per pass (see ordered.cuh and clustercull.hip): phase 1 decide -> per-draw emit
 // count / LOD / old visibility in LDS, phase 2 tile total, phase 3 look-back across tiles, phase 4 ordered emit.
-template <bool LATE, bool TASK>
+template <bool LATE, bool TASK, bool MESH_LDS>
 __global__ __launch_bounds__(DC_THREADS) void drawcull_kernel(DrawArgs a)
 {
 	__shared__ uint32_t s_count[DC_TMAX];
 	__shared__ uint32_t s_flags[DC_TMAX];
 	__shared__ uint32_t s_old[DC_TMAX];
+	__shared__ uint32_t s_mesh[DC_TMAX]; // meshIndex and meshletVisibilityOffset of the tile's draws, for the emit phase
+	__shared__ uint32_t s_mvo[DC_TMAX];
+	// the Mesh table (center/radius, LOD errors, LOD ranges) is read by every draw: staged once per workgroup when
+	// nv_upload_meshes registered a table of at most DC_MESH_LDS meshes, otherwise gathered from global memory
+	__shared__ __attribute__((aligned(16))) uint32_t s_meshTable[MESH_LDS ? DC_MESH_LDS * sizeof(NvMesh) / 4 : 4];
 	__shared__ uint32_t s_part[DC_WAVES];
 	__shared__ uint32_t s_scratch[16];
 
@@ -139,6 +145,17 @@ __global__ __launch_bounds__(DC_THREADS) void drawcull_kernel(DrawArgs a)
 	const uint32_t numTiles = (drawCount + T - 1) / T;
 	const uint32_t epoch = load_epoch(a.ctl);
 	const uint32_t base0 = a.fusedReset ? 0u : a.count4[0];
+
+	const char* meshBase = reinterpret_cast<const char*>(a.meshes);
+	if (MESH_LDS)
+	{
+		const uint32_t words = a.meshCount * (uint32_t)(sizeof(NvMesh) / 4);
+		const uint32_t* src = reinterpret_cast<const uint32_t*>(a.meshes);
+		for (uint32_t i = tid; i < words; i += DC_THREADS)
+			s_meshTable[i] = src[i];
+		meshBase = reinterpret_cast<const char*>(s_meshTable);
+		__syncthreads();
+	}
 
 	for (uint32_t tile = blockIdx.x; tile < numTiles; tile += G)
 	{
@@ -165,10 +182,12 @@ __global__ __launch_bounds__(DC_THREADS) void drawcull_kernel(DrawArgs a)
 				const uint32_t c = c0 + j * DC_THREADS + tid;
 				if (c < n)
 				{
-					DrawResult res = decide_draw<LATE, TASK>(a, first + c, ld[j].d0, ld[j].d1, ld[j].d2, ld[j].oldVis);
+					DrawResult res = decide_draw<LATE, TASK>(a, meshBase, first + c, ld[j].d0, ld[j].d1, ld[j].d2, ld[j].oldVis);
 					s_count[c] = res.count;
 					s_flags[c] = res.lodWord;
 					s_old[c] = ld[j].oldVis;
+					s_mesh[c] = ld[j].d2.x;
+					s_mvo[c] = ld[j].d2.y;
 					threadSum += res.count;
 				}
 			}
@@ -224,9 +243,8 @@ __global__ __launch_bounds__(DC_THREADS) void drawcull_kernel(DrawArgs a)
 				uint32_t meshIndex = 0, mvo = 0, oldVis = 0;
 				if (emit && cnt != 0)
 				{
-					const uint2 ids = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.draws + di) + 32);
-					meshIndex = ids.x;
-					mvo = ids.y;
+					meshIndex = s_mesh[c];
+					mvo = s_mvo[c];
 					oldVis = s_old[c];
 				}
 				while (owners)
@@ -242,7 +260,7 @@ __global__ __launch_bounds__(DC_THREADS) void drawcull_kernel(DrawArgs a)
 					const uint32_t oMvo = __builtin_amdgcn_readlane(mvo, src);
 					if (oDci + oGroups <= NV_TASK_WGLIMIT) // drop the whole draw on overflow (:128)
 					{
-						const char* mesh = reinterpret_cast<const char*>(a.meshes + oMesh);
+						const char* mesh = meshBase + (size_t)oMesh * sizeof(NvMesh);
 						const uint32_t meshletOffset = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * oLod + 8);
 						const uint32_t meshletCount = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * oLod + 12);
 						for (uint32_t i = lane; i < oGroups; i += 64)
@@ -262,8 +280,8 @@ __global__ __launch_bounds__(DC_THREADS) void drawcull_kernel(DrawArgs a)
 			else if (emit)
 			{
 				// drawcull.comp.glsl:141-150
-				const uint32_t meshIndex = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.draws + di) + 32);
-				const char* mesh = reinterpret_cast<const char*>(a.meshes + meshIndex);
+				const uint32_t meshIndex = s_mesh[c];
+				const char* mesh = meshBase + (size_t)meshIndex * sizeof(NvMesh);
 				const uint32_t indexOffset = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * lodIndex + 0);
 				const uint32_t indexCount = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * lodIndex + 4);
 				const uint32_t vertexOffset = *reinterpret_cast<const uint32_t*>(mesh + 16);
@@ -281,23 +299,32 @@ __global__ __launch_bounds__(DC_THREADS) void drawcull_kernel(DrawArgs a)
 	}
 }
 
-int launch_drawcull(hipStream_t stream, const DrawArgs& a, int late, int task, uint32_t gridBlocks)
+template <bool MESH_LDS>
+static void launch_dc(hipStream_t stream, const DrawArgs& a, int late, int task, uint32_t gridBlocks)
 {
 	dim3 grid(gridBlocks), block(DC_THREADS);
 	if (late)
 	{
 		if (task)
-			hipLaunchKernelGGL((drawcull_kernel<true, true>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((drawcull_kernel<true, true, MESH_LDS>), grid, block, 0, stream, a);
 		else
-			hipLaunchKernelGGL((drawcull_kernel<true, false>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((drawcull_kernel<true, false, MESH_LDS>), grid, block, 0, stream, a);
 	}
 	else
 	{
 		if (task)
-			hipLaunchKernelGGL((drawcull_kernel<false, true>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((drawcull_kernel<false, true, MESH_LDS>), grid, block, 0, stream, a);
 		else
-			hipLaunchKernelGGL((drawcull_kernel<false, false>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((drawcull_kernel<false, false, MESH_LDS>), grid, block, 0, stream, a);
 	}
+}
+
+int launch_drawcull(hipStream_t stream, const DrawArgs& a, int late, int task, uint32_t gridBlocks)
+{
+	if (a.meshCount && a.meshCount <= DC_MESH_LDS)
+		launch_dc<true>(stream, a, late, task, gridBlocks);
+	else
+		launch_dc<false>(stream, a, late, task, gridBlocks);
 	return (int)hipGetLastError();
 }
 

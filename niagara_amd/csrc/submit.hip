@@ -79,6 +79,61 @@ int launch_reset_count(hipStream_t stream, uint32_t* a, uint32_t* b)
 	return (int)hipGetLastError();
 }
 
+// meshlet.mesh.glsl:91-116: decode of one cluster index per thread (the header part of the mesh stage)
+__global__ __launch_bounds__(256) void cluster_expand_kernel(const NvMeshTaskCommand* __restrict__ commands, const NvMeshlet* __restrict__ meshlets,
+                                                            const uint32_t* __restrict__ clusterIndices, const uint32_t* __restrict__ cc4,
+                                                            NvClusterRecord* __restrict__ records, uint32_t capacity, unsigned long long* __restrict__ totals)
+{
+	// grid of the consumer: {cc4[1], cc4[2], cc4[3]} = {16, Y, 16}; index = x + 256 y + 16 z enumerates [0, 256 Y)
+	const uint32_t slots = cc4[1] * cc4[2] * cc4[3];
+	unsigned long long clusters = 0, vertices = 0, triangles = 0;
+	for (uint32_t index = blockIdx.x * 256u + threadIdx.x; index < slots; index += gridDim.x * 256u)
+	{
+		const uint32_t ci = clusterIndices[index];
+		NvClusterRecord r = { ~0u, 0, 0, 0, 0, 0, 0, 0 };
+		if (ci != ~0u)
+		{
+			const NvMeshTaskCommand command = commands[ci & 0xffffffu];
+			const uint32_t mi = command.taskOffset + (ci >> 24);
+			const NvMeshlet m = meshlets[mi];
+			r.drawId = command.drawId;
+			r.meshletIndex = mi;
+			r.vertexCount = m.vertexCount;
+			r.triangleCount = m.triangleCount;
+			r.vertexOffset = m.dataOffset;
+			r.shortRefs = m.shortRefs == 1 ? 1u : 0u;
+			r.indexOffset = m.dataOffset + (r.shortRefs ? (r.vertexCount + 1) / 2 : r.vertexCount);
+			r.baseVertex = m.baseVertex;
+			clusters += 1;
+			vertices += r.vertexCount;
+			triangles += r.triangleCount;
+		}
+		if (index < capacity)
+			records[index] = r;
+	}
+	// wave reduction, one atomic per wave and total
+	for (int o = 32; o > 0; o >>= 1)
+	{
+		clusters += __shfl_xor(clusters, o, 64);
+		vertices += __shfl_xor(vertices, o, 64);
+		triangles += __shfl_xor(triangles, o, 64);
+	}
+	if ((threadIdx.x & 63u) == 0 && clusters)
+	{
+		atomicAdd(&totals[0], clusters);
+		atomicAdd(&totals[1], vertices);
+		atomicAdd(&totals[2], triangles);
+	}
+}
+
+int launch_cluster_expand(hipStream_t stream, const NvMeshTaskCommand* commands, const NvMeshlet* meshlets, const uint32_t* clusterIndices,
+                          const uint32_t* cc4, NvClusterRecord* records, uint32_t capacity, uint64_t* totals, uint32_t gridBlocks)
+{
+	hipLaunchKernelGGL(cluster_expand_kernel, dim3(gridBlocks), dim3(256), 0, stream, commands, meshlets, clusterIndices, cc4, records, capacity,
+	                   reinterpret_cast<unsigned long long*>(totals));
+	return (int)hipGetLastError();
+}
+
 int launch_tasksubmit(hipStream_t stream, uint32_t* count4, NvMeshTaskCommand* commands)
 {
 	hipLaunchKernelGGL(tasksubmit_kernel, dim3(1), dim3(64), 0, stream, count4, commands);

@@ -25,6 +25,9 @@ CULLDATA = np.dtype([("view", "<f4", 16), ("P00", "<f4"), ("P11", "<f4"), ("znea
                      ("clusterOcclusionEnabled", "<i4"), ("clusterBackfaceEnabled", "<i4"), ("postPass", "<u4"),
                      ("_pad", "<u4", 2)])
 
+CLUSTERRECORD = np.dtype([("drawId", "<u4"), ("meshletIndex", "<u4"), ("vertexCount", "<u4"), ("triangleCount", "<u4"), ("vertexOffset", "<u4"),
+                          ("indexOffset", "<u4"), ("baseVertex", "<u4"), ("shortRefs", "<u4")])
+
 TASK_WGSIZE = 64
 TASK_WGLIMIT = 1 << 22
 CLUSTER_LIMIT = 1 << 24

@@ -80,6 +80,9 @@ class Context:
     def upload_meshlets(self, mlb, count):
         check(lib.nv_upload_meshlets(self.h, _stream(), _ptr(mlb), count), "nv_upload_meshlets")
 
+    def upload_meshes(self, mb, count):
+        check(lib.nv_upload_meshes(self.h, _stream(), _ptr(mb), count), "nv_upload_meshes")
+
     def drawcull(self, cull, late, task, db, mb, dcb, dccb, dvb, pyramid=None):
         check(lib.nv_drawcull(self.h, _stream(), C.c_void_p(cull.ctypes.data), int(late), int(task), _ptr(db), _ptr(mb), _ptr(dcb),
                               _ptr(dccb), _ptr(dvb), None if pyramid is None else C.byref(pyramid)), "nv_drawcull")
@@ -100,6 +103,10 @@ class Context:
     def taskcull(self, cull, late, dcb, dccb, db, mlb, mvb, pyramid, payloads, payload_counts):
         check(lib.nv_taskcull(self.h, _stream(), C.c_void_p(cull.ctypes.data), int(late), _ptr(dcb), _ptr(dccb), _ptr(db), _ptr(mlb),
                               _ptr(mvb), None if pyramid is None else C.byref(pyramid), _ptr(payloads), _ptr(payload_counts)), "nv_taskcull")
+
+    def cluster_expand(self, dcb, mlb, cib, ccb, records, capacity, totals3):
+        check(lib.nv_cluster_expand(self.h, _stream(), _ptr(dcb), _ptr(mlb), _ptr(cib), _ptr(ccb), _ptr(records), capacity, _ptr(totals3)),
+              "nv_cluster_expand")
 
     def depthreduce(self, depth, width, height, pyramid):
         check(lib.nv_depthreduce(self.h, _stream(), _ptr(depth), width, height, C.byref(pyramid)), "nv_depthreduce")
@@ -153,6 +160,7 @@ class VisibilityPipeline:
         self.pyramid = DepthPyramid(dev, *depth_size)
         if use_soa and self.meshlet_count:
             self.ctx.upload_meshlets(self.mlb, self.meshlet_count)
+        self.ctx.upload_meshes(self.mb, self.mesh_count)
 
     # src/niagara.cpp:1530-1574
     def cull(self, cull_data, late, task=True, post_pass=0):

@@ -165,5 +165,9 @@ def probe_cluster_scalars(cd, commands, draws, meshlets, pyr=None):
     return out
 
 
+def cluster_expand(commands, meshlets, cib, cc4, records, totals3):
+    lib().orc_cluster_expand(_p(commands), _p(meshlets), _p(cib), _p(cc4), _p(records), C.c_uint32(len(records)), _p(totals3))
+
+
 def max_threads():
     return int(lib().orc_max_threads())

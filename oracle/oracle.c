@@ -696,6 +696,42 @@ void orc_taskcull(const OrcCullData* cd, int late, const OrcMeshTaskCommand* com
 	}
 }
 
+/* src/shaders/meshlet.mesh.glsl:91-116; index = gl_WorkGroupID.x + gl_WorkGroupID.y * 256 + gl_WorkGroupID.z * CLUSTER_TILE over the
+ * grid clustersubmit wrote */
+void orc_cluster_expand(const OrcMeshTaskCommand* commands, const OrcMeshlet* meshlets, const uint32_t* clusterIndices, const uint32_t* cc4,
+                        uint32_t* records8, uint32_t capacity, uint64_t* totals3)
+{
+	for (uint32_t y = 0; y < cc4[2]; ++y)
+		for (uint32_t z = 0; z < cc4[3]; ++z)
+			for (uint32_t x = 0; x < cc4[1]; ++x)
+			{
+				uint32_t index = x + y * 256 + z * CLUSTER_TILE;
+				uint32_t ci = clusterIndices[index];
+				uint32_t rec[8] = { ~0u, 0, 0, 0, 0, 0, 0, 0 };
+				if (ci != ~0u)
+				{
+					const OrcMeshTaskCommand* command = &commands[ci & 0xffffff];
+					uint32_t mi = command->taskOffset + (ci >> 24);
+					uint32_t vertexCount = meshlets[mi].vertexCount, triangleCount = meshlets[mi].triangleCount;
+					uint32_t dataOffset = meshlets[mi].dataOffset;
+					int shortRefs = meshlets[mi].shortRefs == 1;
+					rec[0] = command->drawId;
+					rec[1] = mi;
+					rec[2] = vertexCount;
+					rec[3] = triangleCount;
+					rec[4] = dataOffset;
+					rec[5] = dataOffset + (shortRefs ? (vertexCount + 1) / 2 : vertexCount);
+					rec[6] = meshlets[mi].baseVertex;
+					rec[7] = (uint32_t)shortRefs;
+					totals3[0] += 1;
+					totals3[1] += vertexCount;
+					totals3[2] += triangleCount;
+				}
+				if (index < capacity)
+					memcpy(records8 + (size_t)index * 8, rec, sizeof(rec));
+			}
+}
+
 void orc_probe_cluster_scalars(const OrcCullData* cd, const OrcMeshTaskCommand* commands, uint32_t commandCount,
                                const OrcMeshDraw* draws, const OrcMeshlet* meshlets, const OrcPyramid* pyr, float* out16)
 {

@@ -128,6 +128,11 @@ void orc_taskcull(const OrcCullData* cull, int late, const OrcMeshTaskCommand* c
                   const OrcPyramid* pyr, uint32_t* payloads, uint32_t* payloadCounts);               /* meshlet.task.glsl:53-149 */
 void orc_depthreduce(const float* depth, uint32_t w, uint32_t h, const OrcPyramid* pyr);            /* depthreduce.comp.glsl:14-22 + niagara.cpp:1703-1733 */
 
+/* src/shaders/meshlet.mesh.glsl:91-116: decode of the cluster list by its consumer; records = 8 x u32 per
+ * index in [0, cc4[1]*cc4[2]*cc4[3]), totals3 += {clusters, vertices, triangles} */
+void orc_cluster_expand(const OrcMeshTaskCommand* commands, const OrcMeshlet* meshlets, const uint32_t* clusterIndices,
+                        const uint32_t* cc4, uint32_t* records8, uint32_t capacity, uint64_t* totals3);
+
 /* per-meshlet scalar intermediates, 16 floats per lane (same record as nv_probe_cluster_scalars) */
 void orc_probe_cluster_scalars(const OrcCullData* cull, const OrcMeshTaskCommand* commands, uint32_t commandCount,
                                const OrcMeshDraw* draws, const OrcMeshlet* meshlets, const OrcPyramid* pyr, float* out16);

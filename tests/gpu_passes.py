@@ -22,6 +22,7 @@ class GpuScene:
         self.use_soa = use_soa
         if use_soa:
             ctx.upload_meshlets(self.mlb, len(scene["meshlets"]))
+            ctx.upload_meshes(self.mb, len(scene["meshes"]))  # Mesh table staged in LDS; the other variant gathers it
 
     def depthreduce(self, depth):
         d = torch.from_numpy(np.ascontiguousarray(depth)).to(self.ctx.device)

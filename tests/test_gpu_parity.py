@@ -478,3 +478,34 @@ def test_fused_count_reset_option(ctx):
     finally:
         ctx.set_option(P.NV_OPT_FUSED_COUNT_RESET, 0)
     ctx.status()
+
+
+def test_cluster_expand_decodes_the_lists_like_the_mesh_stage(ctx):
+    """§8f N1: the consumer's view of the output (meshlet.mesh.glsl:91-116): grid {16,Y,16} walk, ~0 padding, command /
+    meshlet decode, header fields and totals — HIP vs oracle on a full drawcull -> tasksubmit -> clustercull ->
+    clustersubmit chain"""
+    scene = make_scene(seed=77, n_draws=1200, meshlets_lod0=140)
+    rng = np.random.default_rng(5)
+    ml = scene["meshlets"]
+    ml["vertexCount"] = rng.integers(3, 65, len(ml))
+    ml["triangleCount"] = rng.integers(1, 97, len(ml))
+    ml["dataOffset"] = rng.integers(0, 1 << 24, len(ml))
+    ml["baseVertex"] = rng.integers(0, 1 << 20, len(ml))
+    ml["shortRefs"] = rng.integers(0, 2, len(ml))
+    cd = passes.set_flags(scene["cull"], (1, 1, 0, 0, 1))
+    dvb = np.ones(len(scene["draws"]), np.uint32)
+    cmds, c4 = passes.run_drawcull(oracle, scene, cd, 0, 1, dvb, None)
+    oracle.tasksubmit(c4, cmds)
+    cib, cc4 = passes.run_cluster(oracle, scene, cd, 0, cmds, c4, None, None)
+    slots = int(cc4[1]) * int(cc4[2]) * int(cc4[3])
+    assert slots >= cc4[0] > 0 and slots % 256 == 0
+    rec_o, tot_o = np.zeros(slots, dtype=L.CLUSTERRECORD), np.zeros(3, np.uint64)
+    oracle.cluster_expand(cmds, ml, cib, cc4, rec_o, tot_o)
+    assert tot_o[0] == cc4[0] and (rec_o["drawId"][cc4[0]:] == 0xffffffff).all()
+    dev = ctx.device
+    d_rec = torch.zeros(slots * 32, dtype=torch.uint8, device=dev)
+    d_tot = torch.zeros(3, dtype=torch.int64, device=dev)
+    ctx.cluster_expand(P.to_device(cmds, dev), P.to_device(ml, dev), torch.from_numpy(cib.view(np.int32).copy()).to(dev),
+                       torch.from_numpy(cc4.view(np.int32).copy()).to(dev), d_rec, slots, d_tot)
+    assert P.from_device(d_rec, L.CLUSTERRECORD).tobytes() == rec_o.tobytes()
+    assert (d_tot.cpu().numpy().view(np.uint64) == tot_o).all()

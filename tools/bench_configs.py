@@ -49,6 +49,7 @@ def config2(ctx, iters, n_draws=1_000_000, copies=6):
     host.assign_visibility_offsets(draws, meshes)
     cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, lodEnabled=1)
     mb = P.to_device(meshes, dev)
+    ctx.upload_meshes(mb, len(meshes))
     dbs = [P.to_device(draws, dev) for _ in range(copies)]
     dvbs = [torch.ones(n_draws, dtype=torch.int32, device=dev) for _ in range(copies)]
     dcb = torch.zeros(n_draws * 24 + 64, dtype=torch.uint8, device=dev)
