@@ -118,6 +118,57 @@ NV_DEV void lane_cone(const NvCullData& cd, const DrawUniform& u, const LaneData
 	cutoff = (float)(int)(int8_t)(l.cone >> 24) / 127.0f;
 }
 
+// Visibility-bit update of one command (clustercull.comp.glsl:125-131): lanes in setAll become 1, lanes in clrAll become 0.
+// Instead of one atomicOr/atomicAnd per lane, lane j < 3 handles word (offset >> 5) + j:
+//   * bits that already have the wanted value are left alone (needs the loaded words, BITS);
+//   * a word that lies entirely inside this command's slot range has no other writer: plain store of the new value;
+//   * edge words shared with a neighbouring command: one atomicAnd / atomicOr with only the bits that change.
+template <bool BITS>
+NV_DEV void update_visibility_words(const ClusterArgs& a, uint32_t off, uint32_t taskCount, const LaneData& l, uint32_t lane, uint64_t setAll,
+                                    uint64_t clrAll)
+{
+	if ((setAll | clrAll) == 0)
+		return;
+	const uint32_t sh = off & 31u;
+	// word j's old value sits in any lane whose slot falls into it: the first such lane is max(0, 32 j - sh)
+	const int lo = 32 * (int)(lane < 3 ? lane : 0u) - (int)sh;
+	uint32_t old = 0;
+	if (BITS)
+		old = __shfl(l.mvbWord, lo > 0 ? (lo < 64 ? lo : 63) : 0, 64);
+	if (lane < 3)
+	{
+		// bits of word j come from lanes [32 j - sh, 32 j - sh + 32)
+		uint32_t setw, clrw;
+		if (lo >= 0)
+		{
+			setw = lo < 64 ? (uint32_t)(setAll >> lo) : 0u;
+			clrw = lo < 64 ? (uint32_t)(clrAll >> lo) : 0u;
+		}
+		else
+		{
+			setw = (uint32_t)(setAll << (-lo));
+			clrw = (uint32_t)(clrAll << (-lo));
+		}
+		uint32_t* word = a.mvb + (off >> 5) + lane;
+		if (BITS)
+		{
+			setw &= ~old; // only bits that change
+			clrw &= old;
+			const bool owned = lo >= 0 && (uint32_t)lo + 32u <= taskCount;
+			if (owned)
+			{
+				if (setw | clrw)
+					*word = (old & ~clrw) | setw;
+				return;
+			}
+		}
+		if (clrw)
+			atomicAnd(word, ~clrw);
+		if (setw)
+			atomicOr(word, setw);
+	}
+}
+
 // One command on one wave.  Returns the ballot of lanes that append (visible && !skip) and, for the late pass,
 // applies the visibility-bit update.  All arguments except `l` are wave-uniform.
 // BITS = (clusterOcclusionEnabled == 1 && postPass == 0), resolved on the host so that the variant without
@@ -157,7 +208,7 @@ NV_DEV uint64_t cull_command(const ClusterArgs& a, const NvMeshTaskCommand& cmd,
 			visible = visible && !cone_cull(c, r, axis, cutoff);
 		}
 
-		if (LATE && cd.clusterOcclusionEnabled == 1 && visible)
+		if (LATE && cd.clusterOcclusionEnabled == 1 && visible && !(a.debugMode & 512u)) // bit 9 (experiments): no HiZ
 			visible = hiz_test(cd, a.pyr, c, r);
 	}
 
@@ -165,32 +216,8 @@ NV_DEV uint64_t cull_command(const ClusterArgs& a, const NvMeshTaskCommand& cmd,
 
 	if (LATE && cd.clusterOcclusionEnabled == 1)
 	{
-		// clustercull.comp.glsl:125-131, as <= 3 word-level atomics per wave: lane j carries word (off>>5)+j
 		const uint64_t validMask = __ballot(valid);
-		const uint32_t off = cmd.meshletVisibilityOffset;
-		const uint32_t sh = off & 31u;
-		if (lane < 3)
-		{
-			// bits of word j come from lanes [32*j - sh, 32*j - sh + 32)
-			int lo = 32 * (int)lane - (int)sh;
-			uint64_t setAll = visMask & validMask, clrAll = ~visMask & validMask;
-			uint32_t setw, clrw;
-			if (lo >= 0)
-			{
-				setw = lo < 64 ? (uint32_t)(setAll >> lo) : 0u;
-				clrw = lo < 64 ? (uint32_t)(clrAll >> lo) : 0u;
-			}
-			else
-			{
-				setw = (uint32_t)(setAll << (-lo));
-				clrw = (uint32_t)(clrAll << (-lo));
-			}
-			uint32_t* word = a.mvb + (off >> 5) + lane;
-			if (clrw)
-				atomicAnd(word, ~clrw);
-			if (setw)
-				atomicOr(word, setw);
-		}
+		update_visibility_words<BITS>(a, cmd.meshletVisibilityOffset, cmd.taskCount, l, lane, visMask & validMask, ~visMask & validMask);
 	}
 
 	return __ballot(visible && !skip);
@@ -201,29 +228,16 @@ NV_DEV uint64_t cull_command(const ClusterArgs& a, const NvMeshTaskCommand& cmd,
 template <bool BITS>
 NV_DEV void clear_visibility_bits(const ClusterArgs& a, const NvMeshTaskCommand& cmd, const LaneData& l, uint32_t lane)
 {
-	const bool valid = lane < cmd.taskCount;
-	const uint32_t mvi = lane + cmd.meshletVisibilityOffset;
-	const bool set = valid && (!BITS || (l.mvbWord >> (mvi & 31u) & 1u));
-	const uint64_t clrAll = __ballot(set);
-	if (clrAll == 0)
-		return;
-	const uint32_t off = cmd.meshletVisibilityOffset;
-	const uint32_t sh = off & 31u;
-	if (lane < 3)
-	{
-		int lo = 32 * (int)lane - (int)sh;
-		uint32_t clrw = lo >= 0 ? (lo < 64 ? (uint32_t)(clrAll >> lo) : 0u) : (uint32_t)(clrAll << (-lo));
-		if (clrw)
-			atomicAnd(a.mvb + (off >> 5) + lane, ~clrw);
-	}
+	const uint64_t validMask = __ballot(lane < cmd.taskCount);
+	update_visibility_words<BITS>(a, cmd.meshletVisibilityOffset, cmd.taskCount, l, lane, 0ull, validMask);
 }
 
 NV_DEV uint32_t load_mvb_word(const ClusterArgs& a, uint32_t meshletVisibilityOffset, uint32_t taskCount, uint32_t lane)
 {
 	const uint32_t mvi = taskCount ? meshletVisibilityOffset + (lane < taskCount ? lane : 0u) : 0u;
-	// late pass: other waves update neighbouring bits of shared words concurrently; an agent-scope load keeps the
-	// read out of a stale L1 line (our own bit is only ever written by this lane, later)
-	return __hip_atomic_load(a.mvb + (mvi >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	// Other waves update neighbouring bits of shared words concurrently (late pass), but only this lane's own bit is
+	// extracted from the word and nobody else writes it during the pass, so a plain (possibly L1-served) load is exact.
+	return a.mvb[mvi >> 5];
 }
 
 NV_DEV uint32_t indirect_command_count(const ClusterArgs& a)
@@ -433,7 +447,7 @@ NV_DEV void ringA_issue(SlotA& s, const ClusterArgs& a, uint32_t off8, uint32_t 
 {
 	if (BITS)
 	{
-		asm volatile("global_load_dwordx2 %0, %2, %3\n\tglobal_load_dword %1, %4, %5 sc1"
+		asm volatile("global_load_dwordx2 %0, %2, %3\n\tglobal_load_dword %1, %4, %5"
 		             : "=&v"(s.bounds), "=&v"(s.mvbWord)
 		             : "v"(off8), "s"(a.soaBounds), "v"(offw), "s"(a.mvb), "s"(order)
 		             : "memory");
@@ -465,7 +479,7 @@ NV_DEV void ringB_issue(SlotB& s, const ClusterArgs& a, uint32_t taskOffset, uin
 	if (BITS)
 	{
 		const uint32_t offw = taskCount ? ((mvo + li) >> 5) * 4u : 0u;
-		asm volatile("global_load_dwordx2 %0, %3, %4\n\tglobal_load_dword %1, %5, %6\n\tglobal_load_dword %2, %7, %8 sc1"
+		asm volatile("global_load_dwordx2 %0, %3, %4\n\tglobal_load_dword %1, %5, %6\n\tglobal_load_dword %2, %7, %8"
 		             : "=&v"(s.bounds), "=&v"(s.cone), "=&v"(s.mvbWord)
 		             : "v"(off8), "s"(a.soaBounds), "v"(off4), "s"(a.soaCones), "v"(offw), "s"(a.mvb), "s"(order)
 		             : "memory");

@@ -203,6 +203,91 @@ __global__ __launch_bounds__(256) void reduce_chain_kernel(ChainArgs a)
 	}
 }
 
+
+// ---- first stage for large sources: row-coalesced variant of the chain.  A wave reads 8 source rows x 256 columns,
+// one 16-B load per lane and row (1 KiB contiguous per wave-instruction), and reduces 4 x 8 -> 2 x 4 -> 1 x 2 in
+// registers; level +2 pairs neighbouring lanes with a DPP shuffle, levels +3 and +4 pair the workgroup's four waves
+// (32 source rows) through 512 B of LDS.  Five levels per launch, every store a contiguous run.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(ChainArgs a)
+{
+	__shared__ float s_l2[4][32];
+
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t L = a.firstLevel;
+	const uint32_t col0 = blockIdx.x * 256u + lane * 4u; // source column of this lane
+	const uint32_t row0 = blockIdx.y * 32u + wave * 8u;  // first source row of this wave
+
+	float4 v[8];
+#pragma unroll
+	for (int r = 0; r < 8; ++r)
+		v[r] = *reinterpret_cast<const float4*>(a.src + (size_t)(row0 + r) * a.sw + col0);
+
+	// level L: 2 x 4 per lane
+	float q[4][2];
+#pragma unroll
+	for (int i = 0; i < 4; ++i)
+	{
+		q[i][0] = min4(v[2 * i].x, v[2 * i].y, v[2 * i + 1].x, v[2 * i + 1].y);
+		q[i][1] = min4(v[2 * i].z, v[2 * i].w, v[2 * i + 1].z, v[2 * i + 1].w);
+	}
+	{
+		const uint32_t lw = a.sw / 2;
+		float* dst = a.base + a.mipOffset[L] + (size_t)(row0 / 2) * lw + col0 / 2;
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+			*reinterpret_cast<float2*>(dst + (size_t)i * lw) = make_float2(q[i][0], q[i][1]);
+	}
+	if (a.numLevels < 2)
+		return;
+
+	// level L+1: 1 x 2 per lane
+	float h[2];
+	h[0] = min4(q[0][0], q[0][1], q[1][0], q[1][1]);
+	h[1] = min4(q[2][0], q[2][1], q[3][0], q[3][1]);
+	{
+		const uint32_t lw = a.sw / 4;
+		float* dst = a.base + a.mipOffset[L + 1] + (size_t)(row0 / 4) * lw + col0 / 4;
+		dst[0] = h[0];
+		dst[lw] = h[1];
+	}
+	if (a.numLevels < 3)
+		return;
+
+	// level L+2: lane pairs
+	float t = gl_min(h[0], h[1]);
+	t = gl_min(t, __shfl_xor(t, 1, 64));
+	if ((lane & 1u) == 0)
+	{
+		const uint32_t lw = a.sw / 8;
+		a.base[a.mipOffset[L + 2] + (size_t)(row0 / 8) * lw + col0 / 8] = t;
+		s_l2[wave][lane >> 1] = t;
+	}
+	if (a.numLevels < 4)
+		return;
+	__syncthreads();
+
+	// levels L+3 (2 x 16 per workgroup) and L+4 (1 x 8): lanes 0..31 of wave 0, lane = y * 16 + x
+	if (threadIdx.x < 32)
+	{
+		const uint32_t x = threadIdx.x & 15u, y = threadIdx.x >> 4;
+		float m = min4(s_l2[2 * y][2 * x], s_l2[2 * y][2 * x + 1], s_l2[2 * y + 1][2 * x], s_l2[2 * y + 1][2 * x + 1]);
+		{
+			const uint32_t lw = a.sw / 16;
+			a.base[a.mipOffset[L + 3] + (size_t)(blockIdx.y * 2 + y) * lw + blockIdx.x * 16 + x] = m;
+		}
+		if (a.numLevels >= 5)
+		{
+			m = gl_min(m, __shfl_xor(m, 1, 64));
+			m = gl_min(m, __shfl_xor(m, 16, 64));
+			if (y == 0 && (x & 1u) == 0)
+			{
+				const uint32_t lw = a.sw / 32;
+				a.base[a.mipOffset[L + 4] + (size_t)blockIdx.y * lw + blockIdx.x * 8 + x / 2] = m;
+			}
+		}
+	}
+}
+
 static bool halves(uint32_t s, uint32_t d) { return s == 2 * d || (s == 1 && d == 1); }
 
 int launch_depthreduce(hipStream_t stream, const float* depth, uint32_t w, uint32_t h, const NvPyramidDesc& pyr)
@@ -237,8 +322,19 @@ int launch_depthreduce(hipStream_t stream, const float* depth, uint32_t w, uint3
 		uint32_t lw = pyr.width >> L, lh = pyr.height >> L;
 		lw = lw ? lw : 1;
 		lh = lh ? lh : 1;
-		dim3 grid((lw + 63) / 64, (lh + 63) / 64);
-		hipLaunchKernelGGL(reduce_chain_kernel, grid, dim3(256), 0, stream, a);
+		// big sources: row-coalesced five-level stage (needs whole 256 x 32 source tiles and exact halving down to its
+		// last level); everything else: the seven-level 128 x 128 tile chain
+		const bool rows = sw % 256 == 0 && sh % 32 == 0 && sw == 2 * lw && sh == 2 * lh && sw >= 512 && sh >= 64 && pyr.levels - L >= 5;
+		if (rows)
+		{
+			a.numLevels = 5;
+			hipLaunchKernelGGL(reduce_rows_kernel, dim3(sw / 256, sh / 32), dim3(256), 0, stream, a);
+		}
+		else
+		{
+			dim3 grid((lw + 63) / 64, (lh + 63) / 64);
+			hipLaunchKernelGGL(reduce_chain_kernel, grid, dim3(256), 0, stream, a);
+		}
 
 		uint32_t last = L + a.numLevels - 1;
 		src = pyr.d_base + pyr.mipOffset[last];

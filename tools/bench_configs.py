@@ -159,6 +159,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     ctx = P.Context(0)
     runs = {"2": lambda: config2(ctx, a.iters), "3b": lambda: config3b(ctx, a.iters), "4": lambda: config4(ctx, a.iters),
+            "4b": lambda: config4(ctx, a.iters, size=1024),
             "big": lambda: roofline_size(ctx, max(5, a.iters // 3)), "big_aos": lambda: roofline_size(P.Context(0), max(5, a.iters // 3), aos=True)}
     for k, fn in runs.items():
         if a.only and k not in a.only.split(","):
