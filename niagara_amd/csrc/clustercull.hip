@@ -170,11 +170,12 @@ NV_DEV void update_visibility_words(const ClusterArgs& a, uint32_t off, uint32_t
 }
 
 // One command on one wave.  Returns the ballot of lanes that append (visible && !skip) and, for the late pass,
-// applies the visibility-bit update.  All arguments except `l` are wave-uniform.
+// applies the visibility-bit update (or hands the visible ballot to the caller through visOut).  All arguments except `l` are wave-uniform.
 // BITS = (clusterOcclusionEnabled == 1 && postPass == 0), resolved on the host so that the variant without
 // visibility bits carries no load for them.
 template <bool LATE, bool BITS>
-NV_DEV uint64_t cull_command(const ClusterArgs& a, const NvMeshTaskCommand& cmd, const DrawUniform& u, const LaneData& l, uint32_t lane)
+NV_DEV uint64_t cull_command(const ClusterArgs& a, const NvMeshTaskCommand& cmd, const DrawUniform& u, const LaneData& l, uint32_t lane,
+                             uint64_t* visOut = nullptr)
 {
 	const NvCullData& cd = a.cd;
 	const bool valid = lane < cmd.taskCount;
@@ -214,7 +215,9 @@ NV_DEV uint64_t cull_command(const ClusterArgs& a, const NvMeshTaskCommand& cmd,
 
 	const uint64_t visMask = __ballot(visible);
 
-	if (LATE && cd.clusterOcclusionEnabled == 1)
+	if (visOut)
+		*visOut = visMask; // the caller applies the visibility-bit update for its whole segment (update_segment_visibility)
+	else if (LATE && cd.clusterOcclusionEnabled == 1)
 	{
 		const uint64_t validMask = __ballot(valid);
 		update_visibility_words<BITS>(a, cmd.meshletVisibilityOffset, cmd.taskCount, l, lane, visMask & validMask, ~visMask & validMask);
@@ -223,13 +226,51 @@ NV_DEV uint64_t cull_command(const ClusterArgs& a, const NvMeshTaskCommand& cmd,
 	return __ballot(visible && !skip);
 }
 
-// late pass, whole command invisible: clear the visibility bits of its valid lanes (clustercull.comp.glsl:125-131 with
-// visible == false).  When the words were loaded (BITS) only bits that are still set are touched.
-template <bool BITS>
-NV_DEV void clear_visibility_bits(const ClusterArgs& a, const NvMeshTaskCommand& cmd, const LaneData& l, uint32_t lane)
+// Late pass, lane-parallel form of the same update for a whole segment: lane c owns the segment's c-th command and
+// holds its `visible` ballot in vis (0 for commands the filter rejected).  Runs after the load rings have drained, so
+// its stores and atomics never sit between counted loads (a store issued inside a ring lengthens every s_waitcnt
+// vmcnt(N) behind it by its own latency).  The <= 3 words per command are re-read here: they were fetched by this wave
+// moments ago, and only this command's own bits of them are used.
+NV_DEV void update_segment_visibility(const ClusterArgs& a, bool active, uint32_t off, uint32_t taskCount, uint64_t vis)
 {
-	const uint64_t validMask = __ballot(lane < cmd.taskCount);
-	update_visibility_words<BITS>(a, cmd.meshletVisibilityOffset, cmd.taskCount, l, lane, 0ull, validMask);
+	if (!active || taskCount == 0)
+		return;
+	const uint64_t valid = taskCount >= 64u ? ~0ull : (1ull << taskCount) - 1ull;
+	const uint64_t setAll = vis & valid, clrAll = valid & ~vis;
+	const uint32_t sh = off & 31u;
+	uint32_t* words = a.mvb + (off >> 5);
+#pragma unroll
+	for (int j = 0; j < 3; ++j)
+	{
+		const int lo = 32 * j - (int)sh; // bits of word j come from lanes [lo, lo + 32)
+		if (lo >= (int)taskCount)
+			break;
+		uint32_t setw, clrw;
+		if (lo >= 0)
+		{
+			setw = (uint32_t)(setAll >> lo);
+			clrw = (uint32_t)(clrAll >> lo);
+		}
+		else
+		{
+			setw = (uint32_t)(setAll << (-lo));
+			clrw = (uint32_t)(clrAll << (-lo));
+		}
+		const uint32_t old = words[j];
+		setw &= ~old; // only bits that change
+		clrw &= old;
+		if ((setw | clrw) == 0)
+			continue;
+		if (lo >= 0 && (uint32_t)lo + 32u <= taskCount) // the whole word belongs to this command: no other writer
+			words[j] = (old & ~clrw) | setw;
+		else
+		{
+			if (clrw)
+				atomicAnd(words + j, ~clrw);
+			if (setw)
+				atomicOr(words + j, setw);
+		}
+	}
 }
 
 NV_DEV uint32_t load_mvb_word(const ClusterArgs& a, uint32_t meshletVisibilityOffset, uint32_t taskCount, uint32_t lane)
@@ -586,7 +627,9 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 		const bool useFilter = !(a.debugMode & 32u);   // bit 5 (experiments): every valid command goes to the exact pass
 		const bool streamOnly = (a.debugMode & 64u) != 0; // bit 6 (experiments): no arithmetic at all
 		const bool updateBits = LATE && a.cd.clusterOcclusionEnabled == 1;
+		constexpr bool BITS_A = BITS && !LATE; // the filter pass needs the visibility words only for the early pass's bit test
 		uint32_t maskLo = 0, maskHi = 0; // lane c ends up holding the ballot of the segment's c-th command (v_writelane)
+		uint32_t visLo = 0, visHi = 0;   // late pass: likewise the `visible` ballot, for the visibility-bit update
 
 		if (SOA)
 		{
@@ -618,13 +661,13 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 					const uint32_t tc = __builtin_amdgcn_readlane(r.taskCount, c);
 					off8 = __builtin_amdgcn_readlane(base8, c) + (lane < tc ? lane8 : 0u);
 				}
-				if (BITS)
+				if (BITS_A)
 				{
 					const uint32_t tc = __builtin_amdgcn_readlane(r.taskCount, c);
 					const uint32_t mvo = __builtin_amdgcn_readlane(r.meshletVisibilityOffset, c);
 					offw = tc ? ((mvo + (lane < tc ? lane : 0u)) >> 5) * 4u : 0u;
 				}
-				ringA_issue<BITS>(slot, a, off8, offw, order);
+				ringA_issue<BITS_A>(slot, a, off8, offw, order);
 			};
 
 			// one command through the filter; returns the ballot of lanes that may survive
@@ -636,24 +679,13 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 					fd = segment_filter(r, c);
 				const LaneData cur = { b0, b1, 0u, mvbWord };
 				bool candidate = true;
-				uint32_t tc = 64, mvo = 0;
 				if (!(fullMask >> c & 1ull))
-				{
-					tc = __builtin_amdgcn_readlane(r.taskCount, c);
-					candidate = lane < tc;
-				}
-				if (BITS || updateBits)
-					mvo = __builtin_amdgcn_readlane(r.meshletVisibilityOffset, c);
+					candidate = lane < (uint32_t)__builtin_amdgcn_readlane(r.taskCount, c);
 				if (BITS && !LATE) // early pass: only last frame's visible clusters (clustercull.comp.glsl:91-92)
-					candidate = candidate && (mvbWord >> ((lane + mvo) & 31u) & 1u);
+					candidate = candidate && (mvbWord >> ((lane + (uint32_t)__builtin_amdgcn_readlane(r.meshletVisibilityOffset, c)) & 31u) & 1u);
 				if (useFilter)
 					candidate = candidate && !certainly_outside(a.cd, fd, cur);
 				const uint64_t any = __ballot(candidate);
-				if (any == 0 && updateBits) // every valid lane is invisible (clustercull.comp.glsl:129-130)
-				{
-					const NvMeshTaskCommand cmd = { 0u, 0u, tc, 0u, mvo };
-					clear_visibility_bits<BITS>(a, cmd, cur, lane);
-				}
 				return any;
 			};
 
@@ -662,7 +694,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 #pragma unroll
 				for (int k = 0; k < CC_DA; ++k)
 					issueA(ring[k], (uint32_t)k < cnt ? k : cnt - 1, 0); // clamped: redundant but unconditional loads
-				asm volatile("s_waitcnt vmcnt(%2)" : "+v"(g0), "+v"(g1) : "i"(CC_DA * (BITS ? 2 : 1)) : "memory"); // the gather
+				asm volatile("s_waitcnt vmcnt(%2)" : "+v"(g0), "+v"(g1) : "i"(CC_DA * (BITS_A ? 2 : 1)) : "memory"); // the gather
 				gather_finish();
 				NV_STAMP(2);
 				for (uint32_t i = 0; i < cnt; i += CC_DA)
@@ -684,7 +716,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 					for (int k = 0; k < CC_DA; ++k)
 					{
 						const uint32_t c = i + k;
-						ringA_wait<BITS, CC_DA - 1>(ring[k]);
+						ringA_wait<BITS_A, CC_DA - 1>(ring[k]);
 						uint64_t any = 0;
 						if (c < cnt)
 							any = filter_command(c, (uint32_t)ring[k].bounds, (uint32_t)(ring[k].bounds >> 32), ring[k].mvbWord);
@@ -742,9 +774,15 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 							cur.b1 = (uint32_t)(ring[k].bounds >> 32);
 							cur.cone = ring[k].cone;
 							cur.mvbWord = ring[k].mvbWord;
-							m = cull_command<LATE, BITS>(a, cmd, du, cur, lane);
+							uint64_t vis = 0;
+							m = cull_command<LATE, BITS>(a, cmd, du, cur, lane, &vis);
 							maskLo = writelane_u32(maskLo, (uint32_t)m, c);
 							maskHi = writelane_u32(maskHi, (uint32_t)(m >> 32), c);
+							if (updateBits)
+							{
+								visLo = writelane_u32(visLo, (uint32_t)vis, c);
+								visHi = writelane_u32(visHi, (uint32_t)(vis >> 32), c);
+							}
 						}
 						if (pending)
 						{
@@ -791,7 +829,13 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 						curDraw = cmd.drawId;
 						du = segment_draw(r, c);
 					}
-					m = cull_command<LATE, BITS>(a, cmd, du, cur, lane);
+					uint64_t vis = 0;
+					m = cull_command<LATE, BITS>(a, cmd, du, cur, lane, &vis);
+					if (updateBits)
+					{
+						visLo = writelane_u32(visLo, (uint32_t)vis, c);
+						visHi = writelane_u32(visHi, (uint32_t)(vis >> 32), c);
+					}
 				}
 				maskLo = writelane_u32(maskLo, (uint32_t)m, c);
 				maskHi = writelane_u32(maskHi, (uint32_t)(m >> 32), c);
@@ -801,6 +845,8 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 
 		// the segment's ballots: one 8-B store per lane (32-B runs per chunk), after the rings have drained so that no
 		// store sits between counted loads
+		if (updateBits) // clustercull.comp.glsl:125-131 for the whole segment
+			update_segment_visibility(a, lane < cnt && myIdx < numCmds, r.meshletVisibilityOffset, r.taskCount, ((uint64_t)visHi << 32) | visLo);
 		if (lane < cnt && myIdx < numCmds)
 		{
 			const uint64_t m = ((uint64_t)maskHi << 32) | maskLo;
