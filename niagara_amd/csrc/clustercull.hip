@@ -324,6 +324,7 @@ struct FilterDraw
 	float m[9];  // M, row-major
 	float b[3];
 	float aK, bK; // 4 K u alpha, 4 K u beta (+ an absolute floor)
+	float aR;     // 2^-20 |scale|: covers the roundings of radius * scale, which the filter folds into its threshold
 	float scale;
 };
 
@@ -366,25 +367,51 @@ NV_DEV FilterDraw make_filter(const NvCullData& cd, const DrawUniform& u)
 	const float k4u = 4.0f * 48.0f * 5.9604644775390625e-8f * 1.001f; // 4 K u, rounded up
 	f.aK = k4u * alpha;
 	f.bK = k4u * beta + 1e-30f;
+	f.aR = 9.5367431640625e-7f * __builtin_fabsf(s);
 	f.scale = s;
 	return f;
 }
 
-// true for lanes whose sphere is certainly outside the frustum (see above); never true on NaN
-NV_DEV bool certainly_outside(const NvCullData& cd, const FilterDraw& f, const LaneData& l)
+// Wave-uniform copy of one draw's filter.  M, aK, aR and scale live in SGPRs; the addends of the four FMA chains are
+// pinned in VGPRs (a VOP3P instruction reads at most one SGPR, so an SGPR addend would cost a v_mov per use).
+struct FilterUniform
 {
-	const float vx = half_bits_to_float(l.b0 & 0xffffu), vy = half_bits_to_float(l.b0 >> 16), vz = half_bits_to_float(l.b1 & 0xffffu);
-	const float nu = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(vx), __builtin_fabsf(vy)), __builtin_fabsf(vz));
-	const float cx = __builtin_fmaf(f.m[0], vx, __builtin_fmaf(f.m[1], vy, __builtin_fmaf(f.m[2], vz, f.b[0])));
-	const float cy = __builtin_fmaf(f.m[3], vx, __builtin_fmaf(f.m[4], vy, __builtin_fmaf(f.m[5], vz, f.b[1])));
-	const float cz = __builtin_fmaf(f.m[6], vx, __builtin_fmaf(f.m[7], vy, __builtin_fmaf(f.m[8], vz, f.b[2])));
-	const float r = half_bits_to_float(l.b1 >> 16) * f.scale;
-	const float T = __builtin_fmaf(f.aK, nu, f.bK);
-	const float g1 = __builtin_fmaf(cz, cd.frustum[1], -(__builtin_fabsf(cx) * cd.frustum[0])) + r;
-	const float g2 = __builtin_fmaf(cz, cd.frustum[3], -(__builtin_fabsf(cy) * cd.frustum[2])) + r;
-	const float gn = (cz + r) - cd.znear;
-	const float gf = cd.zfar - (cz - r);
-	return (g1 < -T) | (g2 < -T) | (gn < -T) | (gf < -T);
+	float m[9];
+	float aK, aR, scale;
+	float b0, b1, b2, bK; // VGPR-resident
+};
+
+NV_DEV float pin_vgpr(float x)
+{
+	float v;
+	asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+	return v;
+}
+
+// true for lanes whose sphere is certainly outside the frustum (see above); never true on NaN.
+// 23 VALU instructions per 64 meshlets: 9 + 5 mixed-precision FMAs straight from the packed halfs, 8 for the plane
+// distances and their minimum, one compare.  The threshold carries the radius:  every predicate of the reference reads
+// g > -r (or z + r > znear, z - r < zfar; unit-length plane coefficients), so  min(g_i) < -(r + T)  proves all of them
+// false at once;  T = bK + aK (|vx| + |vy| + |vz|) + aR |radius|  over-estimates 4E (sum >= max) plus the roundings of
+// radius * scale and of the sums with r.
+NV_DEV bool certainly_outside(const NvCullData& cd, const FilterUniform& f, uint32_t b0, uint32_t b1)
+{
+	const float vx = half_bits_to_float(b0 & 0xffffu), vy = half_bits_to_float(b0 >> 16), vz = half_bits_to_float(b1 & 0xffffu);
+	const float rad = half_bits_to_float(b1 >> 16);
+	const float cx = __builtin_fmaf(f.m[0], vx, __builtin_fmaf(f.m[1], vy, __builtin_fmaf(f.m[2], vz, f.b0)));
+	const float cy = __builtin_fmaf(f.m[3], vx, __builtin_fmaf(f.m[4], vy, __builtin_fmaf(f.m[5], vz, f.b1)));
+	const float cz = __builtin_fmaf(f.m[6], vx, __builtin_fmaf(f.m[7], vy, __builtin_fmaf(f.m[8], vz, f.b2)));
+	float T = __builtin_fmaf(f.aK, __builtin_fabsf(vx), f.bK);
+	T = __builtin_fmaf(f.aK, __builtin_fabsf(vy), T);
+	T = __builtin_fmaf(f.aK, __builtin_fabsf(vz), T);
+	T = __builtin_fmaf(f.aR, __builtin_fabsf(rad), T);
+	const float thr = __builtin_fmaf(f.scale, rad, T);
+	const float g1 = __builtin_fmaf(cz, cd.frustum[1], -(__builtin_fabsf(cx) * cd.frustum[0]));
+	const float g2 = __builtin_fmaf(cz, cd.frustum[3], -(__builtin_fabsf(cy) * cd.frustum[2]));
+	const float gn = cz - cd.znear;
+	const float gf = cd.zfar - cz;
+	const float g = __builtin_fminf(__builtin_fminf(g1, g2), __builtin_fminf(gn, gf)); // minNum: a NaN distance is ignored, as a false compare was
+	return g < -thr;
 }
 
 // lane l of a wave holds the l-th command of the wave's current 64-command segment (one coalesced 1280-B read
@@ -416,18 +443,19 @@ NV_DEV uint32_t writelane_u32(uint32_t vec, uint32_t val, uint32_t c)
 
 NV_DEV float readlane_f(float v, uint32_t c) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), c)); }
 
-NV_DEV FilterDraw segment_filter(const SegmentRegs& r, uint32_t c)
+NV_DEV FilterUniform segment_filter(const SegmentRegs& r, uint32_t c)
 {
-	FilterDraw f;
+	FilterUniform f;
 #pragma unroll
 	for (int i = 0; i < 9; ++i)
 		f.m[i] = readlane_f(r.f.m[i], c);
-#pragma unroll
-	for (int i = 0; i < 3; ++i)
-		f.b[i] = readlane_f(r.f.b[i], c);
 	f.aK = readlane_f(r.f.aK, c);
-	f.bK = readlane_f(r.f.bK, c);
+	f.aR = readlane_f(r.f.aR, c);
 	f.scale = readlane_f(r.f.scale, c);
+	f.b0 = pin_vgpr(readlane_f(r.f.b[0], c));
+	f.b1 = pin_vgpr(readlane_f(r.f.b[1], c));
+	f.b2 = pin_vgpr(readlane_f(r.f.b[2], c));
+	f.bK = pin_vgpr(readlane_f(r.f.bK, c));
 	return f;
 }
 
@@ -641,7 +669,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 			// Commands with no possible survivor are finished here (ballot 0); the rest are queued in candMask.
 			// ---- per-segment scalar summaries (one ballot each) so that the walk needs no per-command v_readlane for
 			// control: which commands are full (64 meshlets), empty (dummy), or start a new draw
-			const uint64_t fullMask = __ballot(r.taskCount == 64u);
+			const uint64_t fullMask = __ballot(r.taskCount >= 64u);
 			const uint64_t emptyMask = __ballot(r.taskCount == 0u);
 			const uint32_t prevDraw = __shfl_up(r.drawId, 1, 64);
 			const uint64_t changeMask = __ballot(lane == 0 || r.drawId != prevDraw) | 1ull;
@@ -649,7 +677,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 			const uint32_t lane8 = lane * 8u;
 
 			uint64_t candMask = 0;
-			FilterDraw fd = {};
+			FilterUniform fd = {};
 
 			auto issueA = [&](SlotA& slot, uint32_t c, uint64_t order)
 			{
@@ -677,16 +705,14 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 					return 0;
 				if (changeMask >> c & 1ull) // first command of a draw within this segment
 					fd = segment_filter(r, c);
-				const LaneData cur = { b0, b1, 0u, mvbWord };
-				bool candidate = true;
+				uint64_t cand = ~0ull; // all mask arithmetic is scalar; the tests run on every lane (clamped loads)
 				if (!(fullMask >> c & 1ull))
-					candidate = lane < (uint32_t)__builtin_amdgcn_readlane(r.taskCount, c);
+					cand = (1ull << (uint32_t)__builtin_amdgcn_readlane(r.taskCount, c)) - 1ull; // 0 < taskCount < 64 here
 				if (BITS && !LATE) // early pass: only last frame's visible clusters (clustercull.comp.glsl:91-92)
-					candidate = candidate && (mvbWord >> ((lane + (uint32_t)__builtin_amdgcn_readlane(r.meshletVisibilityOffset, c)) & 31u) & 1u);
+					cand &= __ballot((mvbWord >> ((lane + (uint32_t)__builtin_amdgcn_readlane(r.meshletVisibilityOffset, c)) & 31u) & 1u) != 0);
 				if (useFilter)
-					candidate = candidate && !certainly_outside(a.cd, fd, cur);
-				const uint64_t any = __ballot(candidate);
-				return any;
+					cand &= ~__ballot(certainly_outside(a.cd, fd, b0, b1));
+				return cand;
 			};
 
 			{
