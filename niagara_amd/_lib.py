@@ -15,7 +15,7 @@ except ImportError:  # pragma: no cover - the C ABI itself does not need torch
     pass
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libniagara_vis.so")
+SO_PATH = os.environ.get("NV_LIBRARY_PATH") or os.path.join(_HERE, "libniagara_vis.so")  # override: A/B builds during development
 
 
 class NvError(RuntimeError):

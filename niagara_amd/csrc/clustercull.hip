@@ -302,7 +302,7 @@ NV_DEV uint32_t indirect_command_count(const ClusterArgs& a)
 // The ballots cost 8 B per 64 meshlets of extra traffic (1 %), the extra launch boundary ~2 us.
 constexpr uint32_t CC_CHUNK = 4; // consecutive commands per dealt chunk
 constexpr int CC_DA = 8;         // ring slots of the filter pass: CC_DA - 1 commands' bounds in flight behind the one being filtered
-constexpr int CC_DB = 3;         // ring slots of the exact pass
+constexpr int CC_DB = 6;         // ring slots of the exact pass
 
 // ---- conservative frustum filter (exactness-preserving early-out)
 // The reference's sphere transform costs ~58 un-fused fp32 operations per meshlet and must be reproduced bit for bit
@@ -384,7 +384,9 @@ struct FilterUniform
 NV_DEV float pin_vgpr(float x)
 {
 	float v;
-	asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+	// x usually comes straight from a v_readlane: gfx950 needs 2 wait states between a VALU write of an SGPR and a VALU
+	// read of it, and the hazard recognizer does not look inside inline asm
+	asm("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(v) : "s"(x));
 	return v;
 }
 
@@ -670,7 +672,6 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 			// ---- per-segment scalar summaries (one ballot each) so that the walk needs no per-command v_readlane for
 			// control: which commands are full (64 meshlets), empty (dummy), or start a new draw
 			const uint64_t fullMask = __ballot(r.taskCount >= 64u);
-			const uint64_t emptyMask = __ballot(r.taskCount == 0u);
 			const uint32_t prevDraw = __shfl_up(r.drawId, 1, 64);
 			const uint64_t changeMask = __ballot(lane == 0 || r.drawId != prevDraw) | 1ull;
 			const uint32_t base8 = (r.taskCount ? r.taskOffset : 0u) * 8u; // lane-parallel: byte offset of each command's bounds
@@ -698,23 +699,6 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 				ringA_issue<BITS_A>(slot, a, off8, offw, order);
 			};
 
-			// one command through the filter; returns the ballot of lanes that may survive
-			auto filter_command = [&](uint32_t c, uint32_t b0, uint32_t b1, uint32_t mvbWord) -> uint64_t
-			{
-				if (streamOnly || (emptyMask >> c & 1ull))
-					return 0;
-				if (changeMask >> c & 1ull) // first command of a draw within this segment
-					fd = segment_filter(r, c);
-				uint64_t cand = ~0ull; // all mask arithmetic is scalar; the tests run on every lane (clamped loads)
-				if (!(fullMask >> c & 1ull))
-					cand = (1ull << (uint32_t)__builtin_amdgcn_readlane(r.taskCount, c)) - 1ull; // 0 < taskCount < 64 here
-				if (BITS && !LATE) // early pass: only last frame's visible clusters (clustercull.comp.glsl:91-92)
-					cand &= __ballot((mvbWord >> ((lane + (uint32_t)__builtin_amdgcn_readlane(r.meshletVisibilityOffset, c)) & 31u) & 1u) != 0);
-				if (useFilter)
-					cand &= ~__ballot(certainly_outside(a.cd, fd, b0, b1));
-				return cand;
-			};
-
 			{
 				SlotA ring[CC_DA];
 #pragma unroll
@@ -738,17 +722,27 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 						default: __builtin_amdgcn_s_setprio(3); break;
 						}
 					}
+					// One straight body per command (pass A is bound by scalar and vector ISSUE, not by memory): the filter
+					// runs on all 64 lanes of every slot — clamped loads make that harmless for partial, dummy and
+					// out-of-range commands — and validity is applied to the ballot with scalar mask arithmetic.
 #pragma unroll
 					for (int k = 0; k < CC_DA; ++k)
 					{
 						const uint32_t c = i + k;
 						ringA_wait<BITS_A, CC_DA - 1>(ring[k]);
-						uint64_t any = 0;
-						if (c < cnt)
-							any = filter_command(c, (uint32_t)ring[k].bounds, (uint32_t)(ring[k].bounds >> 32), ring[k].mvbWord);
-						if (any)
+						const uint32_t b0 = (uint32_t)ring[k].bounds, b1 = (uint32_t)(ring[k].bounds >> 32);
+						if (changeMask >> c & 1ull) // first command of a draw within this segment
+							fd = segment_filter(r, c);
+						uint64_t cand = useFilter ? ~__ballot(certainly_outside(a.cd, fd, b0, b1)) : ~0ull;
+						if (!(fullMask >> c & 1ull)) // partial, dummy (taskCount 0) or past the wave's last command (lanes >= cnt hold 0)
+							cand &= (1ull << (uint32_t)__builtin_amdgcn_readlane(r.taskCount, c)) - 1ull;
+						if (BITS_A) // early pass: only last frame's visible clusters (clustercull.comp.glsl:91-92)
+							cand &= __ballot((ring[k].mvbWord >> ((lane + (uint32_t)__builtin_amdgcn_readlane(r.meshletVisibilityOffset, c)) & 31u) & 1u) != 0);
+						if (streamOnly)
+							cand = 0;
+						if (cand)
 							candMask |= 1ull << c;
-						issueA(ring[k], c + CC_DA < cnt ? c + CC_DA : cnt - 1, any);
+						issueA(ring[k], c + CC_DA < cnt ? c + CC_DA : cnt - 1, cand);
 					}
 				}
 			}
@@ -756,7 +750,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 			NV_STAMP(3);
 
 			// ---- pass B: exact tests (reference arithmetic) for the commands that can have survivors, bounds + cone
-			if (candMask)
+			if (candMask && !(a.debugMode & 1024u)) // bit 10 (experiments): no exact pass
 			{
 				uint32_t curDraw = ~0u;
 				DrawUniform du = {};

@@ -59,3 +59,20 @@ print("entry->loop done", np.percentile(busy, [0, 10, 50, 90, 99, 100]).astype(i
 blk = rel.reshape(-1, 4, 6)
 span = blk[:, :, 5].max(axis=1) - blk[:, :, 0].min(axis=1)
 print("per-workgroup span", np.percentile(span, [0, 10, 50, 90, 99, 100]).astype(int))
+
+# per-XCD view (each XCD has its own s_memtime base): when does the LAST wave of the XCD pass each stamp, relative to
+# the XCD's first wave entry
+xcd = (t[:, 0] // 10**9)
+for x in np.unique(xcd):
+    sel = t[xcd == x][:, :6]
+    base = sel[:, 0].min()
+    print("xcd@%d: %5d waves  last entry %6d | last passA-done %6d | last passB-done %6d | last end %6d | median passA-done %6d" %
+          (x, len(sel), sel[:, 0].max() - base, sel[:, 3].max() - base, sel[:, 4].max() - base, sel[:, 5].max() - base, np.median(sel[:, 3]) - base))
+
+# what do the slowest waves spend their time on?
+order = np.argsort(tot)
+for name, idx in (("fastest 10%", order[:len(order) // 10]), ("middle 10%", order[len(order) * 45 // 100:len(order) * 55 // 100]),
+                  ("slowest 10%", order[-(len(order) // 10):]), ("slowest 1%", order[-(len(order) // 100):])):
+    print("%-12s total %6d = " % (name, tot[idx].mean()) + "  ".join("%s %6d" % (nm.split()[0] + nm.split()[1][:1] if " " in nm else nm, d[idx, i].mean()) for i, nm in enumerate(names[1:])))
+# per-workgroup: when does the workgroup's last wave end relative to its first entry, vs the mean over its waves
+print("workgroups: span p50 %d p90 %d p100 %d" % tuple(np.percentile(span, [50, 90, 100])))
