@@ -168,7 +168,8 @@ typedef struct nv_context nv_context;
 int nv_create(nv_context** out_ctx, int device);
 void nv_destroy(nv_context* ctx);
 const char* nv_version(void);
-/* reads and clears the device-side error word; NV_OK or NV_ESTATE. Synchronises the stream. */
+/* Synchronises the stream and returns its state: NV_OK or the HIP error.  (The library has no inter-workgroup waits
+ * and therefore no device-side error word any more; NV_ESTATE is kept for ABI stability.) */
 int nv_status(nv_context* ctx, void* stream);
 
 /* Kernel-level timing with HIP events recorded on the launch stream (replaces the vkCmdWriteTimestamp pairs around

@@ -13,13 +13,16 @@ namespace nv
 // Per-tile survivor counts handed from the cull kernel to the scatter kernel (clustercull.hip).  Two banks: a pass adds
 // into counts[parity] and clears counts[parity ^ 1] for the next one, so nothing is memset between passes and a
 // captured hipGraph replays correctly.
+// Each counter sits in its own 64-byte line: atomics to one line serialise in its L2 channel (measured: 14 k adds into
+// 8 lines cost 13 us, 78 k into 16 lines 20 us), spread over hundreds of lines they are free.
 constexpr uint32_t CC_MAX_SCATTER_TILES = 512;
+constexpr uint32_t CC_COUNT_STRIDE = 16; // words between two tile counters
 struct ClusterCounts
 {
 	uint32_t parity;   // read by the cull kernel; flipped by one thread of the scatter kernel
 	uint32_t k2parity; // the parity of the running pass, written by the cull kernel for the scatter kernel
 	uint32_t pad[30];
-	uint32_t counts[2][CC_MAX_SCATTER_TILES];
+	uint32_t counts[2][CC_MAX_SCATTER_TILES * CC_COUNT_STRIDE];
 };
 
 struct ClusterArgs
@@ -39,9 +42,6 @@ struct ClusterArgs
 	uint64_t* __restrict__ masks; // scratch: one 64-bit ballot per task command
 	ClusterCounts* __restrict__ tileCounts;
 	uint32_t scatterTiles; // grid of the scatter kernel (<= CC_MAX_SCATTER_TILES)
-	uint64_t* __restrict__ state;
-	OrderCtl* __restrict__ ctl;
-	uint32_t stateCapacity;
 	uint32_t commandCountOverride; // probe/taskcull: explicit command count (0 = use count4[1]*64)
 	float* __restrict__ probeOut;
 	uint32_t debugMode; // tuning experiments only (NV_DEBUG_MODE); 0 in production
@@ -57,11 +57,12 @@ struct DrawArgs
 	void* commands;
 	uint32_t* count4;
 	uint32_t* dvb;
-	uint64_t* state;
-	OrderCtl* ctl;
-	uint32_t stateCapacity;
+	uint8_t* results;          // scratch: one result byte per draw, decide kernel -> scatter kernel
+	ClusterCounts* tileCounts; // per-scatter-tile command counts (own instance, same two-bank scheme as clustercull)
+	uint32_t scatterTiles;     // grid of the scatter kernel (<= CC_MAX_SCATTER_TILES)
 	uint32_t fusedReset; // NV_OPT_FUSED_COUNT_RESET
 	uint32_t meshCount;  // > 0 when nv_upload_meshes registered `meshes`: the table may be staged in LDS
+	uint32_t debugMode;  // tuning experiments only (NV_DEBUG_MODE); 0 in production
 };
 
 } // namespace nv

@@ -23,9 +23,8 @@ size_t clustercull_mask_bytes();
 int launch_taskcull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t gridBlocks);
 int launch_probe(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
 int launch_soa_split(hipStream_t, const NvMeshlet*, uint32_t count, uint32_t padded, uint2* bounds, uint32_t* cones);
-uint32_t clustercull_max_tiles(uint32_t gridBlocks);
-int launch_drawcull(hipStream_t, const DrawArgs&, int late, int task, uint32_t gridBlocks);
-uint32_t drawcull_max_tiles(uint32_t drawCount, uint32_t gridBlocks);
+int launch_drawcull(hipStream_t, const DrawArgs&, int late, int task);
+size_t drawcull_result_bytes(uint32_t drawCount);
 int launch_tasksubmit(hipStream_t, uint32_t* count4, NvMeshTaskCommand* commands);
 int launch_reset_count(hipStream_t, uint32_t* a, uint32_t* b);
 int launch_cluster_expand(hipStream_t, const NvMeshTaskCommand*, const NvMeshlet*, const uint32_t* clusterIndices, const uint32_t* cc4,
@@ -46,11 +45,12 @@ struct nv_context
 {
 	int device;
 	int numCUs;
-	nv::OrderCtl* ctl;
-	uint64_t* state;
-	uint32_t stateCapacity;
 	uint64_t* masks; // per-command ballots between the two clustercull launches
 	nv::ClusterCounts* tileCounts;
+	// drawcull: per-draw result bytes between its two launches, and its own per-tile counts
+	uint8_t* drawResults;
+	size_t drawResultsCapacity;
+	nv::ClusterCounts* drawTileCounts;
 	// SoA mirror of the meshlet cull bytes
 	const NvMeshlet* mirroredFrom;
 	uint32_t mirroredCount;
@@ -116,25 +116,23 @@ NvPyramidDesc null_pyramid()
 	return p;
 }
 
-int ensure_state(nv_context* ctx, uint32_t tiles)
+// per-draw result bytes between drawcull's two launches; growth is rare and synchronises the device
+int ensure_draw_results(nv_context* ctx, uint32_t drawCount)
 {
-	if (tiles <= ctx->stateCapacity)
+	const size_t need = nv::drawcull_result_bytes(drawCount);
+	if (need <= ctx->drawResultsCapacity)
 		return NV_OK;
-	// growth is rare (only for > 2^28 draws); it synchronises the device
 	hipError_t e = hipDeviceSynchronize();
 	if (e != hipSuccess)
 		return (int)e;
-	if (ctx->state)
-		(void)hipFree(ctx->state);
-	ctx->state = nullptr;
-	ctx->stateCapacity = 0;
-	e = hipMalloc(&ctx->state, (size_t)tiles * sizeof(uint64_t));
-	if (e != hipSuccess)
+	if (ctx->drawResults)
+		(void)hipFree(ctx->drawResults);
+	ctx->drawResults = nullptr;
+	ctx->drawResultsCapacity = 0;
+	const size_t cap = need < (size_t(1) << 21) ? (size_t(1) << 21) : need + need / 2;
+	if (hipMalloc(&ctx->drawResults, cap) != hipSuccess)
 		return NV_ENOMEM;
-	e = hipMemset(ctx->state, 0, (size_t)tiles * sizeof(uint64_t));
-	if (e != hipSuccess)
-		return (int)e;
-	ctx->stateCapacity = tiles;
+	ctx->drawResultsCapacity = cap;
 	return NV_OK;
 }
 
@@ -145,7 +143,7 @@ uint32_t scatter_grid(const nv_context* ctx)
 	return g > nv::CC_MAX_SCATTER_TILES ? nv::CC_MAX_SCATTER_TILES : g;
 }
 
-// co-resident grid of the ordered passes (ordered.cuh): blocksPerCU workgroups of 256 threads per CU
+// grid of the streaming kernels: blocksPerCU workgroups of 256 threads per CU
 uint32_t persistent_grid(const nv_context* ctx, uint32_t blocksPerCU)
 {
 	return (uint32_t)ctx->numCUs * blocksPerCU;
@@ -189,35 +187,14 @@ int nv_create(nv_context** out_ctx, int device)
 	if (const char* v = getenv("NV_CC_BLOCKS_PER_CU"))
 		ctx->ccBlocksPerCU = (uint32_t)atoi(v) ? (uint32_t)atoi(v) : 6;
 
-	e = hipMalloc(&ctx->ctl, sizeof(nv::OrderCtl));
-	if (e == hipSuccess)
-	{
-		nv::OrderCtl init;
-		memset(&init, 0, sizeof(init));
-		init.epoch = 1;
-		e = hipMemcpy(ctx->ctl, &init, sizeof(init), hipMemcpyHostToDevice);
-	}
-	if (e != hipSuccess)
-	{
-		nv_destroy(ctx);
-		return e == hipErrorOutOfMemory ? NV_ENOMEM : (int)e;
-	}
-
 	if (hipMalloc(&ctx->masks, nv::clustercull_mask_bytes()) != hipSuccess || hipMalloc(&ctx->tileCounts, sizeof(nv::ClusterCounts)) != hipSuccess ||
-	    hipMemset(ctx->tileCounts, 0, sizeof(nv::ClusterCounts)) != hipSuccess)
+	    hipMemset(ctx->tileCounts, 0, sizeof(nv::ClusterCounts)) != hipSuccess ||
+	    hipMalloc(&ctx->drawTileCounts, sizeof(nv::ClusterCounts)) != hipSuccess ||
+	    hipMemset(ctx->drawTileCounts, 0, sizeof(nv::ClusterCounts)) != hipSuccess || ensure_draw_results(ctx, 1u << 20) != NV_OK)
 	{
 		nv_destroy(ctx);
 		return NV_ENOMEM;
 	}
-	// one granule per tile of the largest pass
-	uint32_t tiles = nv::clustercull_max_tiles(persistent_grid(ctx, 4));
-	int rc = ensure_state(ctx, tiles < (1u << 16) ? (1u << 16) : tiles);
-	if (rc != NV_OK)
-	{
-		nv_destroy(ctx);
-		return rc;
-	}
-
 	*out_ctx = ctx;
 	return NV_OK;
 }
@@ -227,10 +204,10 @@ void nv_destroy(nv_context* ctx)
 	if (!ctx)
 		return;
 	DeviceGuard guard(ctx->device);
-	if (ctx->ctl)
-		(void)hipFree(ctx->ctl);
-	if (ctx->state)
-		(void)hipFree(ctx->state);
+	if (ctx->drawResults)
+		(void)hipFree(ctx->drawResults);
+	if (ctx->drawTileCounts)
+		(void)hipFree(ctx->drawTileCounts);
 	if (ctx->masks)
 		(void)hipFree(ctx->masks);
 	if (ctx->tileCounts)
@@ -253,21 +230,6 @@ int nv_status(nv_context* ctx, void* stream)
 	hipError_t e = hipStreamSynchronize((hipStream_t)stream);
 	if (e != hipSuccess)
 		return (int)e;
-	uint32_t err = 0;
-	e = hipMemcpy(&err, &ctx->ctl->error, sizeof(err), hipMemcpyDeviceToHost);
-	if (e != hipSuccess)
-		return (int)e;
-	if (err)
-	{
-		// a timed-out chain leaves tickets/epoch in an undefined state: re-arm everything
-		nv::OrderCtl init;
-		memset(&init, 0, sizeof(init));
-		init.epoch = 1;
-		(void)hipMemcpy(ctx->ctl, &init, sizeof(init), hipMemcpyHostToDevice);
-		(void)hipMemset(ctx->state, 0, (size_t)ctx->stateCapacity * sizeof(uint64_t));
-		(void)hipMemset(ctx->tileCounts, 0, sizeof(nv::ClusterCounts));
-		return NV_ESTATE;
-	}
 	return NV_OK;
 }
 
@@ -395,8 +357,7 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 		return NV_EINVAL;
 	DeviceGuard guard(ctx->device);
 
-	const uint32_t grid = persistent_grid(ctx, 4);
-	int rc = ensure_state(ctx, nv::drawcull_max_tiles(cull->drawCount, grid));
+	int rc = ensure_draw_results(ctx, cull->drawCount);
 	if (rc)
 		return rc;
 
@@ -408,13 +369,14 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 	a.commands = d_commands;
 	a.count4 = d_count4;
 	a.dvb = d_drawVisibility;
-	a.state = ctx->state;
-	a.ctl = ctx->ctl;
-	a.stateCapacity = ctx->stateCapacity;
+	a.results = ctx->drawResults;
+	a.tileCounts = ctx->drawTileCounts;
+	a.scatterTiles = scatter_grid(ctx);
+	a.debugMode = ctx->debugMode;
 	a.fusedReset = ctx->fusedReset;
 	a.meshCount = ctx->meshesFrom == d_meshes ? ctx->meshCount : 0u;
 	hipEvent_t e0 = prof_mark(ctx, (hipStream_t)stream);
-	rc = nv::launch_drawcull((hipStream_t)stream, a, late, task, grid);
+	rc = nv::launch_drawcull((hipStream_t)stream, a, late, task);
 	prof_push(ctx, NV_PROF_DRAWCULL, e0, prof_mark(ctx, (hipStream_t)stream));
 	return rc;
 }
@@ -459,9 +421,6 @@ static int fill_cluster_args(nv_context* ctx, nv::ClusterArgs& a, const NvCullDa
 	a.masks = ctx->masks;
 	a.tileCounts = ctx->tileCounts;
 	a.scatterTiles = scatter_grid(ctx);
-	a.state = ctx->state;
-	a.ctl = ctx->ctl;
-	a.stateCapacity = ctx->stateCapacity;
 	return NV_OK;
 }
 

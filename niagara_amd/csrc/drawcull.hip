@@ -2,15 +2,20 @@
 //
 // Replaces src/shaders/drawcull.comp.glsl:54-156 (4 pipelines LATE x TASK, src/niagara.cpp:724-727).
 //
-// Mapping to CDNA4:
-//   * one lane per draw; a workgroup owns one contiguous tile of draws per pass and keeps the next step's 48-B
-//     MeshDraw record (3 x 16-B loads) + visibility word in flight while it tests the current one;
-//   * the emit count of a draw (1 command, or ceil(meshletCount/64) task commands) is scanned inside the wave with
-//     DPP shuffles, across waves through LDS, and across tiles through ordered.cuh — append index = exclusive prefix
-//     in draw order, no per-draw global atomic (drawcull.comp.glsl:123,143);
-//   * TASK mode expands a draw's commands wave-cooperatively: the owning lane's (draw, LOD range, dci) is broadcast
-//     with readlane and all 64 lanes write consecutive 20-B MeshTaskCommands, instead of one lane looping over
-//     up to hundreds of commands (drawcull.comp.glsl:131-138).
+// Mapping to CDNA4 — two wait-free launches on the stream, the same scheme as clustercull.hip:
+//   K1 draw_decide_kernel   one lane per draw, 1024 draws per workgroup, all four 52-B records of a lane requested
+//                           before the first is used.  Decides visibility / LOD (reference arithmetic), writes one
+//                           result byte per draw (LOD | emit << 3 | old visibility << 4), the new drawVisibility word
+//                           (LATE), and adds each wave's command count to the count of the scatter tile it falls in
+//                           (one fire-and-forget atomic per wave that emits anything).
+//   K2 draw_scatter_kernel  one workgroup per CU owns a contiguous range of draws; its append base is the count word
+//                           plus the counts of the tiles before it, so no workgroup waits on another.  Each lane owns
+//                           16 consecutive draws (one 16-B load of result bytes); the append index of a draw is the
+//                           exclusive prefix sum of the emit counts in draw order — one valid serialisation of the
+//                           reference's atomicAdd (drawcull.comp.glsl:123,143), and bit-reproducible.
+//                           TASK mode expands a draw's commands wave-cooperatively: the owning lane's (draw, LOD range,
+//                           dci) is broadcast with readlane and all 64 lanes write consecutive 20-B MeshTaskCommands,
+//                           instead of one lane looping over up to hundreds of commands (drawcull.comp.glsl:131-138).
 #include "cullmath.cuh"
 #include "ordered.cuh"
 #include "args.cuh"
@@ -20,7 +25,8 @@ namespace nv
 
 constexpr int DC_WAVES = 4;
 constexpr int DC_THREADS = DC_WAVES * 64;
-constexpr uint32_t DC_TMAX = 1024;    // draws per tile: 5 x 4 KiB of per-draw results in LDS
+constexpr int DC_BATCH = 4;                          // draws per lane of the decide kernel
+constexpr uint32_t DC_TILE = DC_THREADS * DC_BATCH;   // draws per workgroup of the decide kernel
 constexpr uint32_t DC_MESH_LDS = 64;  // meshes staged in LDS (13 KiB) when the table is registered and small enough
 
 
@@ -73,7 +79,7 @@ NV_DEV DrawResult decide_draw(const DrawArgs& a, const char* meshBase, uint32_t 
 	if (visible && (!LATE || cd.clusterOcclusionEnabled == 1 || oldVis == 0 || cd.postPass != 0))
 	{
 		uint32_t lodIndex = 0;
-		if (cd.lodEnabled == 1)
+		if (cd.lodEnabled == 1 && !(a.debugMode & 2u))
 		{
 			float distance = gl_max(length3(c) - radius, 0.0f);
 			float threshold = distance * cd.lodTarget / d0.w;
@@ -118,146 +124,304 @@ NV_DEV DrawLoad load_draw_record(const DrawArgs& a, uint32_t di)
 	return l;
 }
 
-// Static tiles, one per workgroup per pass (see ordered.cuh and clustercull.hip): phase 1 decide -> per-draw emit
-// count / LOD / old visibility in LDS, phase 2 tile total, phase 3 look-back across tiles, phase 4 ordered emit.
-template <bool LATE, bool TASK, bool MESH_LDS>
-__global__ __launch_bounds__(DC_THREADS) void drawcull_kernel(DrawArgs a)
+// draws per scatter tile: an even split over the scatter grid, rounded up to whole waves of the decide kernel
+NV_DEV uint32_t scatter_tile_draws(uint32_t drawCount, uint32_t tiles)
 {
-	__shared__ uint32_t s_count[DC_TMAX];
-	__shared__ uint32_t s_flags[DC_TMAX];
-	__shared__ uint32_t s_old[DC_TMAX];
-	__shared__ uint32_t s_mesh[DC_TMAX]; // meshIndex and meshletVisibilityOffset of the tile's draws, for the emit phase
-	__shared__ uint32_t s_mvo[DC_TMAX];
+	const uint32_t t = (drawCount + tiles - 1) / tiles;
+	return t < 64u ? 64u : (t + 63u) / 64u * 64u;
+}
+
+template <bool MESH_LDS>
+NV_DEV const char* stage_mesh_table(const DrawArgs& a, uint32_t* s_meshTable)
+{
+	if (!MESH_LDS)
+		return reinterpret_cast<const char*>(a.meshes);
+	const uint32_t words = a.meshCount * (uint32_t)(sizeof(NvMesh) / 4);
+	const uint32_t* src = reinterpret_cast<const uint32_t*>(a.meshes);
+	for (uint32_t i = threadIdx.x; i < words; i += DC_THREADS)
+		s_meshTable[i] = src[i];
+	__syncthreads();
+	return reinterpret_cast<const char*>(s_meshTable);
+}
+
+// K1
+template <bool LATE, bool TASK, bool MESH_LDS>
+__global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
+{
 	// the Mesh table (center/radius, LOD errors, LOD ranges) is read by every draw: staged once per workgroup when
 	// nv_upload_meshes registered a table of at most DC_MESH_LDS meshes, otherwise gathered from global memory
 	__shared__ __attribute__((aligned(16))) uint32_t s_meshTable[MESH_LDS ? DC_MESH_LDS * sizeof(NvMesh) / 4 : 4];
-	__shared__ uint32_t s_part[DC_WAVES];
-	__shared__ uint32_t s_scratch[16];
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const uint32_t G = gridDim.x;
 
 	const uint32_t drawCount = a.cd.drawCount;
-	uint32_t T = ((drawCount + G - 1) / G + DC_THREADS - 1) / DC_THREADS * DC_THREADS;
-	T = T < DC_THREADS ? DC_THREADS : (T > DC_TMAX ? DC_TMAX : T);
-	const uint32_t numTiles = (drawCount + T - 1) / T;
-	const uint32_t epoch = load_epoch(a.ctl);
-	const uint32_t base0 = a.fusedReset ? 0u : a.count4[0];
+	const uint32_t T2 = scatter_tile_draws(drawCount, a.scatterTiles);
+	const uint32_t bank = __hip_atomic_load(&a.tileCounts->parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
+	if (blockIdx.x == 0 && tid == 0)
+		__hip_atomic_store(&a.tileCounts->k2parity, bank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-	const char* meshBase = reinterpret_cast<const char*>(a.meshes);
-	if (MESH_LDS)
+	const uint32_t first = blockIdx.x * DC_TILE;
+	if (first >= drawCount)
+		return;
+	const uint32_t n = drawCount - first < DC_TILE ? drawCount - first : DC_TILE;
+
+	// Indices past the tile are clamped, not branched, so that the loads are unconditional and the compiler can count
+	// them (s_waitcnt vmcnt(N)) instead of draining after each one; they are issued ahead of the mesh-table staging.
+	DrawLoad ld[DC_BATCH];
+#pragma unroll
+	for (int j = 0; j < DC_BATCH; ++j)
 	{
-		const uint32_t words = a.meshCount * (uint32_t)(sizeof(NvMesh) / 4);
-		const uint32_t* src = reinterpret_cast<const uint32_t*>(a.meshes);
-		for (uint32_t i = tid; i < words; i += DC_THREADS)
-			s_meshTable[i] = src[i];
-		meshBase = reinterpret_cast<const char*>(s_meshTable);
-		__syncthreads();
+		const uint32_t c = j * DC_THREADS + tid;
+		ld[j] = load_draw_record(a, first + (c < n ? c : n - 1));
 	}
+	const char* meshBase = stage_mesh_table<MESH_LDS>(a, s_meshTable);
 
-	for (uint32_t tile = blockIdx.x; tile < numTiles; tile += G)
+	// per wave-batch command counts -> LDS; merged per scatter tile below
+	__shared__ uint32_t s_waveCount[DC_BATCH * DC_WAVES];
+#pragma unroll
+	for (int j = 0; j < DC_BATCH; ++j)
 	{
-		const uint32_t first = tile * T;
-		const uint32_t n = drawCount - first < T ? drawCount - first : T;
-
-		// ---- phase 1: one draw per lane per step, four steps' records (4 x 52 bytes per lane) requested before any of
-		// them is used.  Indices past the tile are clamped, not branched, so that the loads are unconditional and the
-		// compiler can count them (s_waitcnt vmcnt(N)) instead of draining after each one.
-		uint32_t threadSum = 0;
-		constexpr int DC_BATCH = 4;
-		for (uint32_t c0 = 0; c0 < n; c0 += DC_THREADS * DC_BATCH)
+		const uint32_t c = j * DC_THREADS + tid;
+		uint32_t count = 0;
+		if (c < n)
 		{
-			DrawLoad ld[DC_BATCH];
+			DrawResult res = { 0, 0, 0 };
+			if (a.debugMode & 1u) // experiments: loads only
+				res.lodWord = __float_as_uint(ld[j].d0.x + ld[j].d1.x) + ld[j].d2.x + ld[j].oldVis == 12345u ? 0x100u : 0u;
+			else
+				res = decide_draw<LATE, TASK>(a, meshBase, first + c, ld[j].d0, ld[j].d1, ld[j].d2, ld[j].oldVis);
+			a.results[first + c] = (uint8_t)((res.lodWord & 7u) | ((res.lodWord >> 8 & 1u) << 3) | ((ld[j].oldVis != 0 ? 1u : 0u) << 4));
+			count = res.count;
+		}
+		const uint32_t waveCount = wave_sum_u32(count);
+		if (lane == 0)
+			s_waveCount[j * DC_WAVES + wave] = waveCount;
+	}
+	__syncthreads();
+	// One thread adds the workgroup's counts to the scatter tiles they fall in (tiles are whole multiples of 64 draws, so
+	// a wave-batch never straddles; a workgroup's 1024 draws usually span one or two tiles): ~1.3 atomics per
+	// workgroup instead of one per wave-batch — atomics into one line serialise in its L2 channel (args.cuh).
+	if (tid == 0 && !(a.debugMode & 4u))
+	{
+		uint32_t runTile = first / T2, runSum = 0;
 #pragma unroll
-			for (int j = 0; j < DC_BATCH; ++j)
+		for (uint32_t i = 0; i < DC_BATCH * DC_WAVES; ++i)
+		{
+			const uint32_t t = (first + i * 64u) / T2;
+			if (t != runTile)
 			{
-				const uint32_t c = c0 + j * DC_THREADS + tid;
-				ld[j] = load_draw_record(a, first + (c < n ? c : n - 1));
+				if (runSum)
+					atomicAdd(&a.tileCounts->counts[bank][runTile * CC_COUNT_STRIDE], runSum);
+				runTile = t;
+				runSum = 0;
 			}
+			runSum += s_waveCount[i];
+		}
+		if (runSum)
+			atomicAdd(&a.tileCounts->counts[bank][runTile * CC_COUNT_STRIDE], runSum);
+	}
+}
+
+// result bytes of PER consecutive draws, packed little-endian into words
+template <uint32_t PER>
+NV_DEV void load_result_bytes(const uint8_t* p, uint32_t (&w)[4])
+{
+	w[0] = w[1] = w[2] = w[3] = 0;
+	if (PER == 1)
+		w[0] = *p;
+	else if (PER == 4)
+		w[0] = *reinterpret_cast<const uint32_t*>(p);
+	else
+	{
+		const uint4 v = *reinterpret_cast<const uint4*>(p);
+		w[0] = v.x;
+		w[1] = v.y;
+		w[2] = v.z;
+		w[3] = v.w;
+	}
+}
+
+// K2.  DC_PER_LANE = consecutive draws per lane (1, 4 or 16, chosen by the launcher so that a tile is one step and all
+// lanes have work: 16 for >= 1 M draws, 1 for the few thousand draws of a small scene).
+template <bool TASK, bool MESH_LDS, uint32_t DC_PER_LANE>
+__global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
+{
+	constexpr uint32_t DC_STEP = DC_THREADS * DC_PER_LANE;
+	__shared__ __attribute__((aligned(16))) uint32_t s_meshTable[MESH_LDS ? DC_MESH_LDS * sizeof(NvMesh) / 4 : 4];
+	__shared__ uint32_t s_part[DC_WAVES];
+	__shared__ uint32_t s_sum[DC_WAVES];
+
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63u;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+	const uint32_t drawCount = a.cd.drawCount;
+	const uint32_t T = scatter_tile_draws(drawCount, a.scatterTiles);
+	const uint32_t numTiles = (drawCount + T - 1) / T; // <= gridDim.x
+	const uint32_t tile = blockIdx.x;
+
+	// Everything below was written by the decide kernel, i.e. before this launch: plain loads, all issued together.
+	// Both banks of tile counts are read speculatively so that no load waits for the parity word.
+	const uint32_t k2parity = a.tileCounts->k2parity;
+	const uint32_t base0 = a.fusedReset ? 0u : a.count4[0];
+	uint32_t cnt0[2] = { 0, 0 }, cnt1[2] = { 0, 0 }; // this thread's tiles tid and tid + 256, per bank
 #pragma unroll
-			for (int j = 0; j < DC_BATCH; ++j)
+	for (int j = 0; j < 2; ++j)
+	{
+		const uint32_t i = j * DC_THREADS + tid;
+		if (i < numTiles)
+		{
+			cnt0[j] = a.tileCounts->counts[0][i * CC_COUNT_STRIDE];
+			cnt1[j] = a.tileCounts->counts[1][i * CC_COUNT_STRIDE];
+		}
+	}
+	const uint32_t first = tile * T;
+	const uint32_t n = tile < numTiles ? (drawCount - first < T ? drawCount - first : T) : 0u;
+	uint32_t bw[4] = { 0, 0, 0, 0 }; // first step's result bytes (usually the only step)
+	if (tid * DC_PER_LANE < n)
+		load_result_bytes<DC_PER_LANE>(a.results + first + tid * DC_PER_LANE, bw);
+
+	const uint32_t bank = k2parity & 1u;
+	// every workgroup clears its entries of the other bank for the next pass; one thread flips the parity the next
+	// decide kernel will read (this pass reads k2parity only)
+	for (uint32_t i = tile * DC_THREADS + tid; i < CC_MAX_SCATTER_TILES; i += gridDim.x * DC_THREADS)
+		a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE] = 0;
+	if (tile == 0 && tid == 0)
+	{
+		a.tileCounts->parity = bank ^ 1u;
+		if (numTiles == 0 && a.fusedReset)
+			a.count4[0] = 0; // no draws: the fused reset still leaves a zero count
+	}
+	if (tile >= numTiles)
+		return;
+
+	const char* meshBase = stage_mesh_table<MESH_LDS>(a, s_meshTable);
+
+	uint32_t before = 0, all = 0;
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		const uint32_t i = j * DC_THREADS + tid;
+		const uint32_t v = bank ? cnt1[j] : cnt0[j];
+		all += v;
+		before += i < tile ? v : 0u;
+	}
+	const uint32_t wBefore = wave_sum_u32(before), wAll = wave_sum_u32(all);
+	if (lane == 0)
+	{
+		s_part[wave] = wBefore;
+		s_sum[wave] = wAll;
+	}
+	__syncthreads();
+	uint32_t running = base0, total = base0;
+#pragma unroll
+	for (int w = 0; w < DC_WAVES; ++w)
+	{
+		running += s_part[w];
+		total += s_sum[w];
+	}
+	if (tid == 0 && tile == numTiles - 1)
+		a.count4[0] = total; // what the chain of atomicAdds leaves in the count word
+
+	for (uint32_t c0 = 0; c0 < n; c0 += DC_STEP)
+	{
+		const uint32_t c = c0 + tid * DC_PER_LANE; // this lane's first draw within the tile
+		if (c0)
+		{
+			bw[0] = bw[1] = bw[2] = bw[3] = 0;
+			if (c < n)
+				load_result_bytes<DC_PER_LANE>(a.results + first + c, bw);
+		}
+		uint32_t res[DC_PER_LANE];  // result byte, 0 past the tile
+		uint32_t meshIndex[DC_PER_LANE], mvo[DC_PER_LANE], cnt[DC_PER_LANE];
+#pragma unroll
+		for (uint32_t j = 0; j < DC_PER_LANE; ++j)
+		{
+			res[j] = c + j < n ? (bw[j / 4] >> (8 * (j % 4)) & 0xffu) : 0u;
+			meshIndex[j] = 0;
+			mvo[j] = 0;
+			if (res[j] & 8u) // emitting draws only: meshIndex, meshletVisibilityOffset (8 B of the 48-B record)
 			{
-				const uint32_t c = c0 + j * DC_THREADS + tid;
-				if (c < n)
-				{
-					DrawResult res = decide_draw<LATE, TASK>(a, meshBase, first + c, ld[j].d0, ld[j].d1, ld[j].d2, ld[j].oldVis);
-					s_count[c] = res.count;
-					s_flags[c] = res.lodWord;
-					s_old[c] = ld[j].oldVis;
-					s_mesh[c] = ld[j].d2.x;
-					s_mvo[c] = ld[j].d2.y;
-					threadSum += res.count;
-				}
+				const uint2 d2 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.draws + first + c + j) + 32);
+				meshIndex[j] = d2.x;
+				mvo[j] = d2.y;
 			}
 		}
-
-		// ---- phase 2 + 3
-		uint32_t waveSum = wave_sum_u32(threadSum);
-		if (lane == 0)
-			s_part[wave] = waveSum;
+		uint32_t mine = 0;
+#pragma unroll
+		for (uint32_t j = 0; j < DC_PER_LANE; ++j)
+		{
+			cnt[j] = 0;
+			if (res[j] & 8u)
+			{
+				if (TASK)
+				{
+					const char* mesh = meshBase + (size_t)meshIndex[j] * sizeof(NvMesh);
+					const uint32_t meshletCount = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * (res[j] & 7u) + 12);
+					cnt[j] = (meshletCount + NV_TASK_WGSIZE - 1) / NV_TASK_WGSIZE;
+				}
+				else
+					cnt[j] = 1;
+			}
+			mine += cnt[j];
+		}
+		const uint32_t incl = wave_inclusive_scan(mine, lane);
+		__syncthreads(); // s_part free (base reduction / previous step's readers are done)
+		if (lane == 63)
+			s_part[wave] = incl;
 		__syncthreads();
-		uint32_t aggregate = 0;
+		uint32_t dci = running + incl - mine;
 #pragma unroll
 		for (int w = 0; w < DC_WAVES; ++w)
-			aggregate += s_part[w];
-		const uint32_t exclusive = lookback_exclusive(a.state, a.ctl, tile, epoch, aggregate, base0, s_scratch);
-		if (tid == 0 && tile == numTiles - 1)
 		{
-			a.count4[0] = exclusive + aggregate;
-			advance_epoch(a.ctl, epoch);
+			const uint32_t p = s_part[w];
+			dci += w < (int)wave ? p : 0u;
+			running += p;
 		}
-		__syncthreads(); // s_part is reused by the emit scan
 
-		// ---- phase 4: ordered emit, 256 draws per step
-		uint32_t running = exclusive;
-		for (uint32_t c0 = 0; c0 < n; c0 += DC_THREADS)
-		{
-			const uint32_t c = c0 + tid;
-			const uint32_t cnt = c < n ? s_count[c] : 0u;
-			const uint32_t flags = c < n ? s_flags[c] : 0u;
-			const uint32_t incl = wave_inclusive_scan(cnt, lane);
-			__syncthreads();
-			if (lane == 63)
-				s_part[wave] = incl;
-			__syncthreads();
-			uint32_t waveBase = running;
 #pragma unroll
-			for (int w = 0; w < DC_WAVES; ++w)
-			{
-				uint32_t p = s_part[w];
-				waveBase += w < (int)wave ? p : 0u;
-				running += p;
-			}
-			const uint32_t dci = waveBase + incl - cnt;
-			const bool emit = (flags & 0x100u) != 0;
-			const uint32_t lodIndex = flags & 0xffu;
-			const uint32_t di = first + c;
-
+		for (uint32_t j = 0; j < DC_PER_LANE; ++j)
+		{
+			const uint32_t lodIndex = res[j] & 7u;
 			if (TASK)
 			{
-				// wave-cooperative expansion, one owning lane at a time (drawcull.comp.glsl:120-139)
-				uint64_t owners = __ballot(emit && cnt != 0);
+				// drawcull.comp.glsl:120-139.  Draws with a handful of task groups write their own commands (all lanes
+				// in parallel); larger ones are expanded wave-cooperatively, one owning lane at a time, so that no lane
+				// loops over hundreds of commands while 63 others wait.
+				constexpr uint32_t DC_SMALL = 4;
+				uint64_t owners = __ballot(cnt[j] > DC_SMALL);
+				const uint32_t oldVis = res[j] >> 4 & 1u;
 				NvMeshTaskCommand* tc = static_cast<NvMeshTaskCommand*>(a.commands);
-				uint32_t meshIndex = 0, mvo = 0, oldVis = 0;
-				if (emit && cnt != 0)
+				if (cnt[j] != 0 && cnt[j] <= DC_SMALL && dci + cnt[j] <= NV_TASK_WGLIMIT) // drop the whole draw on overflow (:128)
 				{
-					meshIndex = s_mesh[c];
-					mvo = s_mvo[c];
-					oldVis = s_old[c];
+					const char* mesh = meshBase + (size_t)meshIndex[j] * sizeof(NvMesh);
+					const uint32_t meshletOffset = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * lodIndex + 8);
+					const uint32_t meshletCount = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * lodIndex + 12);
+					for (uint32_t i = 0; i < cnt[j]; ++i)
+					{
+						NvMeshTaskCommand cmd;
+						cmd.drawId = first + c + j;
+						cmd.taskOffset = meshletOffset + i * NV_TASK_WGSIZE;
+						const uint32_t rest = meshletCount - i * NV_TASK_WGSIZE;
+						cmd.taskCount = rest < NV_TASK_WGSIZE ? rest : NV_TASK_WGSIZE;
+						cmd.lateDrawVisibility = oldVis;
+						cmd.meshletVisibilityOffset = mvo[j] + i * NV_TASK_WGSIZE;
+						tc[dci + i] = cmd;
+					}
 				}
 				while (owners)
 				{
 					const int src = __builtin_ctzll(owners);
 					owners &= owners - 1;
-					const uint32_t oDraw = first + c0 + wave * 64 + src;
+					const uint32_t oDraw = first + c0 + (wave * 64 + src) * DC_PER_LANE + j;
 					const uint32_t oDci = __builtin_amdgcn_readlane(dci, src);
-					const uint32_t oGroups = __builtin_amdgcn_readlane(cnt, src);
+					const uint32_t oGroups = __builtin_amdgcn_readlane(cnt[j], src);
 					const uint32_t oLod = __builtin_amdgcn_readlane(lodIndex, src);
 					const uint32_t oVis = __builtin_amdgcn_readlane(oldVis, src);
-					const uint32_t oMesh = __builtin_amdgcn_readlane(meshIndex, src);
-					const uint32_t oMvo = __builtin_amdgcn_readlane(mvo, src);
+					const uint32_t oMesh = __builtin_amdgcn_readlane(meshIndex[j], src);
+					const uint32_t oMvo = __builtin_amdgcn_readlane(mvo[j], src);
 					if (oDci + oGroups <= NV_TASK_WGLIMIT) // drop the whole draw on overflow (:128)
 					{
 						const char* mesh = meshBase + (size_t)oMesh * sizeof(NvMesh);
@@ -277,61 +441,74 @@ __global__ __launch_bounds__(DC_THREADS) void drawcull_kernel(DrawArgs a)
 					}
 				}
 			}
-			else if (emit)
+			else if (cnt[j])
 			{
 				// drawcull.comp.glsl:141-150
-				const uint32_t meshIndex = s_mesh[c];
-				const char* mesh = meshBase + (size_t)meshIndex * sizeof(NvMesh);
+				const char* mesh = meshBase + (size_t)meshIndex[j] * sizeof(NvMesh);
 				const uint32_t indexOffset = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * lodIndex + 0);
 				const uint32_t indexCount = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * lodIndex + 4);
 				const uint32_t vertexOffset = *reinterpret_cast<const uint32_t*>(mesh + 16);
 				uint2* dc = reinterpret_cast<uint2*>(static_cast<NvMeshDrawCommand*>(a.commands) + dci);
-				dc[0] = make_uint2(di, indexCount);
+				dc[0] = make_uint2(first + c + j, indexCount);
 				dc[1] = make_uint2(1u, indexOffset);
 				dc[2] = make_uint2(vertexOffset, 0u);
 			}
+			dci += cnt[j];
 		}
-		__syncthreads(); // LDS is rewritten by the next tile
-
-		if (tile == numTiles - 1 && ((epoch + 1) & 0x3fffffffu) == 0)
-			for (uint32_t i = tid; i < a.stateCapacity; i += DC_THREADS)
-				a.state[i] = 0;
 	}
 }
 
 template <bool MESH_LDS>
-static void launch_dc(hipStream_t stream, const DrawArgs& a, int late, int task, uint32_t gridBlocks)
+static void launch_dc(hipStream_t stream, const DrawArgs& a, int late, int task, uint32_t decideBlocks)
 {
-	dim3 grid(gridBlocks), block(DC_THREADS);
+	dim3 grid(decideBlocks), block(DC_THREADS);
 	if (late)
 	{
 		if (task)
-			hipLaunchKernelGGL((drawcull_kernel<true, true, MESH_LDS>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((draw_decide_kernel<true, true, MESH_LDS>), grid, block, 0, stream, a);
 		else
-			hipLaunchKernelGGL((drawcull_kernel<true, false, MESH_LDS>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((draw_decide_kernel<true, false, MESH_LDS>), grid, block, 0, stream, a);
 	}
 	else
 	{
 		if (task)
-			hipLaunchKernelGGL((drawcull_kernel<false, true, MESH_LDS>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((draw_decide_kernel<false, true, MESH_LDS>), grid, block, 0, stream, a);
 		else
-			hipLaunchKernelGGL((drawcull_kernel<false, false, MESH_LDS>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((draw_decide_kernel<false, false, MESH_LDS>), grid, block, 0, stream, a);
+	}
+	const uint32_t t = (a.cd.drawCount + a.scatterTiles - 1) / a.scatterTiles; // scatter_tile_draws, before rounding
+	const dim3 sgrid(a.scatterTiles);
+	if (task)
+	{
+		if (t <= DC_THREADS)
+			hipLaunchKernelGGL((draw_scatter_kernel<true, MESH_LDS, 1>), sgrid, block, 0, stream, a);
+		else if (t <= DC_THREADS * 4)
+			hipLaunchKernelGGL((draw_scatter_kernel<true, MESH_LDS, 4>), sgrid, block, 0, stream, a);
+		else
+			hipLaunchKernelGGL((draw_scatter_kernel<true, MESH_LDS, 16>), sgrid, block, 0, stream, a);
+	}
+	else
+	{
+		if (t <= DC_THREADS)
+			hipLaunchKernelGGL((draw_scatter_kernel<false, MESH_LDS, 1>), sgrid, block, 0, stream, a);
+		else if (t <= DC_THREADS * 4)
+			hipLaunchKernelGGL((draw_scatter_kernel<false, MESH_LDS, 4>), sgrid, block, 0, stream, a);
+		else
+			hipLaunchKernelGGL((draw_scatter_kernel<false, MESH_LDS, 16>), sgrid, block, 0, stream, a);
 	}
 }
 
-int launch_drawcull(hipStream_t stream, const DrawArgs& a, int late, int task, uint32_t gridBlocks)
+int launch_drawcull(hipStream_t stream, const DrawArgs& a, int late, int task)
 {
+	const uint32_t decideBlocks = (a.cd.drawCount + DC_TILE - 1) / DC_TILE;
 	if (a.meshCount && a.meshCount <= DC_MESH_LDS)
-		launch_dc<true>(stream, a, late, task, gridBlocks);
+		launch_dc<true>(stream, a, late, task, decideBlocks ? decideBlocks : 1u);
 	else
-		launch_dc<false>(stream, a, late, task, gridBlocks);
+		launch_dc<false>(stream, a, late, task, decideBlocks ? decideBlocks : 1u);
 	return (int)hipGetLastError();
 }
 
-uint32_t drawcull_max_tiles(uint32_t drawCount, uint32_t gridBlocks)
-{
-	uint32_t byCap = (drawCount + DC_TMAX - 1) / DC_TMAX;
-	return (byCap > gridBlocks ? byCap : gridBlocks) + 1;
-}
+// bytes of the per-draw result scratch (padded so that the scatter kernel's 16-B loads stay in range)
+size_t drawcull_result_bytes(uint32_t drawCount) { return (size_t)drawCount + 64; }
 
 } // namespace nv
