@@ -106,16 +106,29 @@ NV_DEV void lane_sphere(const NvCullData& cd, const DrawUniform& u, const LaneDa
 	r = half_bits_to_float(l.b1 >> 16) * u.scale;
 }
 
+// int8 / 127.0 exactly as IEEE division rounds it, in 3 instructions instead of the ~10 of a full-range fp32 division:
+// q = k * c with c = RN(1/127), one residual correction q' = fma(fma(-127, q, k), c, q).  Verified against the division
+// for all 256 inputs (tests/test_host_helpers.py::test_s8_over_127_is_exact does the same arithmetic in exact rationals;
+// the GPU parity tests exercise every int8 value through the cone axes).
+NV_DEV float s8_over_127(uint32_t byte)
+{
+	const float k = (float)(int)(int8_t)byte;
+	const float c = 0.00787401571869850158691406250f; // 0x3c010204
+	const float q = k * c;
+	const float r = __builtin_fmaf(-127.0f, q, k);
+	return __builtin_fmaf(r, c, q);
+}
+
 // clustercull.comp.glsl:78-80: cone axis / cutoff
 NV_DEV void lane_cone(const NvCullData& cd, const DrawUniform& u, const LaneData& l, f3& axis, float& cutoff)
 {
 	f3 la;
-	la.x = (float)(int)(int8_t)(l.cone & 0xffu) / 127.0f;
-	la.y = (float)(int)(int8_t)((l.cone >> 8) & 0xffu) / 127.0f;
-	la.z = (float)(int)(int8_t)((l.cone >> 16) & 0xffu) / 127.0f;
+	la.x = s8_over_127(l.cone & 0xffu);
+	la.y = s8_over_127((l.cone >> 8) & 0xffu);
+	la.z = s8_over_127((l.cone >> 16) & 0xffu);
 	f3 ra = rotate_quat(la, u.q, u.qw);
 	axis = view_dir(cd.view, ra);
-	cutoff = (float)(int)(int8_t)(l.cone >> 24) / 127.0f;
+	cutoff = s8_over_127(l.cone >> 24);
 }
 
 // Visibility-bit update of one command (clustercull.comp.glsl:125-131): lanes in setAll become 1, lanes in clrAll become 0.
@@ -803,7 +816,8 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 							cur.cone = ring[k].cone;
 							cur.mvbWord = ring[k].mvbWord;
 							uint64_t vis = 0;
-							m = cull_command<LATE, BITS>(a, cmd, du, cur, lane, &vis);
+							if (!(a.debugMode & 4096u)) // bit 12 (experiments): exact pass loads only
+								m = cull_command<LATE, BITS>(a, cmd, du, cur, lane, &vis);
 							maskLo = writelane_u32(maskLo, (uint32_t)m, c);
 							maskHi = writelane_u32(maskHi, (uint32_t)(m >> 32), c);
 							if (updateBits)

@@ -131,15 +131,47 @@ NV_DEV uint32_t scatter_tile_draws(uint32_t drawCount, uint32_t tiles)
 	return t < 64u ? 64u : (t + 63u) / 64u * 64u;
 }
 
+// The Mesh table (center/radius, LOD errors, LOD ranges) is read by every draw: staged in LDS once per workgroup when
+// nv_upload_meshes registered a table of at most DC_MESH_LDS meshes, otherwise gathered from global memory.
+// Two halves, because s_waitcnt vmcnt counts in issue order: the table's loads are ISSUED before the workgroup's draw
+// records and committed to LDS after them, so that waiting for the table does not wait for the records.
+constexpr uint32_t DC_STAGE_WORDS = (DC_MESH_LDS * sizeof(NvMesh) / 4 + DC_THREADS - 1) / DC_THREADS;
+struct MeshStage
+{
+	uint32_t w[DC_STAGE_WORDS];
+};
+
 template <bool MESH_LDS>
-NV_DEV const char* stage_mesh_table(const DrawArgs& a, uint32_t* s_meshTable)
+NV_DEV MeshStage stage_mesh_issue(const DrawArgs& a)
+{
+	MeshStage st;
+	if (MESH_LDS)
+	{
+		const uint32_t words = a.meshCount * (uint32_t)(sizeof(NvMesh) / 4);
+		const uint32_t* src = reinterpret_cast<const uint32_t*>(a.meshes);
+#pragma unroll
+		for (uint32_t k = 0; k < DC_STAGE_WORDS; ++k)
+		{
+			const uint32_t i = k * DC_THREADS + threadIdx.x;
+			st.w[k] = src[i < words ? i : 0u]; // clamped: unconditional loads
+		}
+	}
+	return st;
+}
+
+template <bool MESH_LDS>
+NV_DEV const char* stage_mesh_commit(const DrawArgs& a, const MeshStage& st, uint32_t* s_meshTable)
 {
 	if (!MESH_LDS)
 		return reinterpret_cast<const char*>(a.meshes);
 	const uint32_t words = a.meshCount * (uint32_t)(sizeof(NvMesh) / 4);
-	const uint32_t* src = reinterpret_cast<const uint32_t*>(a.meshes);
-	for (uint32_t i = threadIdx.x; i < words; i += DC_THREADS)
-		s_meshTable[i] = src[i];
+#pragma unroll
+	for (uint32_t k = 0; k < DC_STAGE_WORDS; ++k)
+	{
+		const uint32_t i = k * DC_THREADS + threadIdx.x;
+		if (i < words)
+			s_meshTable[i] = st.w[k];
+	}
 	__syncthreads();
 	return reinterpret_cast<const char*>(s_meshTable);
 }
@@ -168,7 +200,8 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 	const uint32_t n = drawCount - first < DC_TILE ? drawCount - first : DC_TILE;
 
 	// Indices past the tile are clamped, not branched, so that the loads are unconditional and the compiler can count
-	// them (s_waitcnt vmcnt(N)) instead of draining after each one; they are issued ahead of the mesh-table staging.
+	// them (s_waitcnt vmcnt(N)) instead of draining after each one.
+	const MeshStage st = stage_mesh_issue<MESH_LDS>(a);
 	DrawLoad ld[DC_BATCH];
 #pragma unroll
 	for (int j = 0; j < DC_BATCH; ++j)
@@ -176,7 +209,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 		const uint32_t c = j * DC_THREADS + tid;
 		ld[j] = load_draw_record(a, first + (c < n ? c : n - 1));
 	}
-	const char* meshBase = stage_mesh_table<MESH_LDS>(a, s_meshTable);
+	const char* meshBase = stage_mesh_commit<MESH_LDS>(a, st, s_meshTable);
 
 	// per wave-batch command counts -> LDS; merged per scatter tile below
 	__shared__ uint32_t s_waveCount[DC_BATCH * DC_WAVES];
@@ -297,7 +330,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 	if (tile >= numTiles)
 		return;
 
-	const char* meshBase = stage_mesh_table<MESH_LDS>(a, s_meshTable);
+	const char* meshBase = stage_mesh_commit<MESH_LDS>(a, stage_mesh_issue<MESH_LDS>(a), s_meshTable);
 
 	uint32_t before = 0, all = 0;
 #pragma unroll

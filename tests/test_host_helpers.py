@@ -52,3 +52,25 @@ def test_count4_for_matches_tasksubmit():
         c4 = np.array([n, 0, 0, 0], np.uint32)
         oracle.tasksubmit(c4, np.zeros(min(n, L.TASK_WGLIMIT) + 64, dtype=L.TASKCMD))
         assert (synth.count4_for(n) == c4).all()
+
+
+def test_s8_over_127_is_exact():
+    """The HIP cone unpack replaces int8 / 127.0f by  q = k*c,  q' = fma(fma(-127, q, k), c, q)  (clustercull.hip
+    s8_over_127).  Exact-rational re-evaluation: the result equals the correctly rounded quotient for all 256 inputs,
+    i.e. what the reference's division (clustercull.comp.glsl:78-80) produces."""
+    from fractions import Fraction
+
+    def rn(fr):
+        f32 = np.float32(float(fr))
+        cands = [np.nextafter(f32, np.float32(-np.inf)), f32, np.nextafter(f32, np.float32(np.inf))]
+        return np.float32(min(cands, key=lambda c: (abs(Fraction(float(c)) - fr), int(np.float32(c).view(np.uint32)) & 1)))
+
+    c = np.float32(0.00787401571869850158691406250)
+    assert c.view(np.uint32) == 0x3c010204 and c == rn(Fraction(1, 127))
+    fc = Fraction(float(c))
+    for k in range(-128, 128):
+        q = rn(Fraction(k) * fc)
+        r = rn(Fraction(k) - 127 * Fraction(float(q)))
+        q2 = rn(Fraction(float(q)) + Fraction(float(r)) * fc)
+        assert q2 == np.float32(k) / np.float32(127.0), k
+        assert q2 == rn(Fraction(k, 127)), k
