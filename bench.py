@@ -150,6 +150,8 @@ def main():
     algo_bytes = n_meshlets * per_meshlet + n_cmd * 68 + n_cmd * 8
     achieved = algo_bytes / kernel_avg_s / 1e9
 
+    traffic, traffic_note = pmc_traffic(n_meshlets, args)
+
     if rank == 0:
         out = {
             "metric": "meshlets culled+compacted /sec",
@@ -170,7 +172,7 @@ def main():
                        "input_copies_rotated": copies, "count_reset": "explicit launch" if args.explicit_reset else "fused (NV_OPT_FUSED_COUNT_RESET)", "meshlet_layout": "AoS24" if args.aos else "SoA12",
                        "visible_per_gpu": visible, "visible_total": total_visible, "sharding": "commands x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "cluster_mask_kernel", "kernel_avg_us": kernel_avg_s * 1e6,
+                         "traffic": traffic, "traffic_source": traffic_note, "kernel": "cluster_mask_kernel", "kernel_avg_us": kernel_avg_s * 1e6,
                          "algorithmic_bytes": algo_bytes, "launches_timed": cull_n,
                          "scatter_kernel_avg_us": scatter_avg_s * 1e6, "ms_per_step_with_events": profiled / args.steps * 1e3,
                          "pass_algorithmic_bytes": pass_bytes,
@@ -183,6 +185,22 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(n_meshlets, args):
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the process being timed:
+    they come from separate `rocprofv3 --pmc` passes over this same command (tools/pmc_traffic.sh), whose per-launch
+    means are committed as profiles/r01_pmc_traffic.json with the guide's gfx950 corrections already applied.  Used only
+    when the committed measurement is for this workload; otherwise null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        if rec.get("meshlets_per_gpu") == n_meshlets and rec.get("meshlet_layout") == ("AoS24" if args.aos else "SoA12"):
+            return rec["cluster_mask_kernel"]["traffic_bytes"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE x2 per the gfx950 calibration)"
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
 
 
 def cpu_baseline(args, cd, draws, meshlets, n_cmd, gpu_visible):

@@ -502,9 +502,17 @@ NV_DEV DrawUniform segment_draw(const SegmentRegs& r, uint32_t c)
 //   * a slot's registers are touched by nothing but its issue / wait statements until the wait has passed;
 //   * slots are reissued in a fixed rotation with unconditional loads (indices clamped, never branched), so exactly
 //     (CC_D - 1) * LOADS younger ring loads are outstanding at every wait;
-//   * VMEM operations hipcc issues itself in between (HiZ texels, visibility-bit atomics) are younger than the slot
-//     being waited for and are consumed before the next ring issue (the issue statement takes the command's ballot as
-//     an operand), so they can only make a wait stricter, never too weak.
+//   * VMEM operations hipcc issues itself in between (HiZ texels) are younger than the slot being waited for and are
+//     consumed before the next ring issue (the issue statement takes the command's ballot as an operand), so they can
+//     only make a wait stricter, never too weak.  Stricter is slower, though: a store issued inside a ring lengthens
+//     every counted wait behind it by its own latency, so ballots, tile counts and visibility-bit updates are written
+//     per segment, after the rings have drained;
+//   * each slot has exactly ONE issue site and ONE wait site in the loop body.  With a second copy of the loop (a fast
+//     path next to a general path) hipcc joins the slots' registers at the merge point with v_mov — copying registers
+//     whose loads are still in flight (observed: memory faults from garbage addresses);
+//   * the hazard recognizer does not look inside inline asm: an SGPR written by v_readlane needs s_nop 1 before an
+//     asm VALU instruction reads it (pin_vgpr), and SGPR operands of the asm loads must not be produced by VALU right
+//     before them (they are kernel arguments here).
 // ring A (filter pass): the 8 bounds bytes per meshlet (+ the visibility word when BITS)
 struct SlotA
 {

@@ -25,6 +25,34 @@ for d in sorted(glob.glob("$out/pmc*")):
             for c, v in cs.items():
                 res[short][c] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
 json.dump(res, open("$out/traffic_raw.json", "w"), indent=1)
+# summary with the gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE
+# tallies the 128-B read requests of wide coalesced loads at 64 B -> x2.  Calibrated in this very run on soa_split_kernel,
+# whose byte counts are known exactly (reads 24 B, writes 12 B per meshlet of the 4 x 10 M-meshlet upload).
+def kern(sub):
+    for k, v in res.items():
+        if sub in k:
+            return v
+    return {}
+def mean(v, c):
+    return v.get(c, {}).get("mean_per_launch")
+summary = {"command": "python bench.py --steps 20 --warmup 3 --no-cpu-baseline", "meshlets_per_gpu": 10000000, "meshlet_layout": "SoA12",
+           "units": "bytes per launch (mean over the profiled launches)"}
+cal = kern("soa_split_kernel")
+if cal:
+    known_read, known_write = 40000000 * 24, 40000000 * 12
+    summary["calibration_soa_split_kernel"] = {"known_read_bytes": known_read, "known_write_bytes": known_write,
+        "FETCH_SIZE_KiB": mean(cal, "FETCH_SIZE"), "WRITE_SIZE_KiB": mean(cal, "WRITE_SIZE"),
+        "read_correction": known_read / (mean(cal, "FETCH_SIZE") * 1024), "write_correction": known_write / (mean(cal, "WRITE_SIZE") * 1024)}
+for name in ("cluster_mask_kernel", "cluster_scatter_kernel"):
+    k = kern(name)
+    if not k:
+        continue
+    f, w = mean(k, "FETCH_SIZE"), mean(k, "WRITE_SIZE")
+    summary[name] = {"FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB_raw": w, "read_bytes": 2 * f * 1024, "write_bytes": w * 1024,
+                     "traffic_bytes": 2 * f * 1024 + w * 1024, "TCC_EA0_RDREQ": mean(k, "TCC_EA0_RDREQ_sum"), "TCC_EA0_WRREQ": mean(k, "TCC_EA0_WRREQ_sum"),
+                     "TCC_HIT": mean(k, "TCC_HIT_sum"), "TCC_MISS": mean(k, "TCC_MISS_sum"), "launches": k.get("FETCH_SIZE", {}).get("launches")}
+json.dump(summary, open("$out/pmc_traffic_summary.json", "w"), indent=1)
+print(json.dumps(summary, indent=1))
 for k, v in res.items():
     print(k, {c: round(x["mean_per_launch"], 1) for c, x in v.items()})
 PY

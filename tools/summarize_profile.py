@@ -18,7 +18,13 @@ lines = ["# %s — rocprofv3 summaries (MI355X, gfx950, ROCm 7.2)" % title, "",
          "runs (one per counter group, never combined with other trace domains),",
          "`rocprofv3 --kernel-trace --pmc <counters> -f csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline`.", "",
          "## kernel stats (kernel-trace)", "", "```"]
-for f in glob.glob(src + "/kt/**/*kernel_stats.csv", recursive=True):
+def newest(pattern):
+    """a directory may hold the files of earlier runs (gpurun merges): keep the most recent one"""
+    fs = glob.glob(pattern, recursive=True)
+    return [max(fs, key=os.path.getmtime)] if fs else []
+
+
+for f in newest(src + "/kt/**/*kernel_stats.csv"):
     lines += [l[:230] for l in open(f).read().strip().split("\n")]
 lines += ["```", "", "## bench.py line of the traced run", "", "```"]
 log = os.path.join(src, "kt.log")
@@ -30,7 +36,7 @@ lines += ["```", "", "## PMC averages per dispatch", "",
 for d in sorted(glob.glob(src + "/pmc*")):
     if not os.path.isdir(d):
         continue
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    for f in newest(d + "/**/*counter_collection.csv"):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for row in csv.DictReader(open(f)):
             acc[row["Kernel_Name"][:70]][row["Counter_Name"]].append(float(row["Counter_Value"]))
