@@ -42,6 +42,9 @@ struct ClusterArgs
 	uint64_t* __restrict__ masks; // scratch: one 64-bit ballot per task command
 	ClusterCounts* __restrict__ tileCounts;
 	uint32_t scatterTiles; // grid of the scatter kernel (<= CC_MAX_SCATTER_TILES)
+	uint32_t generations;  // workgroups of the cull kernel per CU (its grid = generations x CUs)
+	uint32_t dealScale;    // percent of the nominal start-delay compensation of the dealing (tuning; 100)
+	uint32_t* hostHint;    // mapped host word: the cull kernel leaves its command count here for the next launch's tuning
 	uint32_t commandCountOverride; // probe/taskcull: explicit command count (0 = use count4[1]*64)
 	float* __restrict__ probeOut;
 	uint32_t debugMode; // tuning experiments only (NV_DEBUG_MODE); 0 in production

@@ -314,7 +314,13 @@ NV_DEV uint32_t indirect_command_count(const ClusterArgs& a)
 //
 // The ballots cost 8 B per 64 meshlets of extra traffic (1 %), the extra launch boundary ~2 us.
 constexpr uint32_t CC_CHUNK = 4; // consecutive commands per dealt chunk
-constexpr int CC_DA = 8;         // ring slots of the filter pass: CC_DA - 1 commands' bounds in flight behind the one being filtered
+// CC_DA (template parameter of the cull kernel) = ring slots of the filter pass: CC_DA - 1 commands' bounds in flight behind
+// the one being filtered.  8 keep HBM saturated through the segment boundaries of a long stream (100 M meshlets: 198 us
+// vs 208 us with 4) and suit the late pass; for a pass of a few hundred thousand commands — one segment per wave — 4
+// measure 3 us faster (10 M meshlets: 27.8 vs 31 us): the queues stay shorter, so every dependent step of the later
+// workgroups' start-up chains is served sooner.  The host picks per launch from the command count of the PREVIOUS
+// clustercull (the kernel leaves it in a mapped host word; frame coherence; a wrong guess only costs speed).
+constexpr uint32_t CC_SHALLOW_COMMANDS = 500000;
 constexpr int CC_DB = 6;         // ring slots of the exact pass
 
 // ---- conservative frustum filter (exactness-preserving early-out)
@@ -611,22 +617,106 @@ NV_DEV bool __all_quad_same(uint32_t v, uint32_t ref)
 	return (diff >> (lane & ~3u) & 0xfull) == 0;
 }
 
-NV_DEV uint32_t dealt_command(uint32_t w, uint32_t W, uint32_t c)
+// Static work assignment of the cull kernel: chunks of CC_CHUNK commands dealt round-robin over the waves — but not
+// evenly.  The workgroups that share a CU start within a microsecond of each other, yet the SIMD arbitrates
+// oldest-first and the later a workgroup was dispatched, the slower it streams (measured, 10 M meshlets, 6 workgroups
+// per CU, even dealing: the first workgroup of a CU finished after 13 us, the sixth after 18-20 us, and the launch
+// ended with a quarter of the waves running alone).  Generation g (= workgroup index / workgroups per generation;
+// dispatch is round-robin over the CUs — an assumption that only affects speed) therefore takes part in fewer rounds:
+// per-wave commands = mean + mean(delay) - delay[g], the delays in units of the time a command takes to stream.
+// Round r hands one chunk to every wave of the generations that still take part (a prefix of the wave index space,
+// because later generations leave first), so the chunks of a round stay contiguous in memory like in plain round-robin;
+// what is left after the weighted rounds is dealt evenly.
+struct Dealing
 {
-	return ((c / CC_CHUNK) * W + w) * CC_CHUNK + c % CC_CHUNK;
+	uint32_t w, W;          // this wave, all waves
+	uint32_t rounds;        // weighted rounds this wave takes part in (one chunk each)
+	uint32_t roundsOf[6];   // ... per generation (non-increasing)
+	uint32_t genWaves;      // waves per generation
+	uint32_t weightedTotal; // chunks dealt in the weighted rounds
+};
+
+NV_DEV Dealing make_dealing(uint32_t numChunks, uint32_t wave, uint32_t generations, bool weighted, float scale)
+{
+	Dealing d;
+	d.W = gridDim.x * CC_WAVES;
+	d.w = blockIdx.x * CC_WAVES + wave;
+	d.rounds = 0;
+	d.weightedTotal = 0;
+	d.genWaves = d.W;
+#pragma unroll
+	for (int k = 0; k < 6; ++k)
+		d.roundsOf[k] = 0;
+	if (!weighted || generations != 6u || gridDim.x % 6u != 0u)
+		return d;
+	d.genWaves = d.W / 6u;
+	const float delay[6] = { 0.0f, 0.5f, 2.4f, 4.2f, 7.1f, 13.1f }; // commands; mean 4.55
+	const float perWave = (float)numChunks * (float)CC_CHUNK / (float)d.W;
+	if (perWave < 16.0f)
+		return d;
+	const uint32_t g = d.w / d.genWaves;
+#pragma unroll
+	for (uint32_t k = 0; k < 6u; ++k)
+	{
+		const float target = perWave + scale * (4.55f - delay[k]) - (float)CC_CHUNK; // keep one even round for the remainder
+		const uint32_t r = target > 0.0f ? (uint32_t)(target / (float)CC_CHUNK) : 0u;
+		d.roundsOf[k] = r;
+		d.weightedTotal += r * d.genWaves;
+		if (k == g)
+			d.rounds = r;
+	}
+	if (d.weightedTotal > numChunks) // cannot happen (floors of targets that sum to less than the total); stay safe
+	{
+		d.rounds = 0;
+		d.weightedTotal = 0;
+#pragma unroll
+		for (int k = 0; k < 6; ++k)
+			d.roundsOf[k] = 0;
+	}
+	return d;
 }
 
-template <bool LATE, bool SOA, bool BITS>
+NV_DEV uint32_t dealt_chunks(const Dealing& d, uint32_t numChunks)
+{
+	const uint32_t rest = numChunks - d.weightedTotal;
+	return d.rounds + (d.w < rest ? (rest - d.w + d.W - 1) / d.W : 0u);
+}
+
+NV_DEV uint32_t dealt_command(const Dealing& d, uint32_t c)
+{
+	const uint32_t j = c / CC_CHUNK;
+	uint32_t chunk;
+	if (j < d.rounds)
+	{
+		uint32_t before = 0; // chunks of rounds < j = genWaves * sum over generations of min(j, roundsOf)
+#pragma unroll
+		for (int k = 0; k < 6; ++k)
+			before += j < d.roundsOf[k] ? j : d.roundsOf[k];
+		chunk = before * d.genWaves + d.w;
+	}
+	else
+		chunk = d.weightedTotal + d.w + (j - d.rounds) * d.W;
+	return chunk * CC_CHUNK + c % CC_CHUNK;
+}
+
+template <bool LATE, bool SOA, bool BITS, int CC_DA>
 __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const uint32_t W = gridDim.x * CC_WAVES;
 	const uint32_t w = blockIdx.x * CC_WAVES + wave;
 
+	// the start-up chain (count -> commands -> draws / first bounds) is latency-critical and a few dozen instructions
+	// long: it must not queue behind the older waves' filter arithmetic (measured: without this the sixth workgroup of
+	// a CU got its first data 11 k cycles after the first one)
+	__builtin_amdgcn_s_setprio(3);
+	const uint32_t gen = blockIdx.x / (gridDim.x / 6u ? gridDim.x / 6u : 1u);
 	const uint32_t numCmds = indirect_command_count(a);
+	if (a.hostHint && blockIdx.x == 0 && threadIdx.x == 0)
+		__hip_atomic_store(a.hostHint, numCmds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	const uint32_t numChunks = (numCmds + CC_CHUNK - 1) / CC_CHUNK;
-	const uint32_t myChunks = w < numChunks ? (numChunks - w + W - 1) / W : 0u;
+	const Dealing deal = make_dealing(numChunks, wave, a.generations, !(a.debugMode & 32768u), (float)a.dealScale * 0.01f); // bit 15 (experiments): even dealing
+	const uint32_t myChunks = dealt_chunks(deal, numChunks);
 	const uint32_t myCmds = myChunks * CC_CHUNK; // the last chunk of the pass may run past numCmds: guarded below
 	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles);
 	const uint32_t bank = __hip_atomic_load(&a.tileCounts->parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
@@ -638,13 +728,29 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 	unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.probeOut) + (size_t)w * 8;
 #define NV_STAMP(i) do { if (dbgTime && lane == 0) stamps[i] = __builtin_readcyclecounter(); } while (0)
 	NV_STAMP(0);
+	if (dbgTime && lane == 0)
+		stamps[6] = wall_clock64(); // 100 MHz, chip-wide: comparable across CUs (the cycle counter is not)
+
+	// Warm this XCD's L2 with the MeshDraw array before the meshlet stream floods the memory queues, so that the draw
+	// gathers below are L2 hits.  Each workgroup touches one slice, one dword per 128-byte line; workgroup -> XCD is
+	// assumed round-robin (speed only).  cd.drawCount bounds the array by contract.
+	uint32_t warm = 0;
+	if (SOA && !(a.debugMode & 16384u)) // bit 14 (experiments): no warm-up
+	{
+		const uint32_t perXcd = gridDim.x / 8u ? gridDim.x / 8u : 1u;
+		const uint32_t lines = (a.cd.drawCount * (uint32_t)sizeof(NvMeshDraw) + 127u) / 128u;
+		const uint32_t perGroup = (lines + perXcd - 1u) / perXcd;
+		const uint32_t line = (blockIdx.x / 8u) % perXcd * perGroup + threadIdx.x;
+		const char* wp = reinterpret_cast<const char*>(a.draws) + (size_t)(threadIdx.x < perGroup && line < lines ? line : 0u) * 128u;
+		asm volatile("global_load_dword %0, %1, off" : "=&v"(warm) : "v"(wp) : "memory");
+	}
 
 	for (uint32_t seg = 0; seg < myCmds; seg += 64)
 	{
 		const uint32_t cnt = myCmds - seg < 64u ? myCmds - seg : 64u;
 
 		// lane l holds the wave's (seg + l)-th command and (below) the MeshDraw it points at
-		const uint32_t myIdx = dealt_command(w, W, seg + lane);
+		const uint32_t myIdx = dealt_command(deal, seg + lane);
 		SegmentRegs r = {};
 		if (lane < cnt && myIdx < numCmds)
 		{
@@ -733,17 +839,18 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 #pragma unroll
 				for (int k = 0; k < CC_DA; ++k)
 					issueA(ring[k], (uint32_t)k < cnt ? k : cnt - 1, 0); // clamped: redundant but unconditional loads
-				asm volatile("s_waitcnt vmcnt(%2)" : "+v"(g0), "+v"(g1) : "i"(CC_DA * (BITS_A ? 2 : 1)) : "memory"); // the gather
+				asm volatile("s_waitcnt vmcnt(%3)" : "+v"(g0), "+v"(g1), "+v"(warm) : "i"(CC_DA * (BITS_A ? 2 : 1)) : "memory"); // the gather (and the warm-up load before it)
 				gather_finish();
 				NV_STAMP(2);
 				for (uint32_t i = 0; i < cnt; i += CC_DA)
 				{
 					// The SIMD arbitrates oldest-first, which lets the oldest resident workgroup run ahead and leaves
-					// the youngest to finish alone at single-wave issue rate.  Rotating the priority with the
-					// workgroup index evens the progress of the waves that share a SIMD (speed only).
+					// the youngest to finish alone at single-wave issue rate.  Rotating the priority, offset by the
+					// workgroup's generation so that the workgroups sharing a CU hold different levels at any time,
+					// evens the progress of the waves that share a SIMD (speed only).
 					if (!(a.debugMode & 256u)) // bit 8 (experiments) turns the rotation off
 					{
-						switch ((blockIdx.x + i / CC_DA) & 3u)
+						switch ((gen + i / CC_DA) & 3u)
 						{
 						case 0: __builtin_amdgcn_s_setprio(0); break;
 						case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -923,6 +1030,8 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 		}
 	}
 	NV_STAMP(5);
+	if (dbgTime && lane == 0)
+		stamps[7] = wall_clock64();
 #undef NV_STAMP
 }
 
@@ -1191,35 +1300,39 @@ __global__ __launch_bounds__(256) void soa_split_kernel(const NvMeshlet* __restr
 // ---------------------------------------------------------------------------------------------------------------
 // launchers (called from context.hip)
 
-template <bool LATE, bool SOA>
+template <bool LATE, bool SOA, int DEPTH>
 static void launch_cc(hipStream_t stream, const ClusterArgs& a, uint32_t gridBlocks)
 {
 	dim3 grid(gridBlocks), block(CC_THREADS);
 	if (a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0)
-		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, true>), grid, block, 0, stream, a);
+		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, true, DEPTH>), grid, block, 0, stream, a);
 	else
-		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, false>), grid, block, 0, stream, a);
+		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, false, DEPTH>), grid, block, 0, stream, a);
 }
 
-// any grid size (pure map)
-int launch_cluster_mask(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t maskBlocks)
+// any grid size (pure map); shallow = use the 4-deep filter ring (early pass over the SoA mirror only)
+int launch_cluster_mask(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t maskBlocks, bool shallow)
 {
 	if (late)
 	{
 		if (soa)
-			launch_cc<true, true>(stream, a, maskBlocks);
+			launch_cc<true, true, 8>(stream, a, maskBlocks);
 		else
-			launch_cc<true, false>(stream, a, maskBlocks);
+			launch_cc<true, false, 8>(stream, a, maskBlocks);
 	}
 	else
 	{
-		if (soa)
-			launch_cc<false, true>(stream, a, maskBlocks);
+		if (soa && shallow)
+			launch_cc<false, true, 4>(stream, a, maskBlocks);
+		else if (soa)
+			launch_cc<false, true, 8>(stream, a, maskBlocks);
 		else
-			launch_cc<false, false>(stream, a, maskBlocks);
+			launch_cc<false, false, 8>(stream, a, maskBlocks);
 	}
 	return (int)hipGetLastError();
 }
+
+bool clustercull_prefers_shallow(uint32_t previousCommandCount) { return previousCommandCount != 0 && previousCommandCount <= CC_SHALLOW_COMMANDS; }
 
 // scatterBlocks workgroups wait on each other: the grid must be co-resident (context.hip launches one per CU)
 int launch_cluster_scatter(hipStream_t stream, const ClusterArgs& a, uint32_t scatterBlocks)

@@ -17,7 +17,8 @@
 namespace nv
 {
 
-int launch_cluster_mask(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t maskBlocks);
+int launch_cluster_mask(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t maskBlocks, bool shallow);
+bool clustercull_prefers_shallow(uint32_t previousCommandCount);
 int launch_cluster_scatter(hipStream_t, const ClusterArgs&, uint32_t scatterBlocks);
 size_t clustercull_mask_bytes();
 int launch_taskcull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t gridBlocks);
@@ -63,6 +64,10 @@ struct nv_context
 	// tuning knobs (environment, read once in nv_create): NV_DEBUG_MODE bit mask, NV_CC_BLOCKS_PER_CU
 	uint32_t debugMode;
 	uint32_t ccBlocksPerCU;
+	uint32_t dealScale;
+	// command count of the previous clustercull launch, written by its kernel into mapped host memory (tuning hint)
+	volatile uint32_t* hintHost;
+	uint32_t* hintDevice;
 	uint32_t fusedReset;
 	// nv_profile_*: event pairs recorded on the launch stream, drained by nv_profile_read
 	int profiling;
@@ -125,6 +130,8 @@ int ensure_draw_results(nv_context* ctx, uint32_t drawCount)
 	hipError_t e = hipDeviceSynchronize();
 	if (e != hipSuccess)
 		return (int)e;
+	if (ctx->hintHost)
+		(void)hipHostFree(const_cast<uint32_t*>(ctx->hintHost));
 	if (ctx->drawResults)
 		(void)hipFree(ctx->drawResults);
 	ctx->drawResults = nullptr;
@@ -184,6 +191,9 @@ int nv_create(nv_context** out_ctx, int device)
 	ctx->ccBlocksPerCU = 6;
 	if (const char* v = getenv("NV_DEBUG_MODE"))
 		ctx->debugMode = (uint32_t)atoi(v);
+	ctx->dealScale = 100;
+	if (const char* v = getenv("NV_DEAL_SCALE"))
+		ctx->dealScale = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_CC_BLOCKS_PER_CU"))
 		ctx->ccBlocksPerCU = (uint32_t)atoi(v) ? (uint32_t)atoi(v) : 6;
 
@@ -195,6 +205,23 @@ int nv_create(nv_context** out_ctx, int device)
 		nv_destroy(ctx);
 		return NV_ENOMEM;
 	}
+	// optional: without it the kernels simply keep the deep ring
+	{
+		void* h = nullptr;
+		if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess)
+		{
+			memset(h, 0, 64);
+			void* d = nullptr;
+			if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess)
+			{
+				ctx->hintHost = static_cast<volatile uint32_t*>(h);
+				ctx->hintDevice = static_cast<uint32_t*>(d);
+			}
+			else
+				(void)hipHostFree(h);
+		}
+	}
+
 	*out_ctx = ctx;
 	return NV_OK;
 }
@@ -204,6 +231,8 @@ void nv_destroy(nv_context* ctx)
 	if (!ctx)
 		return;
 	DeviceGuard guard(ctx->device);
+	if (ctx->hintHost)
+		(void)hipHostFree(const_cast<uint32_t*>(ctx->hintHost));
 	if (ctx->drawResults)
 		(void)hipFree(ctx->drawResults);
 	if (ctx->drawTileCounts)
@@ -421,6 +450,9 @@ static int fill_cluster_args(nv_context* ctx, nv::ClusterArgs& a, const NvCullDa
 	a.masks = ctx->masks;
 	a.tileCounts = ctx->tileCounts;
 	a.scatterTiles = scatter_grid(ctx);
+	a.generations = ctx->ccBlocksPerCU;
+	a.dealScale = ctx->dealScale;
+	a.hostHint = ctx->hintDevice;
 	return NV_OK;
 }
 
@@ -449,7 +481,8 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	// two pure maps: the cull kernel also accumulates survivors per scatter tile, so no workgroup waits on another
 	hipStream_t s = (hipStream_t)stream;
 	hipEvent_t e0 = prof_mark(ctx, s);
-	rc = nv::launch_cluster_mask(s, a, late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU));
+	const bool shallow = ctx->hintHost && nv::clustercull_prefers_shallow(*ctx->hintHost) && !(ctx->debugMode & 65536u); // bit 16 (experiments): always deep
+	rc = nv::launch_cluster_mask(s, a, late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), shallow);
 	hipEvent_t e1 = prof_mark(ctx, s);
 	if (rc == 0 && !(ctx->debugMode & 16u)) // bit 4 (experiments): ballots only
 		rc = nv::launch_cluster_scatter(s, a, a.scatterTiles);

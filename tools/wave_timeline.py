@@ -76,3 +76,44 @@ for name, idx in (("fastest 10%", order[:len(order) // 10]), ("middle 10%", orde
     print("%-12s total %6d = " % (name, tot[idx].mean()) + "  ".join("%s %6d" % (nm.split()[0] + nm.split()[1][:1] if " " in nm else nm, d[idx, i].mean()) for i, nm in enumerate(names[1:])))
 # per-workgroup: when does the workgroup's last wave end relative to its first entry, vs the mean over its waves
 print("workgroups: span p50 %d p90 %d p100 %d" % tuple(np.percentile(span, [50, 90, 100])))
+
+# spread of the pass-A end within a workgroup (what a workgroup-level pooling of the exact pass would wait for), and the
+# exact-pass time summed per workgroup vs the longest single wave
+a_end = blk[:, :, 3]
+print("pass-A end spread within a workgroup (max - min): p50 %d p90 %d p100 %d" % tuple(np.percentile(a_end.max(axis=1) - a_end.min(axis=1), [50, 90, 100])))
+pb = (blk[:, :, 4] - blk[:, :, 3])
+print("exact pass per workgroup: longest wave p50 %d p90 %d p99 %d p100 %d | mean over its 4 waves p50 %d p90 %d p99 %d p100 %d" %
+      (tuple(np.percentile(pb.max(axis=1), [50, 90, 99, 100])) + tuple(np.percentile(pb.mean(axis=1), [50, 90, 99, 100]))))
+end_w = blk[:, :, 5].max(axis=1) - blk[:, :, 0].min(axis=1)
+ideal = (a_end.max(axis=1) - blk[:, :, 0].min(axis=1)) + pb.mean(axis=1)
+print("workgroup lifetime now p50 %d p90 %d p99 %d p100 %d | pooled estimate p50 %d p90 %d p99 %d p100 %d" %
+      (tuple(np.percentile(end_w, [50, 90, 99, 100])) + tuple(np.percentile(ideal, [50, 90, 99, 100]))))
+
+# chip-wide 100 MHz clock (stamps 6, 7): launch ramp and finish order across the whole grid, in microseconds
+rt0 = t[:, 6].min()
+entry_us = (t[:, 6] - rt0) / 100.0
+end_us = (t[:, 7] - rt0) / 100.0
+print("wave entry  (us after the first wave): p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f" % tuple(np.percentile(entry_us, [10, 50, 90, 99, 100])))
+print("wave end    (us after the first wave): p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f" % tuple(np.percentile(end_us, [10, 50, 90, 99, 100])))
+life = end_us - entry_us
+print("wave lifetime (us): p10 %.2f p50 %.2f p90 %.2f max %.2f ; corr(entry, lifetime) = %.2f" % (tuple(np.percentile(life, [10, 50, 90, 100])) + (np.corrcoef(entry_us, life)[0, 1],)))
+late = np.argsort(end_us)[-60:]
+print("last 1%% of waves to finish: entry %.2f lifetime %.2f exact-pass cycles %d (all waves: %.2f %.2f %d)" %
+      (entry_us[late].mean(), life[late].mean(), d[late, 3].mean(), entry_us.mean(), life.mean(), d[:, 3].mean()))
+
+# is the finish time systematic? by XCD (workgroup index mod 8, the usual round-robin) and by dispatch order
+bidx = np.arange(waves) // 4
+for x in range(8):
+    sel = (bidx % 8) == x
+    print("xcd~%d: end p50 %.2f p90 %.2f max %.2f | lifetime p50 %.2f | exact-pass cycles mean %d" %
+          (x, np.percentile(end_us[sel], 50), np.percentile(end_us[sel], 90), end_us[sel].max(), np.percentile(life[sel], 50), d[sel, 3].mean()))
+q = np.argsort(bidx)
+for lo in range(0, 1536, 256):
+    sel = (bidx >= lo) & (bidx < lo + 256)
+    print("workgroups %4d..%4d: entry p50 %.2f end p50 %.2f p90 %.2f max %.2f" % (lo, lo + 255, np.percentile(entry_us[sel], 50), np.percentile(end_us[sel], 50), np.percentile(end_us[sel], 90), end_us[sel].max()))
+nocand = d[:, 3] < 400
+print("waves without exact-pass work: %d, end p50 %.2f p90 %.2f p99 %.2f max %.2f" % ((nocand.sum(),) + tuple(np.percentile(end_us[nocand], [50, 90, 99, 100]))))
+print("waves with exact-pass work:    %d, end p50 %.2f p90 %.2f p99 %.2f max %.2f" % (((~nocand).sum(),) + tuple(np.percentile(end_us[~nocand], [50, 90, 99, 100]))))
+for lo in range(0, 1536, 256):
+    sel = (bidx >= lo) & (bidx < lo + 256)
+    print("workgroups %4d..%4d phases (median cycles): " % (lo, lo + 255) + "  ".join("%s %6d" % (nm[:12], np.median(d[sel, i])) for i, nm in enumerate(names[1:])) + "  | lifetime us %.2f" % np.median(life[sel]))
