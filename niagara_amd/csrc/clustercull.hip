@@ -517,8 +517,10 @@ NV_DEV DrawUniform segment_draw(const SegmentRegs& r, uint32_t c)
 //     path next to a general path) hipcc joins the slots' registers at the merge point with v_mov — copying registers
 //     whose loads are still in flight (observed: memory faults from garbage addresses);
 //   * the hazard recognizer does not look inside inline asm: an SGPR written by v_readlane needs s_nop 1 before an
-//     asm VALU instruction reads it (pin_vgpr), and SGPR operands of the asm loads must not be produced by VALU right
-//     before them (they are kernel arguments here).
+//     asm VALU instruction reads it (pin_vgpr), and 5 wait states before an asm VMEM instruction reads it — which
+//     happens even to kernel arguments: under SGPR pressure hipcc spills the base pointers to VGPR lanes and reloads
+//     them with v_readlane directly in front of the asm statement (observed: memory faults from a stale base).  Every
+//     asm load that takes an SGPR base therefore starts with s_nop 4.
 // ring A (filter pass): the 8 bounds bytes per meshlet (+ the visibility word when BITS)
 struct SlotA
 {
@@ -545,14 +547,14 @@ NV_DEV void ringA_issue(SlotA& s, const ClusterArgs& a, uint32_t off8, uint32_t 
 {
 	if (BITS)
 	{
-		asm volatile("global_load_dwordx2 %0, %2, %3\n\tglobal_load_dword %1, %4, %5"
+		asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %2, %3\n\tglobal_load_dword %1, %4, %5"
 		             : "=&v"(s.bounds), "=&v"(s.mvbWord)
 		             : "v"(off8), "s"(a.soaBounds), "v"(offw), "s"(a.mvb), "s"(order)
 		             : "memory");
 	}
 	else
 	{
-		asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(s.bounds) : "v"(off8), "s"(a.soaBounds), "s"(order) : "memory");
+		asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(s.bounds) : "v"(off8), "s"(a.soaBounds), "s"(order) : "memory");
 		s.mvbWord = 0;
 	}
 }
@@ -577,14 +579,14 @@ NV_DEV void ringB_issue(SlotB& s, const ClusterArgs& a, uint32_t taskOffset, uin
 	if (BITS)
 	{
 		const uint32_t offw = taskCount ? ((mvo + li) >> 5) * 4u : 0u;
-		asm volatile("global_load_dwordx2 %0, %3, %4\n\tglobal_load_dword %1, %5, %6\n\tglobal_load_dword %2, %7, %8"
+		asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %3, %4\n\tglobal_load_dword %1, %5, %6\n\tglobal_load_dword %2, %7, %8"
 		             : "=&v"(s.bounds), "=&v"(s.cone), "=&v"(s.mvbWord)
 		             : "v"(off8), "s"(a.soaBounds), "v"(off4), "s"(a.soaCones), "v"(offw), "s"(a.mvb), "s"(order)
 		             : "memory");
 	}
 	else
 	{
-		asm volatile("global_load_dwordx2 %0, %2, %3\n\tglobal_load_dword %1, %4, %5"
+		asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %2, %3\n\tglobal_load_dword %1, %4, %5"
 		             : "=&v"(s.bounds), "=&v"(s.cone)
 		             : "v"(off8), "s"(a.soaBounds), "v"(off4), "s"(a.soaCones), "s"(order)
 		             : "memory");
@@ -627,76 +629,51 @@ NV_DEV bool __all_quad_same(uint32_t v, uint32_t ref)
 // Round r hands one chunk to every wave of the generations that still take part (a prefix of the wave index space,
 // because later generations leave first), so the chunks of a round stay contiguous in memory like in plain round-robin;
 // what is left after the weighted rounds is dealt evenly.
-struct Dealing
+// The weighted rounds of a wave are computed ONCE, lane-parallel (lane j = the wave's j-th chunk), and kept in one VGPR;
+// keeping the parameters live as scalars instead cost the late-pass variants 30 VGPRs of spill code and with them two
+// of the six resident workgroups per CU.  Returns the number of chunks of this wave; *chunkOf = index of its lane-th
+// chunk, or the plain round-robin when the pass is not weighted (other grid shapes, tiny passes, or more than 64
+// chunks per wave — where a start-up delay of a few commands no longer matters).
+NV_DEV uint32_t make_dealing(uint32_t numChunks, uint32_t wave, uint32_t lane, uint32_t generations, uint32_t gen, bool weighted, uint32_t scalePercent,
+                             uint32_t* chunkOf, bool* isWeighted)
 {
-	uint32_t w, W;          // this wave, all waves
-	uint32_t rounds;        // weighted rounds this wave takes part in (one chunk each)
-	uint32_t roundsOf[6];   // ... per generation (non-increasing)
-	uint32_t genWaves;      // waves per generation
-	uint32_t weightedTotal; // chunks dealt in the weighted rounds
-};
-
-NV_DEV Dealing make_dealing(uint32_t numChunks, uint32_t wave, uint32_t generations, bool weighted, float scale)
-{
-	Dealing d;
-	d.W = gridDim.x * CC_WAVES;
-	d.w = blockIdx.x * CC_WAVES + wave;
-	d.rounds = 0;
-	d.weightedTotal = 0;
-	d.genWaves = d.W;
+	const uint32_t W = gridDim.x * CC_WAVES;
+	const uint32_t w = blockIdx.x * CC_WAVES + wave;
+	*chunkOf = lane * W + w;
+	*isWeighted = false;
+	const uint32_t perWaveChunks = numChunks / W;
+	const uint32_t even = perWaveChunks + (w < numChunks - perWaveChunks * W ? 1u : 0u);
+	if (!weighted || generations != 6u || gridDim.x % 6u != 0u || perWaveChunks < 4u || perWaveChunks >= 60u)
+		return even;
+	const uint32_t genWaves = W / 6u;
+	// delays in 1/16 command: { 0, 0.5, 2.4, 4.2, 7.1, 13.1 }, mean 4.55
+	const int delay16[6] = { 0, 8, 38, 67, 114, 210 };
+	const int perWave16 = (int)((numChunks * (CC_CHUNK * 16u)) / W); // numChunks < 2^22 / CC_CHUNK: no overflow
+	uint32_t roundsOf[6], weightedTotal = 0;
 #pragma unroll
 	for (int k = 0; k < 6; ++k)
-		d.roundsOf[k] = 0;
-	if (!weighted || generations != 6u || gridDim.x % 6u != 0u)
-		return d;
-	d.genWaves = d.W / 6u;
-	const float delay[6] = { 0.0f, 0.5f, 2.4f, 4.2f, 7.1f, 13.1f }; // commands; mean 4.55
-	const float perWave = (float)numChunks * (float)CC_CHUNK / (float)d.W;
-	if (perWave < 16.0f)
-		return d;
-	const uint32_t g = d.w / d.genWaves;
-#pragma unroll
-	for (uint32_t k = 0; k < 6u; ++k)
 	{
-		const float target = perWave + scale * (4.55f - delay[k]) - (float)CC_CHUNK; // keep one even round for the remainder
-		const uint32_t r = target > 0.0f ? (uint32_t)(target / (float)CC_CHUNK) : 0u;
-		d.roundsOf[k] = r;
-		d.weightedTotal += r * d.genWaves;
-		if (k == g)
-			d.rounds = r;
+		const int target16 = perWave16 + ((int)scalePercent * (73 - delay16[k])) / 100 - (int)(CC_CHUNK * 16u); // keep one even round for the remainder
+		roundsOf[k] = target16 > 0 ? (uint32_t)target16 / (CC_CHUNK * 16u) : 0u;
+		weightedTotal += roundsOf[k] * genWaves;
 	}
-	if (d.weightedTotal > numChunks) // cannot happen (floors of targets that sum to less than the total); stay safe
-	{
-		d.rounds = 0;
-		d.weightedTotal = 0;
+	const uint32_t g = gen < 6u ? gen : 5u;
+	const uint32_t rounds = roundsOf[0] * (g == 0) + roundsOf[1] * (g == 1) + roundsOf[2] * (g == 2) + roundsOf[3] * (g == 3) + roundsOf[4] * (g == 4) + roundsOf[5] * (g == 5);
+	if (weightedTotal > numChunks) // cannot happen (floors of targets that sum to less than the total); stay safe
+		return even;
+	const uint32_t rest = numChunks - weightedTotal;
+	const uint32_t mine = rounds + rest / W + (w < rest % W ? 1u : 0u);
+	if (mine > 64u)
+		return even;
+	// lane j: round j of the weighted part (chunks of earlier rounds = genWaves * sum over generations of min(j, roundsOf)),
+	// then the even remainder
+	uint32_t before = 0;
 #pragma unroll
-		for (int k = 0; k < 6; ++k)
-			d.roundsOf[k] = 0;
-	}
-	return d;
-}
-
-NV_DEV uint32_t dealt_chunks(const Dealing& d, uint32_t numChunks)
-{
-	const uint32_t rest = numChunks - d.weightedTotal;
-	return d.rounds + (d.w < rest ? (rest - d.w + d.W - 1) / d.W : 0u);
-}
-
-NV_DEV uint32_t dealt_command(const Dealing& d, uint32_t c)
-{
-	const uint32_t j = c / CC_CHUNK;
-	uint32_t chunk;
-	if (j < d.rounds)
-	{
-		uint32_t before = 0; // chunks of rounds < j = genWaves * sum over generations of min(j, roundsOf)
-#pragma unroll
-		for (int k = 0; k < 6; ++k)
-			before += j < d.roundsOf[k] ? j : d.roundsOf[k];
-		chunk = before * d.genWaves + d.w;
-	}
-	else
-		chunk = d.weightedTotal + d.w + (j - d.rounds) * d.W;
-	return chunk * CC_CHUNK + c % CC_CHUNK;
+	for (int k = 0; k < 6; ++k)
+		before += lane < roundsOf[k] ? lane : roundsOf[k];
+	*chunkOf = lane < rounds ? before * genWaves + w : weightedTotal + w + (lane - rounds) * W;
+	*isWeighted = true;
+	return mine;
 }
 
 template <bool LATE, bool SOA, bool BITS, int CC_DA>
@@ -709,14 +686,16 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 	// the start-up chain (count -> commands -> draws / first bounds) is latency-critical and a few dozen instructions
 	// long: it must not queue behind the older waves' filter arithmetic (measured: without this the sixth workgroup of
 	// a CU got its first data 11 k cycles after the first one)
-	__builtin_amdgcn_s_setprio(3);
+	if (!(a.debugMode & 262144u)) // bit 18 (experiments)
+		__builtin_amdgcn_s_setprio(3);
 	const uint32_t gen = blockIdx.x / (gridDim.x / 6u ? gridDim.x / 6u : 1u);
 	const uint32_t numCmds = indirect_command_count(a);
 	if (a.hostHint && blockIdx.x == 0 && threadIdx.x == 0)
 		__hip_atomic_store(a.hostHint, numCmds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	const uint32_t numChunks = (numCmds + CC_CHUNK - 1) / CC_CHUNK;
-	const Dealing deal = make_dealing(numChunks, wave, a.generations, !(a.debugMode & 32768u), (float)a.dealScale * 0.01f); // bit 15 (experiments): even dealing
-	const uint32_t myChunks = dealt_chunks(deal, numChunks);
+	uint32_t chunkOf;
+	bool dealtWeighted;
+	const uint32_t myChunks = make_dealing(numChunks, wave, lane, a.generations, gen, !LATE && !(a.debugMode & 32768u), a.dealScale, &chunkOf, &dealtWeighted); // (late pass: even — the weights are calibrated on the early pass, and the extra state costs the late variants two resident workgroups per CU) // bit 15 (experiments): even dealing
 	const uint32_t myCmds = myChunks * CC_CHUNK; // the last chunk of the pass may run past numCmds: guarded below
 	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles);
 	const uint32_t bank = __hip_atomic_load(&a.tileCounts->parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
@@ -750,7 +729,9 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 		const uint32_t cnt = myCmds - seg < 64u ? myCmds - seg : 64u;
 
 		// lane l holds the wave's (seg + l)-th command and (below) the MeshDraw it points at
-		const uint32_t myIdx = dealt_command(deal, seg + lane);
+		const uint32_t cidx = (seg + lane) / CC_CHUNK;
+		const uint32_t chunk = dealtWeighted ? (uint32_t)__shfl(chunkOf, cidx & 63u, 64) : cidx * (gridDim.x * CC_WAVES) + w;
+		const uint32_t myIdx = chunk * CC_CHUNK + (seg + lane) % CC_CHUNK;
 		SegmentRegs r = {};
 		if (lane < cnt && myIdx < numCmds)
 		{
@@ -850,7 +831,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 					// evens the progress of the waves that share a SIMD (speed only).
 					if (!(a.debugMode & 256u)) // bit 8 (experiments) turns the rotation off
 					{
-						switch ((gen + i / CC_DA) & 3u)
+						switch (((a.debugMode & 131072u) ? blockIdx.x + i / CC_DA : gen + i / CC_DA) & 3u) // bit 17 (experiments): rotation without the generation offset
 						{
 						case 0: __builtin_amdgcn_s_setprio(0); break;
 						case 1: __builtin_amdgcn_s_setprio(1); break;

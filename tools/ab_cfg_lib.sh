@@ -1,0 +1,11 @@
+#!/bin/bash
+# usage: bash tools/ab_cfg_lib.sh "<configs>" lib1.so lib2.so ... — tools/bench_configs.py per library build (same box, same call)
+cfg=$1; shift
+for rep in 1 2; do for so in "$@"; do
+  NV_LIBRARY_PATH=$PWD/$so python tools/bench_configs.py --only $cfg 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if not l.startswith('{'): continue
+    d=json.loads(l)
+    print('$so', d['config'][:12], {k: round(v,2) for k,v in d.items() if k in ('late_cull_us','cull_us','cluster_cull_us','step_us','kernel_us','pyramid_us')})"
+done; done
