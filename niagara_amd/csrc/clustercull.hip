@@ -710,20 +710,6 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 	if (dbgTime && lane == 0)
 		stamps[6] = wall_clock64(); // 100 MHz, chip-wide: comparable across CUs (the cycle counter is not)
 
-	// Warm this XCD's L2 with the MeshDraw array before the meshlet stream floods the memory queues, so that the draw
-	// gathers below are L2 hits.  Each workgroup touches one slice, one dword per 128-byte line; workgroup -> XCD is
-	// assumed round-robin (speed only).  cd.drawCount bounds the array by contract.
-	uint32_t warm = 0;
-	if (SOA && !(a.debugMode & 16384u)) // bit 14 (experiments): no warm-up
-	{
-		const uint32_t perXcd = gridDim.x / 8u ? gridDim.x / 8u : 1u;
-		const uint32_t lines = (a.cd.drawCount * (uint32_t)sizeof(NvMeshDraw) + 127u) / 128u;
-		const uint32_t perGroup = (lines + perXcd - 1u) / perXcd;
-		const uint32_t line = (blockIdx.x / 8u) % perXcd * perGroup + threadIdx.x;
-		const char* wp = reinterpret_cast<const char*>(a.draws) + (size_t)(threadIdx.x < perGroup && line < lines ? line : 0u) * 128u;
-		asm volatile("global_load_dword %0, %1, off" : "=&v"(warm) : "v"(wp) : "memory");
-	}
-
 	for (uint32_t seg = 0; seg < myCmds; seg += 64)
 	{
 		const uint32_t cnt = myCmds - seg < 64u ? myCmds - seg : 64u;
@@ -820,7 +806,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 #pragma unroll
 				for (int k = 0; k < CC_DA; ++k)
 					issueA(ring[k], (uint32_t)k < cnt ? k : cnt - 1, 0); // clamped: redundant but unconditional loads
-				asm volatile("s_waitcnt vmcnt(%3)" : "+v"(g0), "+v"(g1), "+v"(warm) : "i"(CC_DA * (BITS_A ? 2 : 1)) : "memory"); // the gather (and the warm-up load before it)
+				asm volatile("s_waitcnt vmcnt(%2)" : "+v"(g0), "+v"(g1) : "i"(CC_DA * (BITS_A ? 2 : 1)) : "memory"); // the gather
 				gather_finish();
 				NV_STAMP(2);
 				for (uint32_t i = 0; i < cnt; i += CC_DA)
