@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=4.0)
     ap.add_argument("--aos", action="store_true", help="read the 24-B AoS meshlets in place (no SoA mirror)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for functional tests)")
+    ap.add_argument("--shared-device", action="store_true", help="functional test only: all ranks use cuda:0 (needs --backend gloo)")
     ap.add_argument("--explicit-reset", action="store_true",
                     help="reference contract: zero the count word with a separate launch (nv_reset_count) instead of NV_OPT_FUSED_COUNT_RESET")
     return ap.parse_args()
@@ -57,10 +59,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
+    if args.shared_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     # ---- inputs: rank r owns commands [r*C, (r+1)*C) of a world*C command pool; weak scaling
     n_draws, cpd = args.draws, args.commands_per_draw
@@ -85,7 +92,14 @@ def main():
     dccb = torch.from_numpy(count4.view(np.int32).copy()).to(dev)
     cib = torch.zeros(min(n_meshlets, L.CLUSTER_LIMIT) + 256, dtype=torch.int32, device=dev)
     ccb = torch.zeros(4, dtype=torch.int32, device=dev)
-    counts = torch.zeros(3, dtype=torch.int64, device=dev)
+    # N > 1: the pass's counts are summed over the ranks with one 24-byte all-reduce per pass.  It is
+    # latency-bound (tens of microseconds, comparable to the pass itself), so it is issued asynchronously on the
+    # collective's own stream and only waited for COUNTS_RING passes later, when its buffer is reused: the reduction of
+    # pass i overlaps the cull of passes i+1.. instead of serialising with them.
+    COUNTS_RING = 8
+    counts_ring = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(COUNTS_RING)]
+    pending = [None] * COUNTS_RING
+    counts = counts_ring[0]
     if not args.aos:
         ctx.upload_meshlets(mlb, copies * n_meshlets)
     torch.cuda.synchronize()
@@ -95,11 +109,21 @@ def main():
             ctx.reset_count(ccb)  # the caller's vkCmdFillBuffer(ccb, 0, 4, 0) as its own launch
         ctx.clustercull(cd, 0, dcbs[i % copies], dccb, db, mlb, None, None, cib, ccb)
         if world > 1:
-            ctx.pack_counts(None, dccb, ccb, counts)
-            dist.all_reduce(counts)
+            slot = i % COUNTS_RING
+            if pending[slot] is not None:
+                pending[slot].wait()
+            ctx.pack_counts(None, dccb, ccb, counts_ring[slot])
+            pending[slot] = dist.all_reduce(counts_ring[slot], async_op=True)
+
+    def drain():
+        for k in range(COUNTS_RING):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     for i in range(args.warmup):
         step(i)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -109,11 +133,13 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    drain()  # every pass's reduction has completed inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    last_counts = counts_ring[(args.steps - 1) % COUNTS_RING].clone() if world > 1 else None
 
     # ---- roofline leg: the same `steps` passes again with the library's HIP events bracketing each kernel on the
     # launch stream (nv_profile_*).  It is a separate loop because an event record is itself a barrier packet: three
@@ -122,6 +148,7 @@ def main():
     t1 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    drain()
     torch.cuda.synchronize()
     profiled = time.perf_counter() - t1
     prof = ctx.profile_read()
@@ -133,7 +160,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        total_visible = int(counts[2].item())
+        total_visible = int(last_counts[2].item())
     else:
         total_visible = visible
 

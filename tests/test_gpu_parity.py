@@ -178,7 +178,7 @@ def test_taskcull_payloads(ctx):
         assert (G.host_u32(d_mvb) == mvb_o).all()
 
 
-@pytest.mark.parametrize("size", [(64, 64), (128, 32), (100, 75), (257, 130), (33, 2), (5, 3), (1024, 768), (4096, 4096), (2048, 1024)])
+@pytest.mark.parametrize("size", [(64, 64), (128, 32), (100, 75), (257, 130), (33, 2), (5, 3), (1024, 768), (4096, 4096), (2048, 1024), (1024, 512), (8192, 2048)])
 def test_depthreduce_sizes(ctx, size):
     w, h = size
     rng = np.random.default_rng(w * 1000 + h)
