@@ -259,6 +259,39 @@ int nv_cluster_expand(nv_context* ctx, void* stream, const NvMeshTaskCommand* d_
                       const uint32_t* d_clusterIndices, const uint32_t* d_clusterCount4, NvClusterRecord* d_records,
                       uint32_t recordCapacity, uint64_t* d_totals3 /* clusters, vertices, triangles */);
 
+/* ---- triangle cull of the mesh stage ----
+ * src/shaders/meshlet.mesh.glsl:91-198 with MESH_CULL = 1 (src/config.h:10-11; the reference ships it switched off): for
+ * every slot of the consumer's grid the meshlet's vertices are transformed exactly like the mesh shader does
+ * (rotateQuat * scale + position, view, projection, perspective divide to screen space) and every triangle gets the
+ * shader's gl_CullPrimitiveEXT decision: back-facing / zero-area (:176-181) or missing every sample centre (:183-190),
+ * provided all three vertices are in front of the perspective plane (:192-193).
+ * One NvTriangleMask per slot index in [0, 256 Y): keep bit i = triangle i is NOT culled (i < triangleCount);
+ * counts = triangleCount | vertexCount << 8 | kept << 16; all zero for a padding slot (~0).  Totals are accumulated
+ * (zero them first): clusters, triangles, triangles kept. */
+typedef struct NvVertex /* src/shaders/mesh.h:3-9, 16 bytes */
+{
+	uint16_t vx, vy, vz; /* fp16 position */
+	uint16_t tp;         /* packed tangent */
+	uint32_t np;         /* packed normal */
+	uint16_t tu, tv;     /* fp16 texcoord */
+} NvVertex;
+typedef struct NvGlobals /* src/shaders/mesh.h:46-51, the mesh pipeline's push constants */
+{
+	float projection[16]; /* column-major */
+	NvCullData cullData;  /* only .view is read here */
+	float screenWidth, screenHeight;
+	float pad_[2];
+} NvGlobals;
+typedef struct NvTriangleMask
+{
+	uint32_t keep[3]; /* MESH_MAXTRI = 96 (src/config.h:15) */
+	uint32_t counts;
+} NvTriangleMask;
+int nv_trianglecull(nv_context* ctx, void* stream, const NvGlobals* globals, const NvMeshTaskCommand* d_commands,
+                    const NvMeshDraw* d_draws, const NvMeshlet* d_meshlets, const uint32_t* d_meshletData,
+                    const NvVertex* d_vertices, const uint32_t* d_clusterIndices, const uint32_t* d_clusterCount4,
+                    NvTriangleMask* d_masks, uint32_t maskCapacity, uint64_t* d_totals3 /* clusters, triangles, kept */);
+
 /* depthreduce.comp.glsl:14-22 + the level loop at src/niagara.cpp:1703-1733.
  * d_depth is the width x height fp32 depth target (reverse-Z, far = 0). */
 int nv_depthreduce(nv_context* ctx, void* stream, const float* d_depth, uint32_t width, uint32_t height,
@@ -311,6 +344,9 @@ static_assert(sizeof(NvCullData) == 144, "CullData layout (src/niagara.cpp:242-2
 static_assert(offsetof(NvCullData, P00) == 64 && offsetof(NvCullData, frustum) == 80, "CullData offsets");
 static_assert(offsetof(NvCullData, lodTarget) == 96 && offsetof(NvCullData, drawCount) == 108, "CullData offsets");
 static_assert(offsetof(NvCullData, cullingEnabled) == 112 && offsetof(NvCullData, postPass) == 132, "CullData offsets");
+static_assert(sizeof(NvVertex) == 16, "Vertex layout (src/shaders/mesh.h:3-9)");
+static_assert(sizeof(NvGlobals) == 224 && offsetof(NvGlobals, cullData) == 64 && offsetof(NvGlobals, screenWidth) == 208, "Globals layout (src/shaders/mesh.h:46-51)");
+static_assert(sizeof(NvTriangleMask) == 16, "one mask per grid slot");
 #endif
 
 #endif /* NIAGARA_VIS_H */

@@ -51,6 +51,7 @@ _SIGS = {
     "nv_clustersubmit": (_i, [_vp, _vp, _vp, _vp]),
     "nv_taskcull": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(PyramidDesc), _vp, _vp]),
     "nv_cluster_expand": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "nv_trianglecull": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "nv_depthreduce": (_i, [_vp, _vp, _vp, _u32, _u32, C.POINTER(PyramidDesc)]),
     "nv_previous_pow2": (_u32, [_u32]),
     "nv_image_mip_levels": (_u32, [_u32, _u32]),

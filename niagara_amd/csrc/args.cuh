@@ -68,4 +68,20 @@ struct DrawArgs
 	uint32_t debugMode;  // tuning experiments only (NV_DEBUG_MODE); 0 in production
 };
 
+// trianglecull.hip
+struct TriangleArgs
+{
+	NvGlobals globals;
+	const NvMeshTaskCommand* __restrict__ commands;
+	const NvMeshDraw* __restrict__ draws;
+	const NvMeshlet* __restrict__ meshlets;
+	const uint32_t* __restrict__ meshletData;
+	const NvVertex* __restrict__ vertices;
+	const uint32_t* __restrict__ clusterIndices;
+	const uint32_t* __restrict__ cc4;
+	NvTriangleMask* __restrict__ masks;
+	uint32_t capacity;
+	unsigned long long* __restrict__ totals;
+};
+
 } // namespace nv

@@ -33,6 +33,7 @@ int launch_cluster_expand(hipStream_t, const NvMeshTaskCommand*, const NvMeshlet
 int launch_clustersubmit(hipStream_t, uint32_t* cc4, uint32_t* clusterIndices);
 int launch_pack_counts(hipStream_t, const uint32_t*, const uint32_t*, const uint32_t*, uint64_t*);
 int launch_depthreduce(hipStream_t, const float* depth, uint32_t w, uint32_t h, const NvPyramidDesc& pyr);
+int launch_trianglecull(hipStream_t, const TriangleArgs& a, uint32_t gridBlocks);
 
 } // namespace nv
 
@@ -525,6 +526,29 @@ int nv_cluster_expand(nv_context* ctx, void* stream, const NvMeshTaskCommand* d_
 	DeviceGuard guard(ctx->device);
 	return nv::launch_cluster_expand((hipStream_t)stream, d_commands, d_meshlets, d_clusterIndices, d_clusterCount4, d_records, recordCapacity,
 	                                 d_totals3, (uint32_t)ctx->numCUs * 8);
+}
+
+int nv_trianglecull(nv_context* ctx, void* stream, const NvGlobals* globals, const NvMeshTaskCommand* d_commands, const NvMeshDraw* d_draws,
+                    const NvMeshlet* d_meshlets, const uint32_t* d_meshletData, const NvVertex* d_vertices, const uint32_t* d_clusterIndices,
+                    const uint32_t* d_clusterCount4, NvTriangleMask* d_masks, uint32_t maskCapacity, uint64_t* d_totals3)
+{
+	if (!ctx || !globals || !d_commands || !d_draws || !d_meshlets || !d_meshletData || !d_vertices || !d_clusterIndices || !d_clusterCount4 ||
+	    !d_totals3 || (!d_masks && maskCapacity))
+		return NV_EINVAL;
+	DeviceGuard guard(ctx->device);
+	nv::TriangleArgs a;
+	a.globals = *globals;
+	a.commands = d_commands;
+	a.draws = d_draws;
+	a.meshlets = d_meshlets;
+	a.meshletData = d_meshletData;
+	a.vertices = d_vertices;
+	a.clusterIndices = d_clusterIndices;
+	a.cc4 = d_clusterCount4;
+	a.masks = d_masks;
+	a.capacity = maskCapacity;
+	a.totals = reinterpret_cast<unsigned long long*>(d_totals3);
+	return nv::launch_trianglecull((hipStream_t)stream, a, persistent_grid(ctx, 8));
 }
 
 int nv_depthreduce(nv_context* ctx, void* stream, const float* d_depth, uint32_t width, uint32_t height,

@@ -27,6 +27,10 @@ CULLDATA = np.dtype([("view", "<f4", 16), ("P00", "<f4"), ("P11", "<f4"), ("znea
 
 CLUSTERRECORD = np.dtype([("drawId", "<u4"), ("meshletIndex", "<u4"), ("vertexCount", "<u4"), ("triangleCount", "<u4"), ("vertexOffset", "<u4"),
                           ("indexOffset", "<u4"), ("baseVertex", "<u4"), ("shortRefs", "<u4")])
+VERTEX = np.dtype([("vx", "<u2"), ("vy", "<u2"), ("vz", "<u2"), ("tp", "<u2"), ("np", "<u4"), ("tu", "<u2"), ("tv", "<u2")])  # src/shaders/mesh.h:3-9
+GLOBALS = np.dtype([("projection", "<f4", 16), ("cullData", CULLDATA), ("screenWidth", "<f4"), ("screenHeight", "<f4"), ("_pad", "<f4", 2)])  # mesh.h:46-51
+TRIMASK = np.dtype([("keep", "<u4", 3), ("counts", "<u4")])
+assert (VERTEX.itemsize, GLOBALS.itemsize, TRIMASK.itemsize) == (16, 224, 16)
 
 TASK_WGSIZE = 64
 TASK_WGLIMIT = 1 << 22

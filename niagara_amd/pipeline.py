@@ -108,6 +108,11 @@ class Context:
         check(lib.nv_cluster_expand(self.h, _stream(), _ptr(dcb), _ptr(mlb), _ptr(cib), _ptr(ccb), _ptr(records), capacity, _ptr(totals3)),
               "nv_cluster_expand")
 
+    def trianglecull(self, globals_, dcb, db, mlb, meshlet_data, vertices, cib, ccb, masks, capacity, totals3):
+        """meshlet.mesh.glsl:91-198 with MESH_CULL = 1: one NvTriangleMask per slot of the consumer's grid"""
+        check(lib.nv_trianglecull(self.h, _stream(), C.c_void_p(globals_.ctypes.data), _ptr(dcb), _ptr(db), _ptr(mlb), _ptr(meshlet_data), _ptr(vertices),
+                                  _ptr(cib), _ptr(ccb), _ptr(masks), capacity, _ptr(totals3)), "nv_trianglecull")
+
     def depthreduce(self, depth, width, height, pyramid):
         check(lib.nv_depthreduce(self.h, _stream(), _ptr(depth), width, height, C.byref(pyramid)), "nv_depthreduce")
 

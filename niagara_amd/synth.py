@@ -96,3 +96,63 @@ def cluster_scene(draw_count, commands_per_draw=10, seed=2, scene_radius=300.0):
     draws["meshletVisibilityOffset"] = np.arange(draw_count, dtype=np.uint32) * (commands_per_draw * 64)
     commands = make_task_commands(draw_count, commands_per_draw)
     return draws, meshlets, commands, n_cmd
+
+
+def make_globals(cd, viewport):
+    """the mesh pipeline's push constants (src/shaders/mesh.h:46-51): niagara's reverse-Z infinite projection
+    (perspectiveProjection, src/niagara.cpp:424-431) rebuilt from the P00 / P11 / znear the CullData already carries"""
+    g = np.zeros(1, dtype=L.GLOBALS)
+    p = np.zeros(16, np.float32)
+    p[0], p[5], p[11], p[14] = cd["P00"][0], cd["P11"][0], 1.0, cd["znear"][0]
+    g["projection"][0] = p
+    g["cullData"][0] = cd[0]
+    g["screenWidth"], g["screenHeight"] = viewport
+    return g
+
+
+def make_geometry(meshlets, seed=5, vertices_per_mesh=4096):
+    """Synthetic meshlet payloads in niagara's packed form (src/scene.cpp:24-115, src/shaders/meshlet.mesh.glsl:107-127):
+    per meshlet `dataOffset` words = vertex references (u16 pairs when shortRefs, else u32) followed by 3 index bytes per
+    triangle; vertices = fp16 positions scattered around the meshlet's centre with about its radius.  Fills vertexCount
+    (<= 64), triangleCount (<= 96), dataOffset, baseVertex, shortRefs of `meshlets` in place; returns (meshlet_data u32[],
+    vertices).  meshoptimizer builds the real thing and is not vendored: distributions only, like the bounds."""
+    rng = np.random.default_rng(seed)
+    n = len(meshlets)
+    vc = rng.integers(3, 65, n).astype(np.uint32)
+    tc = np.minimum(rng.integers(1, 97, n), 96).astype(np.uint32)
+    short = rng.integers(0, 2, n).astype(np.uint32)
+    ref_words = np.where(short == 1, (vc + 1) // 2, vc)
+    idx_words = (tc * 3 + 3) // 4
+    words = ref_words + idx_words
+    offsets = np.concatenate([[0], np.cumsum(words)[:-1]]).astype(np.uint32)
+    data = np.zeros(int(words.sum()) + 4, np.uint32)
+    d16, d8 = data.view(np.uint16), data.view(np.uint8)
+    base = (np.arange(n, dtype=np.uint32) * 61) % max(1, vertices_per_mesh - 64 * 4)  # overlapping windows of a shared pool per "mesh"
+    pool = (np.arange(n, dtype=np.uint32) // 4096) * vertices_per_mesh
+    base = base + pool
+    total_vertices = int(pool.max()) + vertices_per_mesh if n else vertices_per_mesh
+    vertices = np.zeros(total_vertices, dtype=L.VERTEX)
+    centers = meshlets["center"].view(np.float16).astype(np.float32).reshape(n, 3)
+    radii = meshlets["radius"].view(np.float16).astype(np.float32)
+    # positions: every vertex of the pool gets a position near the centre of the first meshlet whose window covers it
+    vpos = rng.normal(size=(total_vertices, 3)).astype(np.float32)
+    owner = np.minimum(np.searchsorted(base, np.arange(total_vertices, dtype=np.uint32), side="right").clip(1) - 1, n - 1) if n else np.zeros(total_vertices, int)
+    vpos = centers[owner] + vpos * (radii[owner][:, None] * 0.6)
+    vertices["vx"], vertices["vy"], vertices["vz"] = (vpos[:, k].astype(np.float16).view(np.uint16) for k in range(3))
+    vertices["np"] = rng.integers(0, 2 ** 32, total_vertices, dtype=np.uint64).astype(np.uint32)
+    vertices["tp"] = rng.integers(0, 2 ** 16, total_vertices).astype(np.uint16)
+    for i in range(n):
+        o, v, t = int(offsets[i]), int(vc[i]), int(tc[i])
+        refs = rng.integers(0, 192, v).astype(np.uint32)  # window of 192 pool vertices behind baseVertex
+        if short[i]:
+            d16[o * 2:o * 2 + v] = refs
+        else:
+            data[o:o + v] = refs
+        io = (o + int(ref_words[i])) * 4
+        d8[io:io + t * 3] = rng.integers(0, v, t * 3).astype(np.uint8)
+    meshlets["vertexCount"] = vc
+    meshlets["triangleCount"] = tc
+    meshlets["dataOffset"] = offsets
+    meshlets["baseVertex"] = base
+    meshlets["shortRefs"] = short
+    return data, vertices

@@ -36,6 +36,10 @@ CULLDATA = np.dtype([("view", "<f4", 16), ("P00", "<f4"), ("P11", "<f4"), ("znea
                      ("_pad", "<u4", 2)])
 assert (MESHLET.itemsize, MESHDRAW.itemsize, MESHLOD.itemsize, MESH.itemsize) == (24, 48, 20, 208)
 assert (DRAWCMD.itemsize, TASKCMD.itemsize, CULLDATA.itemsize) == (24, 20, 144)
+VERTEX = np.dtype([("vx", "<u2"), ("vy", "<u2"), ("vz", "<u2"), ("tp", "<u2"), ("np", "<u4"), ("tu", "<u2"), ("tv", "<u2")])  # src/shaders/mesh.h:3-9
+GLOBALS = np.dtype([("projection", "<f4", 16), ("cullData", CULLDATA), ("screenWidth", "<f4"), ("screenHeight", "<f4"), ("_pad", "<f4", 2)])  # mesh.h:46-51
+TRIMASK = np.dtype([("keep", "<u4", 3), ("counts", "<u4")])
+assert (VERTEX.itemsize, GLOBALS.itemsize, TRIMASK.itemsize) == (16, 224, 16)
 
 TASK_WGLIMIT = 1 << 22
 CLUSTER_LIMIT = 1 << 24
@@ -167,6 +171,11 @@ def probe_cluster_scalars(cd, commands, draws, meshlets, pyr=None):
 
 def cluster_expand(commands, meshlets, cib, cc4, records, totals3):
     lib().orc_cluster_expand(_p(commands), _p(meshlets), _p(cib), _p(cc4), _p(records), C.c_uint32(len(records)), _p(totals3))
+
+
+def trianglecull(globals_, commands, draws, meshlets, meshlet_data, vertices, cib, cc4, masks, totals3):
+    lib().orc_trianglecull(_p(globals_), _p(commands), _p(draws), _p(meshlets), _p(meshlet_data), _p(vertices), _p(cib), _p(cc4), _p(masks),
+                           C.c_uint32(len(masks)), _p(totals3))
 
 
 def max_threads():

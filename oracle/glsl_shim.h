@@ -68,6 +68,8 @@ struct ivec2
 struct uvec3
 {
 	uint x, y, z;
+	uvec3() : x(0), y(0), z(0) {}
+	uvec3(uint x_, uint y_, uint z_) : x(x_), y(y_), z(z_) {}
 	uvec2 xy() const { return uvec2(x, y); }
 };
 struct bvec2
@@ -81,6 +83,8 @@ struct vec3
 	vec3() : x(0), y(0), z(0) {}
 	explicit vec3(float s) : x(s), y(s), z(s) {}
 	vec3(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
+	vec3(vec2 v, float z_) : x(v.x), y(v.y), z(z_) {}
+	vec2 xy() const { return vec2(x, y); }
 };
 struct vec4
 {
@@ -101,6 +105,7 @@ inline vec2 operator-(vec2 a, vec2 b) { return vec2(a.x - b.x, a.y - b.y); }
 inline vec2 operator*(vec2 a, vec2 b) { return vec2(a.x * b.x, a.y * b.y); }
 inline vec2 operator/(vec2 a, vec2 b) { return vec2(a.x / b.x, a.y / b.y); }
 inline vec2 operator*(vec2 a, float s) { return vec2(a.x * s, a.y * s); }
+inline vec2 operator/(vec2 a, float s) { return vec2(a.x / s, a.y / s); }
 
 inline vec3 operator+(vec3 a, vec3 b) { return vec3(a.x + b.x, a.y + b.y, a.z + b.z); }
 inline vec3 operator-(vec3 a, vec3 b) { return vec3(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -163,6 +168,17 @@ inline float max(float a, float b) { return a < b ? b : a; }
 inline float min(float a, float b) { return b < a ? b : a; }
 inline uint max(uint a, uint b) { return a < b ? b : a; }
 inline uint min(uint a, uint b) { return b < a ? b : a; }
+inline vec2 min(vec2 a, vec2 b) { return vec2(min(a.x, b.x), min(a.y, b.y)); }
+inline vec2 max(vec2 a, vec2 b) { return vec2(max(a.x, b.x), max(a.y, b.y)); }
+/* round(): GLSL leaves the direction of .5 to the implementation; defined as round-half-to-even (v_rndne_f32, SPIR-V RoundEven) */
+inline float round(float x) { return rintf(x); }
+/* shading attributes (normal / tangent unpacking, src/shaders/math.h:131-136) are outside the visibility path: the
+ * translation keeps only math.h:2-49, and the mesh shader's call resolves to this stub */
+inline void unpackTBN(uint, uint, vec3& normal, vec4& tangent)
+{
+	normal = vec3(0, 0, 1);
+	tangent = vec4(1, 0, 0, 1);
+}
 inline bvec2 lessThanEqual(vec2 a, vec2 b)
 {
 	bvec2 r = { a.x <= b.x, a.y <= b.y };

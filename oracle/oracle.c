@@ -732,6 +732,84 @@ void orc_cluster_expand(const OrcMeshTaskCommand* commands, const OrcMeshlet* me
 			}
 }
 
+/* src/shaders/meshlet.mesh.glsl:91-198, CULL = 1.  One workgroup per grid slot; vertex phase (:121-160), barrier, triangle
+ * phase (:166-205). */
+void orc_trianglecull(const OrcGlobals* globals, const OrcMeshTaskCommand* commands, const OrcMeshDraw* draws, const OrcMeshlet* meshlets,
+                      const uint32_t* meshletData, const OrcVertex* vertices, const uint32_t* clusterIndices, const uint32_t* cc4,
+                      uint32_t* masks4, uint32_t capacity, uint64_t* totals3)
+{
+	const uint16_t* meshletData16 = (const uint16_t*)meshletData;
+	const uint8_t* meshletData8 = (const uint8_t*)meshletData;
+	const float* P = globals->projection;
+	const float* V = globals->cullData.view;
+	for (uint32_t y = 0; y < cc4[2]; ++y)
+		for (uint32_t z = 0; z < cc4[3]; ++z)
+			for (uint32_t x = 0; x < cc4[1]; ++x)
+			{
+				uint32_t index = x + y * 256 + z * CLUSTER_TILE;
+				uint32_t ci = clusterIndices[index];
+				uint32_t out[4] = { 0, 0, 0, 0 };
+				if (ci != ~0u)
+				{
+					const OrcMeshTaskCommand* command = &commands[ci & 0xffffff];
+					uint32_t mi = command->taskOffset + (ci >> 24);
+					const OrcMeshDraw* meshDraw = &draws[command->drawId];
+					uint32_t vertexCount = meshlets[mi].vertexCount, triangleCount = meshlets[mi].triangleCount;
+					uint32_t dataOffset = meshlets[mi].dataOffset, baseVertex = meshlets[mi].baseVertex;
+					int shortRefs = meshlets[mi].shortRefs == 1;
+					uint32_t vertexOffset = dataOffset;
+					uint32_t indexOffset = dataOffset + (shortRefs ? (vertexCount + 1) / 2 : vertexCount);
+					float vertexClip[64][3];
+					memset(vertexClip, 0, sizeof(vertexClip));
+					for (uint32_t i = 0; i < vertexCount && i < 64; ++i)
+					{
+						uint32_t vi = shortRefs ? (uint32_t)meshletData16[vertexOffset * 2 + i] + baseVertex : meshletData[vertexOffset + i] + baseVertex;
+						float position[3] = { orc_half_to_float(vertices[vi].vx), orc_half_to_float(vertices[vi].vy), orc_half_to_float(vertices[vi].vz) };
+						float rot[3], wpos[3], v4[4], clip[4];
+						orc_rotate_quat(position, meshDraw->orientation, rot);
+						for (int k = 0; k < 3; ++k)
+							wpos[k] = rot[k] * meshDraw->scale + meshDraw->position[k];
+						/* clip = projection * (view * vec4(wpos, 1)); mat * vec = ((c0*x + c1*y) + c2*z) + c3*w */
+						for (int r = 0; r < 4; ++r)
+							v4[r] = ((V[r] * wpos[0] + V[4 + r] * wpos[1]) + V[8 + r] * wpos[2]) + V[12 + r] * 1.0f;
+						for (int r = 0; r < 4; ++r)
+							clip[r] = ((P[r] * v4[0] + P[4 + r] * v4[1]) + P[8 + r] * v4[2]) + P[12 + r] * v4[3];
+						/* vertexClip[i] = vec3((clip.xy / clip.w * 0.5 + vec2(0.5)) * screen, clip.w) */
+						vertexClip[i][0] = ((clip[0] / clip[3]) * 0.5f + 0.5f) * globals->screenWidth;
+						vertexClip[i][1] = ((clip[1] / clip[3]) * 0.5f + 0.5f) * globals->screenHeight;
+						vertexClip[i][2] = clip[3];
+					}
+					uint32_t kept = 0;
+					for (uint32_t i = 0; i < triangleCount && i < 96; ++i)
+					{
+						uint32_t offset = indexOffset * 4 + i * 3;
+						uint32_t a = meshletData8[offset], b = meshletData8[offset + 1], c = meshletData8[offset + 2];
+						const float *pa = vertexClip[a & 63], *pb = vertexClip[b & 63], *pc = vertexClip[c & 63];
+						int culled = 0;
+						float ebx = pb[0] - pa[0], eby = pb[1] - pa[1];
+						float ecx = pc[0] - pa[0], ecy = pc[1] - pa[1];
+						culled = culled || (ebx * ecy <= eby * ecx);
+						float bminx = gl_minf(pa[0], gl_minf(pb[0], pc[0])), bminy = gl_minf(pa[1], gl_minf(pb[1], pc[1]));
+						float bmaxx = gl_maxf(pa[0], gl_maxf(pb[0], pc[0])), bmaxy = gl_maxf(pa[1], gl_maxf(pb[1], pc[1]));
+						float sbprec = 1.0f / 256.0f;
+						culled = culled || (rintf(bminx - sbprec) == rintf(bmaxx) || rintf(bminy) == rintf(bmaxy + sbprec));
+						culled = culled && (pa[2] > 0 && pb[2] > 0 && pc[2] > 0);
+						if (!culled)
+						{
+							out[i >> 5] |= 1u << (i & 31);
+							kept++;
+						}
+					}
+					out[3] = (triangleCount & 0xffu) | (vertexCount & 0xffu) << 8 | kept << 16;
+					totals3[0] += 1;
+					totals3[1] += triangleCount;
+					totals3[2] += kept;
+				}
+				if (index < capacity)
+					memcpy(masks4 + (size_t)index * 4, out, sizeof(out));
+			}
+}
+
 void orc_probe_cluster_scalars(const OrcCullData* cd, const OrcMeshTaskCommand* commands, uint32_t commandCount,
                                const OrcMeshDraw* draws, const OrcMeshlet* meshlets, const OrcPyramid* pyr, float* out16)
 {

@@ -133,6 +133,32 @@ void orc_depthreduce(const float* depth, uint32_t w, uint32_t h, const OrcPyrami
 void orc_cluster_expand(const OrcMeshTaskCommand* commands, const OrcMeshlet* meshlets, const uint32_t* clusterIndices,
                         const uint32_t* cc4, uint32_t* records8, uint32_t capacity, uint64_t* totals3);
 
+/* src/shaders/mesh.h:3-9 */
+typedef struct
+{
+	uint16_t vx, vy, vz;
+	uint16_t tp;
+	uint32_t np;
+	uint16_t tu, tv;
+} OrcVertex;
+
+/* src/shaders/mesh.h:46-51 (push constants of the mesh pipeline; size rounded up to the struct's 16-byte alignment) */
+typedef struct
+{
+	float projection[16];
+	OrcCullData cullData;
+	float screenWidth, screenHeight;
+	float pad_[2];
+} OrcGlobals;
+
+/* src/shaders/meshlet.mesh.glsl:91-198 with MESH_CULL = 1: per grid slot 4 words = keep[3] (bit i: triangle i survives),
+ * counts = triangleCount | vertexCount << 8 | kept << 16; totals3 += {clusters, triangles, kept}.
+ * GLSL round() leaves the direction of .5 to the implementation: defined here as round-half-to-even (what the
+ * hardware's v_rndne / the C rintf in the default rounding mode do). */
+void orc_trianglecull(const OrcGlobals* globals, const OrcMeshTaskCommand* commands, const OrcMeshDraw* draws, const OrcMeshlet* meshlets,
+                      const uint32_t* meshletData, const OrcVertex* vertices, const uint32_t* clusterIndices, const uint32_t* cc4,
+                      uint32_t* masks4, uint32_t capacity, uint64_t* totals3);
+
 /* per-meshlet scalar intermediates, 16 floats per lane (same record as nv_probe_cluster_scalars) */
 void orc_probe_cluster_scalars(const OrcCullData* cull, const OrcMeshTaskCommand* commands, uint32_t commandCount,
                                const OrcMeshDraw* draws, const OrcMeshlet* meshlets, const OrcPyramid* pyr, float* out16);

@@ -50,6 +50,12 @@ def clustercull(cd, late, commands, count4, draws, meshlets, mvb, pyr, cib, cc4)
     lib().ref_clustercull(_p(cd), int(late), _p(commands), _p(count4), _p(draws), _p(meshlets), _p(mvb), _pyr(pyr), _p(cib), _p(cc4))
 
 
+def meshlet_mesh(globals_, commands, draws, meshlets, meshlet_data, vertices, cib, cc4, masks, totals3):
+    """src/shaders/meshlet.mesh.glsl (MESH_CULL = 1, TASK = false) over the grid in cc4; see oracle/ref_runner.cpp"""
+    lib().ref_meshlet_mesh(_p(globals_), _p(commands), _p(draws), _p(meshlets), _p(meshlet_data), _p(vertices), _p(cib), _p(cc4), _p(masks),
+                           C.c_uint32(len(masks)), _p(totals3))
+
+
 def clustersubmit(cc4, cib):
     lib().ref_clustersubmit(_p(cc4), _p(cib))
 

@@ -13,6 +13,28 @@
 namespace glsl
 {
 static uvec3 gl_GlobalInvocationID, gl_LocalInvocationID, gl_WorkGroupID;
+#ifdef REF_MESHLET_MESH
+/* GL_EXT_mesh_shader built-ins the mesh stage writes (the runner reads them back after each workgroup) */
+static uint gl_LocalInvocationIndex;
+struct MeshVertexOut
+{
+	vec4 gl_Position;
+};
+struct MeshPrimitiveOut
+{
+	bool gl_CullPrimitiveEXT;
+};
+static MeshVertexOut gl_MeshVerticesEXT[256];
+static uvec3 gl_PrimitiveTriangleIndicesEXT[256];
+static MeshPrimitiveOut gl_MeshPrimitivesEXT[256];
+static uint ref_outVertices, ref_outPrimitives;
+static void SetMeshOutputsEXT(uint vertexCount, uint primitiveCount)
+{
+	ref_outVertices = vertexCount;
+	ref_outPrimitives = primitiveCount;
+}
+static void barrier() {} /* the runner executes the workgroup twice instead (see ref_meshlet_mesh) */
+#endif
 
 namespace REF_NS
 {
@@ -240,5 +262,65 @@ extern "C" void ref_perspective(float fovY, float aspect, float znear, float out
 	frustum[1] = frustumX.z;
 	frustum[2] = frustumY.y;
 	frustum[3] = frustumY.z;
+}
+#endif
+
+#ifdef REF_MESHLET_MESH
+/* vkCmdDrawMeshTasksIndirectEXT(ccb, 4) of meshlet.mesh.glsl without a task stage (TASK = false): one workgroup of
+ * MESH_WGSIZE = 64 invocations per grid cell {x < cc4[1], y < cc4[2], z < cc4[3]} (src/niagara.cpp:1664).  The shader
+ * has one barrier() between its vertex and triangle phases; invocations are serialised here, so every workgroup is run
+ * TWICE: the first run leaves vertexClip[] complete, the second run's triangle phase then reads what a real
+ * workgroup would read after the barrier (main() has no other cross-invocation state and only overwrites its outputs). */
+extern "C" void ref_meshlet_mesh(const void* globals_, void* commands, void* draws_, void* meshlets_, uint32_t* meshletData_, void* vertices_,
+                                 uint32_t* clusterIndices_, const uint32_t* cc4, uint32_t* masks4, uint32_t capacity, uint64_t* totals3)
+{
+	/* push-constant block in the GLSL (std430) layout: mat4 @0, CullData @64 (144 bytes: a struct that contains a mat4 is
+	 * 16-byte aligned, the shim's plain-float CullData is 136), screenWidth / screenHeight @208 */
+	memcpy(&globals.projection, globals_, 64);
+	memcpy(&globals.cullData, (const char*)globals_ + 64, sizeof(CullData));
+	memcpy(&globals.screenWidth, (const char*)globals_ + 208, 4);
+	memcpy(&globals.screenHeight, (const char*)globals_ + 212, 4);
+	TASK = false;
+	taskCommands = (MeshTaskCommand*)commands;
+	draws = (MeshDraw*)draws_;
+	meshlets = (Meshlet*)meshlets_;
+	meshletData = meshletData_;
+	meshletData16 = (uint16_t*)meshletData_;
+	meshletData8 = (uint8_t*)meshletData_;
+	vertices = (Vertex*)vertices_;
+	clusterIndices = clusterIndices_;
+	for (uint y = 0; y < cc4[2]; ++y)
+		for (uint z = 0; z < cc4[3]; ++z)
+			for (uint x = 0; x < cc4[1]; ++x)
+			{
+				gl_WorkGroupID.x = x;
+				gl_WorkGroupID.y = y;
+				gl_WorkGroupID.z = z;
+				for (int run = 0; run < 2; ++run)
+					for (uint l = 0; l < 64; ++l)
+					{
+						gl_LocalInvocationIndex = l;
+						gl_LocalInvocationID.x = l;
+						shader_main();
+					}
+				uint32_t index = x + y * 256 + z * CLUSTER_TILE;
+				uint32_t out[4] = { 0, 0, 0, 0 };
+				if (ref_outVertices || ref_outPrimitives || clusterIndices_[index] != ~0u)
+				{
+					uint32_t kept = 0;
+					for (uint i = 0; i < ref_outPrimitives; ++i)
+						if (!gl_MeshPrimitivesEXT[i].gl_CullPrimitiveEXT)
+						{
+							out[i >> 5] |= 1u << (i & 31);
+							kept++;
+						}
+					out[3] = (ref_outPrimitives & 0xffu) | (ref_outVertices & 0xffu) << 8 | kept << 16;
+					totals3[0] += 1;
+					totals3[1] += ref_outPrimitives;
+					totals3[2] += kept;
+				}
+				if (index < capacity)
+					memcpy(masks4 + (size_t)index * 4, out, sizeof(out));
+			}
 }
 #endif

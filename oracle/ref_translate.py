@@ -19,7 +19,10 @@ Rewrites (nothing semantic):
   * float literals get an `f` suffix (GLSL literals are fp32);
   * the rvalue swizzles .xy .zw .xyz .xwzy -> member calls;
   * `void main()` -> `void shader_main()`.
+  * mesh-shader declarations (meshlet.mesh.glsl): `layout(triangles, ...) out;` dropped, `layout(location=N) out [flat] T
+    name[];` -> `T name[256];`, `taskPayloadSharedEXT` / `shared` qualifiers dropped (the runner serialises a workgroup).
 `--limit math.h:49` keeps only the first 49 lines of that include (the cull helpers; the rest is shading).
+`--define NAME=V` flips one of the reference's own `#define NAME ...` configuration switches (MESH_CULL, src/config.h:10-11).
 Also extracts line ranges of host C++ (PCG32, previousPow2, projection) with --lines.
 """
 import os
@@ -28,6 +31,7 @@ import sys
 
 
 LIMITS = {}  # basename -> number of leading lines to keep (e.g. math.h:49 = the cull helpers only)
+DEFINES = {}  # NAME -> value: rewrites the reference's own `#define NAME x` line
 
 
 def inline_includes(path, seen=None):
@@ -54,6 +58,14 @@ def translate(src):
     src = re.sub(r"^\s*#(version|extension)[^\n]*\n", "", src, flags=re.M)
     src = re.sub(r"layout\s*\(\s*constant_id\s*=\s*\d+\s*\)\s*const\s+bool\s+(\w+)\s*=\s*(\w+)\s*;", r"bool \1 = \2;", src)
     src = re.sub(r"layout\s*\(\s*local_size_x[^)]*\)\s*in\s*;", "", src)
+    src = re.sub(r"layout\s*\(\s*triangles[^)]*\)\s*out\s*;", "", src)
+    src = re.sub(r"layout\s*\(\s*location\s*=\s*\d+\s*\)\s*out\s+(?:flat\s+)?(\w+)\s+(\w+)\s*\[\s*\]\s*;", r"\1 \2[256];", src)
+    src = re.sub(r"\btaskPayloadSharedEXT\s+", "", src)
+    src = re.sub(r"^shared\s+", "", src, flags=re.M)
+    for name, value in DEFINES.items():
+        src, n = re.subn(r"^(\s*#define\s+%s)\s+\S+[^\n]*$" % re.escape(name), r"\1 %s" % value, src, flags=re.M)
+        if n != 1:
+            raise SystemExit("--define %s: expected exactly one #define in the reference, found %d" % (name, n))
 
     def block(m):
         name, body = m.group(1), m.group(2)
@@ -93,9 +105,13 @@ def main():
             chunks.append("\n".join(lines[int(a) - 1:int(b)]))
         open(out, "w").write("\n\n".join(chunks) + "\n")
         return
-    while args[0] == "--limit":
-        name, n = args[1].split(":")
-        LIMITS[name] = int(n)
+    while args[0] in ("--limit", "--define"):
+        if args[0] == "--limit":
+            name, n = args[1].split(":")
+            LIMITS[name] = int(n)
+        else:
+            name, v = args[1].split("=")
+            DEFINES[name] = v
         args = args[2:]
     path, out = args
     open(out, "w").write("// generated from %s by oracle/ref_translate.py — do not commit\n" % path + translate(inline_includes(path)))

@@ -48,5 +48,20 @@ def main():
         print("%-28s %6d bytes, frame-0 late visible clusters: %d" % (name + ".npz", os.path.getsize(path), vis))
 
 
+def mesh_fixture():
+    """tests/golden/mesh/trianglecull.npz: inputs + the reference mesh shader's own triangle-cull decisions (MESH_CULL = 1)"""
+    import test_trianglecull as T
+    from scenes import make_triangle_scene
+    s = make_triangle_scene(seed=77, n_draws=20, commands_per_draw=1, scene_radius=8.0, cam_pos=(1.0, 0.5, -2.0))
+    cib, cc4 = T.cluster_list(R, s)
+    masks, totals = T.run(R.meshlet_mesh, s, cib, cc4)
+    os.makedirs(os.path.join(HERE, "mesh"), exist_ok=True)
+    path = os.path.join(HERE, "mesh", "trianglecull.npz")
+    np.savez_compressed(path, globals=s["globals"], commands=s["commands"], draws=s["draws"], meshlets=s["meshlets"], data=s["data"],
+                        vertices=s["vertices"], cib=cib[:len(masks)], cc4=cc4, masks=masks, totals=totals)
+    print("%-28s %6d bytes, clusters %d, triangles %d, kept %d" % ("mesh/trianglecull.npz", os.path.getsize(path), *totals))
+
+
 if __name__ == "__main__":
     main()
+    mesh_fixture()

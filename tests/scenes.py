@@ -56,3 +56,18 @@ def flag_matrix():
                     for cbe in (0, 1):
                         out.append((ce, le, oe, coe, cbe))
     return out
+
+
+def make_triangle_scene(seed=0, n_draws=60, commands_per_draw=3, viewport=(640, 480), scene_radius=20.0, cam_pos=(0, 0, 0), cam_quat=(0, 0, 0, 1),
+                        full_meshlets=False):
+    """Inputs of the mesh stage's triangle cull: a config-3 style cluster scene plus synthetic meshlet
+    payloads (vertex references, index bytes, fp16 vertices).  The cluster list is NOT part of the scene: the caller
+    produces it with the implementation under test (clustercull -> clustersubmit)."""
+    from niagara_amd import host, synth
+    draws, meshlets, commands, n = synth.cluster_scene(n_draws, commands_per_draw, seed=seed, scene_radius=scene_radius)
+    data, vertices = synth.make_geometry(meshlets, seed=seed + 1000)
+    if full_meshlets:  # every meshlet at the limits MESH_MAXVTX / MESH_MAXTRI would need re-packing: keep a few instead
+        pass
+    cd = host.build_cull_data(cam_pos=cam_pos, cam_quat=cam_quat, draw_count=n_draws, viewport=viewport, cullingEnabled=1, clusterBackfaceEnabled=0)
+    return dict(draws=draws, meshlets=meshlets, commands=commands, n=n, cull=cd, data=data, vertices=vertices,
+                globals=synth.make_globals(cd, viewport), count4=synth.count4_for(n), viewport=viewport)

@@ -128,6 +128,48 @@ def config4(ctx, iters, size=4096, n_draws=15625, cpd=10):
                 late_algorithmic_bytes=algo, late_frac=algo / k_c / 1e3 / HBM, meshlets_per_s=m / ((k_c + prof["cluster_scatter"][0] / max(1, prof["cluster_scatter"][1]) * 1e3) * 1e-6))
 
 
+def config_n4(ctx, iters, n_draws=2048, cpd=1):
+    """the mesh stage's triangle cull (meshlet.mesh.glsl with MESH_CULL = 1) over a cluster list that
+    names every meshlet of a 131 k-meshlet pool once (the list a fully visible scene would produce)"""
+    dev = ctx.device
+    draws, meshlets, commands, n = synth.cluster_scene(n_draws, cpd, seed=9, scene_radius=60.0)
+    data, vertices = synth.make_geometry(meshlets, seed=11)
+    cd = host.build_cull_data(draw_count=n_draws, viewport=(1920, 1080), cullingEnabled=1)
+    g = synth.make_globals(cd, (1920, 1080))
+    m = n * 64
+    ids = (np.arange(m, dtype=np.uint32) // 64) | ((np.arange(m, dtype=np.uint32) % 64) << 24)
+    cib = torch.from_numpy(np.concatenate([ids, np.zeros(512, np.uint32)]).view(np.int32)).to(dev)
+    ccb = torch.from_numpy(np.array([m, 0, 0, 0], np.uint32).view(np.int32)).to(dev)
+    ctx.clustersubmit(ccb, cib)
+    db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+    dd = torch.from_numpy(data.view(np.int32)).to(dev)
+    vb = P.to_device(vertices, dev)
+    slots = (m + 255) // 256 * 256
+    masks = torch.zeros(slots * 16, dtype=torch.uint8, device=dev)
+    totals = torch.zeros(3, dtype=torch.int64, device=dev)
+
+    def step(i):
+        ctx.trianglecull(g, dcb, db, mlb, dd, vb, cib, ccb, masks, slots, totals)
+
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    totals.zero_()
+    e0.record()
+    for i in range(iters):
+        step(i)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    vc, tc = meshlets["vertexCount"].astype(np.int64), meshlets["triangleCount"].astype(np.int64)
+    refs = np.where(meshlets["shortRefs"] == 1, 2, 4) * vc
+    algo = int((4 + 20 + 48 + 24 + 16) * m + refs.sum() + 3 * tc.sum() + 8 * vc.sum())
+    t = totals.cpu().numpy() // iters
+    return dict(config="N4: mesh-stage triangle cull, %d clusters" % m, clusters=int(t[0]), triangles=int(t[1]), kept=int(t[2]), call_us=us,
+                algorithmic_bytes=algo, achieved_GBs=algo / us / 1e3, frac=algo / us / 1e3 / HBM, triangles_per_s=int(t[1]) / (us * 1e-6))
+
+
 def roofline_size(ctx, iters, n_draws=156250, cpd=10, aos=False):
     """config 3A x 10 (100 M meshlets, 1.2 GB of cull bytes): HBM, not launch latency or the Infinity Cache, is the bound"""
     dev = ctx.device
@@ -159,7 +201,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     ctx = P.Context(0)
     runs = {"2": lambda: config2(ctx, a.iters), "3b": lambda: config3b(ctx, a.iters), "4": lambda: config4(ctx, a.iters),
-            "4b": lambda: config4(ctx, a.iters, size=1024),
+            "4b": lambda: config4(ctx, a.iters, size=1024), "n4": lambda: config_n4(ctx, a.iters),
             "big": lambda: roofline_size(ctx, max(5, a.iters // 3)), "big_aos": lambda: roofline_size(P.Context(0), max(5, a.iters // 3), aos=True)}
     for k, fn in runs.items():
         if a.only and k not in a.only.split(","):
