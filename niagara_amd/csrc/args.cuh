@@ -82,6 +82,7 @@ struct TriangleArgs
 	NvTriangleMask* __restrict__ masks;
 	uint32_t capacity;
 	unsigned long long* __restrict__ totals;
+	unsigned long long* __restrict__ partials; // library scratch: 3 counters per workgroup of the launch
 };
 
 } // namespace nv

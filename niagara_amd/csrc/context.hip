@@ -29,7 +29,7 @@ size_t drawcull_result_bytes(uint32_t drawCount);
 int launch_tasksubmit(hipStream_t, uint32_t* count4, NvMeshTaskCommand* commands);
 int launch_reset_count(hipStream_t, uint32_t* a, uint32_t* b);
 int launch_cluster_expand(hipStream_t, const NvMeshTaskCommand*, const NvMeshlet*, const uint32_t* clusterIndices, const uint32_t* cc4,
-                          NvClusterRecord* records, uint32_t capacity, uint64_t* totals, uint32_t gridBlocks);
+                          NvClusterRecord* records, uint32_t capacity, uint64_t* totals, unsigned long long* partials, uint32_t gridBlocks);
 int launch_clustersubmit(hipStream_t, uint32_t* cc4, uint32_t* clusterIndices);
 int launch_pack_counts(hipStream_t, const uint32_t*, const uint32_t*, const uint32_t*, uint64_t*);
 int launch_depthreduce(hipStream_t, const float* depth, uint32_t w, uint32_t h, const NvPyramidDesc& pyr);
@@ -53,6 +53,7 @@ struct nv_context
 	uint8_t* drawResults;
 	size_t drawResultsCapacity;
 	nv::ClusterCounts* drawTileCounts;
+	unsigned long long* totalsPartials; // nv_trianglecull / nv_cluster_expand: per-workgroup partial totals (3 x u64 x grid)
 	// SoA mirror of the meshlet cull bytes
 	const NvMeshlet* mirroredFrom;
 	uint32_t mirroredCount;
@@ -238,6 +239,8 @@ void nv_destroy(nv_context* ctx)
 		(void)hipFree(ctx->drawResults);
 	if (ctx->drawTileCounts)
 		(void)hipFree(ctx->drawTileCounts);
+	if (ctx->totalsPartials)
+		(void)hipFree(ctx->totalsPartials);
 	if (ctx->masks)
 		(void)hipFree(ctx->masks);
 	if (ctx->tileCounts)
@@ -524,8 +527,11 @@ int nv_cluster_expand(nv_context* ctx, void* stream, const NvMeshTaskCommand* d_
 	if (!ctx || !d_commands || !d_meshlets || !d_clusterIndices || !d_clusterCount4 || !d_totals3 || (!d_records && recordCapacity))
 		return NV_EINVAL;
 	DeviceGuard guard(ctx->device);
+	const uint32_t grid = persistent_grid(ctx, 8);
+	if (!ctx->totalsPartials && hipMalloc(&ctx->totalsPartials, (size_t)grid * 3 * sizeof(unsigned long long)) != hipSuccess)
+		return NV_ENOMEM;
 	return nv::launch_cluster_expand((hipStream_t)stream, d_commands, d_meshlets, d_clusterIndices, d_clusterCount4, d_records, recordCapacity,
-	                                 d_totals3, (uint32_t)ctx->numCUs * 8);
+	                                 d_totals3, ctx->totalsPartials, grid);
 }
 
 int nv_trianglecull(nv_context* ctx, void* stream, const NvGlobals* globals, const NvMeshTaskCommand* d_commands, const NvMeshDraw* d_draws,
@@ -548,7 +554,11 @@ int nv_trianglecull(nv_context* ctx, void* stream, const NvGlobals* globals, con
 	a.masks = d_masks;
 	a.capacity = maskCapacity;
 	a.totals = reinterpret_cast<unsigned long long*>(d_totals3);
-	return nv::launch_trianglecull((hipStream_t)stream, a, persistent_grid(ctx, 8));
+	const uint32_t grid = persistent_grid(ctx, 8);
+	if (!ctx->totalsPartials && hipMalloc(&ctx->totalsPartials, (size_t)grid * 3 * sizeof(unsigned long long)) != hipSuccess)
+		return NV_ENOMEM;
+	a.partials = ctx->totalsPartials;
+	return nv::launch_trianglecull((hipStream_t)stream, a, grid);
 }
 
 int nv_depthreduce(nv_context* ctx, void* stream, const float* d_depth, uint32_t width, uint32_t height,

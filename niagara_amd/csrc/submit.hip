@@ -82,7 +82,7 @@ int launch_reset_count(hipStream_t stream, uint32_t* a, uint32_t* b)
 // meshlet.mesh.glsl:91-116: decode of one cluster index per thread (the header part of the mesh stage)
 __global__ __launch_bounds__(256) void cluster_expand_kernel(const NvMeshTaskCommand* __restrict__ commands, const NvMeshlet* __restrict__ meshlets,
                                                             const uint32_t* __restrict__ clusterIndices, const uint32_t* __restrict__ cc4,
-                                                            NvClusterRecord* __restrict__ records, uint32_t capacity, unsigned long long* __restrict__ totals)
+                                                            NvClusterRecord* __restrict__ records, uint32_t capacity, unsigned long long* __restrict__ partials)
 {
 	// grid of the consumer: {cc4[1], cc4[2], cc4[3]} = {16, Y, 16}; index = x + 256 y + 16 z enumerates [0, 256 Y)
 	const uint32_t slots = cc4[1] * cc4[2] * cc4[3];
@@ -111,27 +111,61 @@ __global__ __launch_bounds__(256) void cluster_expand_kernel(const NvMeshTaskCom
 		if (index < capacity)
 			records[index] = r;
 	}
-	// wave reduction, one atomic per wave and total
+	// totals: wave reduction, then per-workgroup partial sums with plain stores; totals3_kernel adds them up.  (One atomic
+	// per wave into the caller's three adjacent counters — one cache line — serialises in its L2 channel.)
 	for (int o = 32; o > 0; o >>= 1)
 	{
 		clusters += __shfl_xor(clusters, o, 64);
 		vertices += __shfl_xor(vertices, o, 64);
 		triangles += __shfl_xor(triangles, o, 64);
 	}
-	if ((threadIdx.x & 63u) == 0 && clusters)
+	__shared__ unsigned long long s_tot[4][3];
+	if ((threadIdx.x & 63u) == 0)
 	{
-		atomicAdd(&totals[0], clusters);
-		atomicAdd(&totals[1], vertices);
-		atomicAdd(&totals[2], triangles);
+		s_tot[threadIdx.x >> 6][0] = clusters;
+		s_tot[threadIdx.x >> 6][1] = vertices;
+		s_tot[threadIdx.x >> 6][2] = triangles;
 	}
+	__syncthreads();
+	if (threadIdx.x < 3)
+		partials[(size_t)blockIdx.x * 3 + threadIdx.x] = s_tot[0][threadIdx.x] + s_tot[1][threadIdx.x] + s_tot[2][threadIdx.x] + s_tot[3][threadIdx.x];
+}
+
+// adds the per-workgroup partial sums of a launch to the caller's three totals (one workgroup)
+__global__ __launch_bounds__(256) void totals3_kernel(const unsigned long long* __restrict__ partials, uint32_t blocks, unsigned long long* __restrict__ totals)
+{
+	__shared__ unsigned long long s_part[4][3];
+	unsigned long long t[3] = { 0, 0, 0 };
+	for (uint32_t i = threadIdx.x; i < blocks; i += 256)
+	{
+		t[0] += partials[(size_t)i * 3];
+		t[1] += partials[(size_t)i * 3 + 1];
+		t[2] += partials[(size_t)i * 3 + 2];
+	}
+#pragma unroll
+	for (int k = 0; k < 3; ++k)
+		for (int o = 32; o > 0; o >>= 1)
+			t[k] += __shfl_xor(t[k], o, 64);
+	if ((threadIdx.x & 63u) == 0)
+		for (int k = 0; k < 3; ++k)
+			s_part[threadIdx.x >> 6][k] = t[k];
+	__syncthreads();
+	if (threadIdx.x < 3)
+		totals[threadIdx.x] += s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+}
+
+int launch_totals3(hipStream_t stream, const unsigned long long* partials, uint32_t blocks, unsigned long long* totals)
+{
+	hipLaunchKernelGGL(totals3_kernel, dim3(1), dim3(256), 0, stream, partials, blocks, totals);
+	return (int)hipGetLastError();
 }
 
 int launch_cluster_expand(hipStream_t stream, const NvMeshTaskCommand* commands, const NvMeshlet* meshlets, const uint32_t* clusterIndices,
-                          const uint32_t* cc4, NvClusterRecord* records, uint32_t capacity, uint64_t* totals, uint32_t gridBlocks)
+                          const uint32_t* cc4, NvClusterRecord* records, uint32_t capacity, uint64_t* totals, unsigned long long* partials,
+                          uint32_t gridBlocks)
 {
-	hipLaunchKernelGGL(cluster_expand_kernel, dim3(gridBlocks), dim3(256), 0, stream, commands, meshlets, clusterIndices, cc4, records, capacity,
-	                   reinterpret_cast<unsigned long long*>(totals));
-	return (int)hipGetLastError();
+	hipLaunchKernelGGL(cluster_expand_kernel, dim3(gridBlocks), dim3(256), 0, stream, commands, meshlets, clusterIndices, cc4, records, capacity, partials);
+	return launch_totals3(stream, partials, gridBlocks, reinterpret_cast<unsigned long long*>(totals));
 }
 
 int launch_tasksubmit(hipStream_t stream, uint32_t* count4, NvMeshTaskCommand* commands)
