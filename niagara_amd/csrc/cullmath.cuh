@@ -247,18 +247,81 @@ NV_DEV float sample_min(const NvPyramidDesc& p, float u, float v, float level)
 	return sample_min_image(p.d_base + p.mipOffset[l], mip_dim(p.width, (uint32_t)l), mip_dim(p.height, (uint32_t)l), u, v);
 }
 
-// drawcull.comp.glsl:86-99 / clustercull.comp.glsl:110-123: returns the sphere's visibility against the pyramid
-NV_DEV bool hiz_test(const NvCullData& cd, const NvPyramidDesc& pyr, f3 c, float r)
+// The HiZ test in two halves, so that a caller can put other work between requesting the (up to) four texels and
+// comparing them (clustercull.hip's late pass).  hiz_prepare: projection, mip selection and the footprint's texel
+// offsets relative to the pyramid base; hiz_finish: MIN over the texels that carry weight, in the oracle's order
+// (x0,y0) (x1,y0) (x0,y1) (x1,y1), and the comparison.  Offsets are always in range (clamped), also for an inactive probe.
+struct HizProbe
 {
+	uint32_t o00, o10, o01, o11; // texel offsets (floats) from pyr.d_base
+	uint32_t use;                // bit 0..3: the texel carries weight; bit 4: the probe is active (projectSphere succeeded)
+	float depthSphere;
+};
+
+NV_DEV HizProbe hiz_prepare(const NvCullData& cd, const NvPyramidDesc& pyr, f3 c, float r)
+{
+	HizProbe p = { 0, 0, 0, 0, 0, 0.0f };
 	float aabb[4];
 	if (project_sphere(c, r, cd.znear, cd.P00, cd.P11, aabb))
 	{
-		float level = occlusion_mip(aabb, cd.pyramidWidth, cd.pyramidHeight);
-		float depth = sample_min(pyr, (aabb[0] + aabb[2]) * 0.5f, (aabb[1] + aabb[3]) * 0.5f, level);
-		float depthSphere = cd.znear / (c.z - r);
-		return depthSphere > depth;
+		const float level = occlusion_mip(aabb, cd.pyramidWidth, cd.pyramidHeight);
+		int l = (int)level;
+		const int top = (int)pyr.levels - 1;
+		l = l < 0 ? 0 : (l > top ? top : l);
+		const uint32_t w = mip_dim(pyr.width, (uint32_t)l), h = mip_dim(pyr.height, (uint32_t)l);
+		const float u = (aabb[0] + aabb[2]) * 0.5f, v = (aabb[1] + aabb[3]) * 0.5f;
+		int x0, x1, y0, y1;
+		bool ux0, ux1, uy0, uy1;
+		footprint(u * (float)w - 0.5f, w, x0, x1, ux0, ux1);
+		footprint(v * (float)h - 0.5f, h, y0, y1, uy0, uy1);
+		const uint32_t base = pyr.mipOffset[l];
+		p.o00 = base + (uint32_t)y0 * w + (uint32_t)x0;
+		p.o10 = base + (uint32_t)y0 * w + (uint32_t)x1;
+		p.o01 = base + (uint32_t)y1 * w + (uint32_t)x0;
+		p.o11 = base + (uint32_t)y1 * w + (uint32_t)x1;
+		p.use = (ux0 && uy0 ? 1u : 0u) | (ux1 && uy0 ? 2u : 0u) | (ux0 && uy1 ? 4u : 0u) | (ux1 && uy1 ? 8u : 0u) | 16u;
+		p.depthSphere = cd.znear / (c.z - r);
 	}
-	return true;
+	return p;
+}
+
+NV_DEV bool hiz_finish(const HizProbe& p, float t00, float t10, float t01, float t11)
+{
+	if (!(p.use & 16u))
+		return true;
+	float best = 0.0f;
+	bool have = false;
+	if (p.use & 1u)
+	{
+		best = t00;
+		have = true;
+	}
+	if (p.use & 2u)
+	{
+		best = have ? gl_min(best, t10) : t10;
+		have = true;
+	}
+	if (p.use & 4u)
+	{
+		best = have ? gl_min(best, t01) : t01;
+		have = true;
+	}
+	if (p.use & 8u)
+	{
+		best = have ? gl_min(best, t11) : t11;
+		have = true;
+	}
+	return p.depthSphere > best;
+}
+
+// drawcull.comp.glsl:86-99 / clustercull.comp.glsl:110-123: returns the sphere's visibility against the pyramid
+NV_DEV bool hiz_test(const NvCullData& cd, const NvPyramidDesc& pyr, f3 c, float r)
+{
+	const HizProbe p = hiz_prepare(cd, pyr, c, r);
+	if (!(p.use & 16u))
+		return true;
+	const float* base = pyr.d_base;
+	return hiz_finish(p, base[p.o00], base[p.o10], base[p.o01], base[p.o11]);
 }
 
 // fp16 bits -> fp32 (exact)
