@@ -774,8 +774,11 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 			// ---- per-segment scalar summaries (one ballot each) so that the walk needs no per-command v_readlane for
 			// control: which commands are full (64 meshlets), empty (dummy), or start a new draw
 			const uint64_t fullMask = __ballot(r.taskCount >= 64u);
-			const uint32_t prevDraw = __shfl_up(r.drawId, 1, 64);
-			const uint64_t changeMask = __ballot(lane == 0 || r.drawId != prevDraw) | 1ull;
+			// "the draw changes" must be judged on the draw whose filter the lane actually holds: an empty command
+			// (taskCount 0) gathered draw 0 above, whatever its drawId says (tests/test_special_values.py)
+			const uint32_t heldDraw = r.taskCount ? r.drawId : 0u;
+			const uint32_t prevDraw = __shfl_up(heldDraw, 1, 64);
+			const uint64_t changeMask = __ballot(lane == 0 || heldDraw != prevDraw) | 1ull;
 			const uint32_t base8 = (r.taskCount ? r.taskOffset : 0u) * 8u; // lane-parallel: byte offset of each command's bounds
 			const uint32_t lane8 = lane * 8u;
 

@@ -59,15 +59,27 @@ def flag_matrix():
 
 
 def make_triangle_scene(seed=0, n_draws=60, commands_per_draw=3, viewport=(640, 480), scene_radius=20.0, cam_pos=(0, 0, 0), cam_quat=(0, 0, 0, 1),
-                        full_meshlets=False):
+                        full_meshlets=False, specials=False):
     """Inputs of the mesh stage's triangle cull: a config-3 style cluster scene plus synthetic meshlet
     payloads (vertex references, index bytes, fp16 vertices).  The cluster list is NOT part of the scene: the caller
     produces it with the implementation under test (clustercull -> clustersubmit)."""
     from niagara_amd import host, synth
     draws, meshlets, commands, n = synth.cluster_scene(n_draws, commands_per_draw, seed=seed, scene_radius=scene_radius)
     data, vertices = synth.make_geometry(meshlets, seed=seed + 1000)
-    if full_meshlets:  # every meshlet at the limits MESH_MAXVTX / MESH_MAXTRI would need re-packing: keep a few instead
-        pass
+    if specials:  # every fp16 class in the vertex stream (NaN, inf, denormals, -0) and non-finite / zero / negative draw fields
+        rng = np.random.default_rng(seed + 5)
+        raw = rng.random(len(vertices)) < 0.2
+        for f in ("vx", "vy", "vz"):
+            vertices[f][raw] = rng.integers(0, 1 << 16, int(raw.sum())).astype(np.uint16)
+        sp = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-42, 3.4e38, -1.0], np.float32)
+        for i in np.nonzero(rng.random(n_draws) < 0.3)[0]:
+            k = rng.integers(0, 3)
+            if k == 0:
+                draws["position"][i][rng.integers(0, 3)] = rng.choice(sp)
+            elif k == 1:
+                draws["scale"][i] = rng.choice(sp)
+            else:
+                draws["orientation"][i][rng.integers(0, 4)] = rng.choice(sp)
     cd = host.build_cull_data(cam_pos=cam_pos, cam_quat=cam_quat, draw_count=n_draws, viewport=viewport, cullingEnabled=1, clusterBackfaceEnabled=0)
     return dict(draws=draws, meshlets=meshlets, commands=commands, n=n, cull=cd, data=data, vertices=vertices,
                 globals=synth.make_globals(cd, viewport), count4=synth.count4_for(n), viewport=viewport)

@@ -22,6 +22,7 @@ def cluster_list(impl, s, backface=0):
     """clustercull<LATE=0> -> clustersubmit with `impl` (oracle or oracle.ref): the consumer's grid and index list"""
     cd = s["cull"].copy()
     cd["clusterBackfaceEnabled"] = backface
+    cd["cullingEnabled"] = 1
     cib = np.zeros(s["n"] * 64 + 256, np.uint32)
     cc4 = np.zeros(4, np.uint32)
     impl.clustercull(cd, 0, s["commands"], s["count4"], s["draws"], s["meshlets"], None, None, cib, cc4)
@@ -38,7 +39,8 @@ def run(fn, s, cib, cc4):
 
 
 CAMERAS = [dict(), dict(cam_pos=(3.0, -2.0, 5.0), cam_quat=(0.0, 0.3826834, 0.0, 0.9238795)), dict(cam_pos=(0, 0, -8.0), viewport=(1920, 1080)),
-           dict(scene_radius=3.0)]  # the last one puts the camera inside the cloud: vertices behind the perspective plane
+           dict(scene_radius=3.0),  # puts the camera inside the cloud: vertices behind the perspective plane
+           dict(scene_radius=6.0, specials=True)]  # NaN / inf / denormal vertices, non-finite draw fields
 
 
 @pytest.mark.skipif(not R.available(), reason="oracle/_ref not built (no reference tree and no prebuilt .so)")
