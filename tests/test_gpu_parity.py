@@ -239,6 +239,21 @@ def test_config3_full_size_bit_identical_and_properties(ctx):
     assert total == total_o and (ids == cib_o[:total_o]).all()
 
 
+@pytest.mark.parametrize("draws_, cpd", [(3000, 10), (39062, 10), (7000, 37)])
+def test_other_sizes_take_other_dealing_paths(ctx, draws_, cpd):
+    """The cull kernel deals its work differently by size (even dealing for tiny and huge passes, generation-weighted
+    rounds in between, 4- or 8-deep filter ring from the previous pass's count): 1.9 M, 25 M and 16.6 M meshlets against
+    the multithreaded oracle, twice each so that both ring depths run."""
+    draws, meshlets, commands, n, cd = _cluster_inputs(draws_, cpd)
+    c4 = synth.count4_for(n)
+    cib_o, cc4_o = np.zeros(n * 64, np.uint32), np.zeros(4, np.uint32)
+    oracle.clustercull(cd, 0, commands, c4, draws, meshlets, None, None, cib_o, cc4_o, threads=oracle.max_threads())
+    total_o = int(cc4_o[0])
+    for total, ids in _gpu_clustercull(ctx, draws, meshlets, commands, n, cd, repeats=2):
+        assert total == total_o
+        assert (ids == cib_o[:total_o]).all()
+
+
 def test_ragged_command_counts_and_dummy_commands(ctx):
     """taskCount < 64, unaligned taskOffset / visibility offsets, and the zeroed dummy commands tasksubmit pads with"""
     rng = np.random.default_rng(77)
