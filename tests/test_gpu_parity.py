@@ -254,6 +254,19 @@ def test_other_sizes_take_other_dealing_paths(ctx, draws_, cpd):
         assert (ids == cib_o[:total_o]).all()
 
 
+def test_100m_meshlets_full_list(ctx):
+    """the roofline size of DESIGN.md (config 3A x 10 = BASELINE config 5's whole pool on one GPU): 100 M meshlets,
+    1.56 M task commands, full visible list against the multithreaded oracle"""
+    draws, meshlets, commands, n, cd = _cluster_inputs(156250, 10)
+    assert n * 64 == 100_000_000
+    c4 = synth.count4_for(n)
+    cib_o, cc4_o = np.zeros(n * 64, np.uint32), np.zeros(4, np.uint32)
+    oracle.clustercull(cd, 0, commands, c4, draws, meshlets, None, None, cib_o, cc4_o, threads=oracle.max_threads())
+    total_o = int(cc4_o[0])
+    (total, ids), = _gpu_clustercull(ctx, draws, meshlets, commands, n, cd)
+    assert total == total_o and (ids == cib_o[:total_o]).all()
+
+
 def test_ragged_command_counts_and_dummy_commands(ctx):
     """taskCount < 64, unaligned taskOffset / visibility offsets, and the zeroed dummy commands tasksubmit pads with"""
     rng = np.random.default_rng(77)
