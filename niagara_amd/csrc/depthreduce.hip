@@ -39,7 +39,10 @@ struct ChainArgs
 	uint32_t mipOffset[NV_MAX_MIPS];
 };
 
-NV_DEV float min4(float a, float b, float c, float d) { return gl_min(gl_min(a, b), gl_min(c, d)); }
+// MIN over a 2 x 2 footprint in the sampler's defined order (x0,y0) (x1,y0) (x0,y1) (x1,y1), as a chain: min(x, y) =
+// y < x ? y : x is neither commutative nor associative once NaN or -0 / +0 are among the texels, and the pyramid must
+// be bit-identical for those too (tests/test_special_values.py)
+NV_DEV float min4(float a, float b, float c, float d) { return gl_min(gl_min(gl_min(a, b), c), d); }
 
 __global__ __launch_bounds__(256) void reduce_chain_kernel(ChainArgs a)
 {
@@ -253,9 +256,8 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(ChainArgs a)
 	if (a.numLevels < 3)
 		return;
 
-	// level L+2: lane pairs
-	float t = gl_min(h[0], h[1]);
-	t = gl_min(t, __shfl_xor(t, 1, 64));
+	// level L+2: lane pairs; (x0,y0) = even lane's h[0], (x1,y0) = odd lane's h[0], (x0,y1) = even h[1], (x1,y1) = odd h[1]
+	const float t = min4(h[0], __shfl_xor(h[0], 1, 64), h[1], __shfl_xor(h[1], 1, 64)); // meaningful on even lanes
 	if ((lane & 1u) == 0)
 	{
 		const uint32_t lw = a.sw / 8;
@@ -277,8 +279,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(ChainArgs a)
 		}
 		if (a.numLevels >= 5)
 		{
-			m = gl_min(m, __shfl_xor(m, 1, 64));
-			m = gl_min(m, __shfl_xor(m, 16, 64));
+			m = min4(m, __shfl_xor(m, 1, 64), __shfl_xor(m, 16, 64), __shfl_xor(m, 17, 64)); // meaningful on lanes y == 0, x even
 			if (y == 0 && (x & 1u) == 0)
 			{
 				const uint32_t lw = a.sw / 32;

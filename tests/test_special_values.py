@@ -165,3 +165,46 @@ def test_drawcull_hip_equals_oracle_on_special_values(seed, late, task):
         assert (G.host_u32(dvb) == dvo).all()
     finally:
         ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------------------- depthreduce
+def special_depth(w, h, seed):
+    rng = np.random.default_rng(seed)
+    d = rng.random((h, w)).astype(np.float32)
+    k = rng.random((h, w))
+    d[k < 0.02] = np.nan
+    d[(k >= 0.02) & (k < 0.04)] = np.inf
+    d[(k >= 0.04) & (k < 0.06)] = -np.inf
+    d[(k >= 0.06) & (k < 0.08)] = -0.0
+    d[(k >= 0.08) & (k < 0.10)] = 1e-42
+    return d
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref not built (no reference tree and no prebuilt .so)")
+@pytest.mark.parametrize("size", [(64, 64), (100, 75), (512, 256), (33, 2)])
+def test_depthreduce_oracle_equals_reference_with_nonfinite_depth(size):
+    """min(x, y) = y < x ? y : x keeps x when y is NaN: which NaNs survive a level depends on the operand order"""
+    w, h = size
+    depth = special_depth(w, h, w * 7 + h)
+    po, pr = oracle.Pyramid(w, h), oracle.Pyramid(w, h)
+    oracle.depthreduce(depth, po)
+    R.depthreduce(depth, pr)
+    assert po.data.tobytes() == pr.data.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(64, 64), (100, 75), (512, 256), (33, 2), (1024, 512), (4096, 4096)])
+def test_depthreduce_hip_equals_oracle_with_nonfinite_depth(size):
+    import torch
+    from niagara_amd import pipeline as P
+    w, h = size
+    depth = special_depth(w, h, w * 7 + h)
+    po = oracle.Pyramid(w, h)
+    oracle.depthreduce(depth, po)
+    ctx = P.Context()
+    try:
+        pg = P.DepthPyramid(ctx.device, w, h)
+        ctx.depthreduce(torch.from_numpy(depth).to(ctx.device), w, h, pg.desc)
+        assert pg.data.cpu().numpy().tobytes() == po.data.tobytes()
+    finally:
+        ctx.close()
