@@ -13,6 +13,18 @@ from niagara_amd import layouts as L
 SPECIAL = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-42, -1e-42, 3.4e38, -3.4e38, 1.0, -1.0, 65504.0], np.float32)
 
 
+def special_depth(w, h, seed):
+    rng = np.random.default_rng(seed)
+    d = rng.random((h, w)).astype(np.float32)
+    k = rng.random((h, w))
+    d[k < 0.02] = np.nan
+    d[(k >= 0.02) & (k < 0.04)] = np.inf
+    d[(k >= 0.04) & (k < 0.06)] = -np.inf
+    d[(k >= 0.06) & (k < 0.08)] = -0.0
+    d[(k >= 0.08) & (k < 0.10)] = 1e-42
+    return d
+
+
 def special_scene(seed, n_draws=48, cpd=2):
     rng = np.random.default_rng(seed)
     draws, meshlets, commands, n = synth.cluster_scene(n_draws, cpd, seed=seed, scene_radius=15.0)
@@ -39,6 +51,9 @@ def special_scene(seed, n_draws=48, cpd=2):
     mvb = rng.integers(0, 2 ** 32, slots // 32 + 2, dtype=np.uint64).astype(np.uint32)
     commands["lateDrawVisibility"][:n] = rng.integers(0, 2, n)
     depth = synth.make_depth(256, 192, seed=seed)
+    bad = special_depth(256, 192, seed)  # NaN / inf / -0 texels among the occluders: the HiZ comparison must agree on them too
+    k = np.random.default_rng(seed + 1).random((192, 256)) < 0.15
+    depth[k] = bad[k]
     return dict(draws=draws, meshlets=meshlets, commands=commands, n=n, cull=cd, mvb=mvb, depth=depth, count4=synth.count4_for(n))
 
 
@@ -115,6 +130,11 @@ def special_draw_scene(seed):
     m["lods"][3][2]["error"] = np.nan
     m["lods"][3][3]["error"] = -np.inf
     scene["dvb0"] = rng.integers(0, 2, len(d)).astype(np.uint32)
+    w, h = scene["viewport"]
+    bad = special_depth(w, h, seed)
+    k = rng.random((h, w)) < 0.15
+    scene["depth"] = scene["depth"].copy()
+    scene["depth"][k] = bad[k]
     return scene
 
 
@@ -168,18 +188,6 @@ def test_drawcull_hip_equals_oracle_on_special_values(seed, late, task):
 
 
 # ------------------------------------------------------------------------------------------------------------- depthreduce
-def special_depth(w, h, seed):
-    rng = np.random.default_rng(seed)
-    d = rng.random((h, w)).astype(np.float32)
-    k = rng.random((h, w))
-    d[k < 0.02] = np.nan
-    d[(k >= 0.02) & (k < 0.04)] = np.inf
-    d[(k >= 0.04) & (k < 0.06)] = -np.inf
-    d[(k >= 0.06) & (k < 0.08)] = -0.0
-    d[(k >= 0.08) & (k < 0.10)] = 1e-42
-    return d
-
-
 @pytest.mark.skipif(not R.available(), reason="oracle/_ref not built (no reference tree and no prebuilt .so)")
 @pytest.mark.parametrize("size", [(64, 64), (100, 75), (512, 256), (33, 2)])
 def test_depthreduce_oracle_equals_reference_with_nonfinite_depth(size):
