@@ -57,10 +57,11 @@ def special_scene(seed, n_draws=48, cpd=2):
     return dict(draws=draws, meshlets=meshlets, commands=commands, n=n, cull=cd, mvb=mvb, depth=depth, count4=synth.count4_for(n))
 
 
-def run_cpu(impl, s, late):
+def run_cpu(impl, s, late, post_pass=0):
     pyr = oracle.Pyramid(256, 192)
     impl.depthreduce(s["depth"], pyr)
     cd = s["cull"].copy()
+    cd["postPass"] = post_pass
     cd["pyramidWidth"], cd["pyramidHeight"] = pyr.width, pyr.height
     cib = np.zeros(s["n"] * 64 + 256, np.uint32)
     cc4 = np.zeros(4, np.uint32)
@@ -72,10 +73,11 @@ def run_cpu(impl, s, late):
 @pytest.mark.skipif(not R.available(), reason="oracle/_ref not built (no reference tree and no prebuilt .so)")
 @pytest.mark.parametrize("seed", range(6))
 @pytest.mark.parametrize("late", [0, 1])
-def test_oracle_equals_reference_on_special_values(seed, late):
+@pytest.mark.parametrize("post_pass", [0, 1])
+def test_oracle_equals_reference_on_special_values(seed, late, post_pass):
     s = special_scene(900 + seed)
-    co, io, mo, _, _ = run_cpu(oracle, s, late)
-    cr, ir, mr, _, _ = run_cpu(R, s, late)
+    co, io, mo, _, _ = run_cpu(oracle, s, late, post_pass)
+    cr, ir, mr, _, _ = run_cpu(R, s, late, post_pass)
     assert co.tolist() == cr.tolist()
     assert (io == ir).all()
     assert (mo == mr).all()
@@ -85,11 +87,12 @@ def test_oracle_equals_reference_on_special_values(seed, late):
 @pytest.mark.parametrize("seed", range(6))
 @pytest.mark.parametrize("late", [0, 1])
 @pytest.mark.parametrize("soa", [True, False])
-def test_hip_equals_oracle_on_special_values(seed, late, soa):
+@pytest.mark.parametrize("post_pass", [0, 1])
+def test_hip_equals_oracle_on_special_values(seed, late, soa, post_pass):
     import torch
     from niagara_amd import pipeline as P
     s = special_scene(900 + seed)
-    co, io, mo, cd, pyr = run_cpu(oracle, s, late)
+    co, io, mo, cd, pyr = run_cpu(oracle, s, late, post_pass)
     ctx = P.Context()
     try:
         dev = ctx.device
