@@ -219,3 +219,62 @@ def test_depthreduce_hip_equals_oracle_with_nonfinite_depth(size):
         assert pg.data.cpu().numpy().tobytes() == po.data.tobytes()
     finally:
         ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------------ degenerate cameras
+WEIRD_CAMERAS = ["nan_view", "inf_translation", "zero_frustum", "inverted_near_far", "huge_scale_view"]
+
+
+def weird_camera(cd, case):
+    cd = cd.copy()
+    if case == "nan_view":
+        cd["view"][0][5] = np.nan
+    elif case == "inf_translation":
+        cd["view"][0][14] = np.inf
+    elif case == "zero_frustum":
+        cd["frustum"][0][:] = 0
+    elif case == "inverted_near_far":
+        cd["znear"], cd["zfar"] = 50.0, 0.01
+    elif case == "huge_scale_view":
+        cd["view"][0][:12] *= np.float32(1e30)
+    return cd
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref not built (no reference tree and no prebuilt .so)")
+@pytest.mark.parametrize("case", WEIRD_CAMERAS)
+@pytest.mark.parametrize("late", [0, 1])
+def test_oracle_equals_reference_with_degenerate_cameras(case, late):
+    s = special_scene(950)
+    s["cull"] = weird_camera(s["cull"], case)
+    co, io, mo, _, _ = run_cpu(oracle, s, late)
+    cr, ir, mr, _, _ = run_cpu(R, s, late)
+    assert co.tolist() == cr.tolist() and (io == ir).all() and (mo == mr).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", WEIRD_CAMERAS)
+@pytest.mark.parametrize("late", [0, 1])
+def test_hip_equals_oracle_with_degenerate_cameras(case, late):
+    import torch
+    from niagara_amd import pipeline as P
+    s = special_scene(950)
+    s["cull"] = weird_camera(s["cull"], case)
+    co, io, mo, cd, pyr = run_cpu(oracle, s, late)
+    ctx = P.Context()
+    try:
+        dev = ctx.device
+        gp = P.DepthPyramid(dev, 256, 192)
+        ctx.depthreduce(torch.from_numpy(s["depth"]).to(dev), 256, 192, gp.desc)
+        db, mlb, dcb = P.to_device(s["draws"], dev), P.to_device(s["meshlets"], dev), P.to_device(s["commands"], dev)
+        ctx.upload_meshlets(mlb, len(s["meshlets"]))
+        dccb = torch.from_numpy(s["count4"].view(np.int32).copy()).to(dev)
+        mvb = torch.from_numpy(s["mvb"].view(np.int32).copy()).to(dev)
+        cib = torch.zeros(s["n"] * 64 + 256, dtype=torch.int32, device=dev)
+        ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+        ctx.clustercull(cd, late, dcb, dccb, db, mlb, mvb, gp.desc, cib, ccb)
+        total = int(ccb[0].item())
+        assert total == int(co[0])
+        assert (cib.cpu().numpy().view(np.uint32)[:total] == io).all()
+        assert (mvb.cpu().numpy().view(np.uint32) == mo).all()
+    finally:
+        ctx.close()
