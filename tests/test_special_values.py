@@ -278,3 +278,45 @@ def test_hip_equals_oracle_with_degenerate_cameras(case, late):
         assert (mvb.cpu().numpy().view(np.uint32) == mo).all()
     finally:
         ctx.close()
+
+
+# --------------------------------------------------------------------------------------------- magnitudes (filter error bound)
+MAGNITUDES = [(1e4, 1.0, 1e9), (1.0, 1e-4, 200.0), (1e4, 1e3, 1e9), (1e-3, 1e-3, 200.0), (3e5, 1e-2, 1e9)]
+
+
+def magnitude_scene(case, seed=31):
+    pos_scale, draw_scale, zfar = MAGNITUDES[case]
+    draws, meshlets, commands, n = synth.cluster_scene(400, 4, seed=seed, scene_radius=30.0)
+    draws["position"] *= np.float32(pos_scale)
+    draws["scale"] *= np.float32(draw_scale)
+    cd = host.build_cull_data(draw_count=len(draws), cullingEnabled=1, clusterBackfaceEnabled=1)
+    cd["zfar"] = zfar
+    return draws, meshlets, commands, n, cd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(MAGNITUDES)))
+def test_filter_is_exact_across_magnitudes(case):
+    """the conservative frustum filter's error bound scales with the draw's position and scale: scenes 1e-3 .. 3e5 units
+    across, scales 1e-4 .. 1e3, with and without the filter, against the oracle"""
+    import torch
+    from niagara_amd import pipeline as P
+    draws, meshlets, commands, n, cd = magnitude_scene(case)
+    c4 = synth.count4_for(n)
+    cib_o, cc4_o = np.zeros(n * 64, np.uint32), np.zeros(4, np.uint32)
+    oracle.clustercull(cd, 0, commands, c4, draws, meshlets, None, None, cib_o, cc4_o)
+    total_o = int(cc4_o[0])
+    ctx = P.Context()
+    try:
+        dev = ctx.device
+        db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+        ctx.upload_meshlets(mlb, len(meshlets))
+        dccb = torch.from_numpy(c4.view(np.int32).copy()).to(dev)
+        cib = torch.zeros(n * 64 + 256, dtype=torch.int32, device=dev)
+        ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+        ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
+        total = int(ccb[0].item())
+        assert total == total_o
+        assert (cib.cpu().numpy().view(np.uint32)[:total] == cib_o[:total_o]).all()
+    finally:
+        ctx.close()
