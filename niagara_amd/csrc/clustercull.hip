@@ -296,8 +296,11 @@ NV_DEV uint32_t load_mvb_word(const ClusterArgs& a, uint32_t meshletVisibilityOf
 
 NV_DEV uint32_t indirect_command_count(const ClusterArgs& a)
 {
-	// vkCmdDispatchIndirect(dccb, 4): grid = (groupCountX, 64, 1), commandId = x*64 + y (clustercull.comp.glsl:59)
-	return a.commandCountOverride ? a.commandCountOverride : a.count4[1] * 64u;
+	// vkCmdDispatchIndirect(dccb, 4): grid = (groupCountX, 64, 1), commandId = x*64 + y (clustercull.comp.glsl:59).
+	// groupCountX is at most 65535 in a valid dispatch (tasksubmit.comp.glsl:36 clamps to it; maxComputeWorkGroupCount);
+	// a larger word is clamped rather than trusted, because the ballot scratch is sized for TASK_WGLIMIT commands
+	const uint32_t groups = a.count4[1] < 65535u ? a.count4[1] : 65535u;
+	return a.commandCountOverride ? a.commandCountOverride : groups * 64u;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(TC_THREADS) void trianglecull_kernel(TriangleArgs a
 					{
 						const uint32_t i = round * 64u + lane;
 						bool keep = false;
-						if (i < tc[k])
+						if (i < tc[k] && i < 96u) // MESH_MAXTRI: a larger count is malformed input; the mask has 96 bits (oracle: same clamp)
 						{
 							const uint32_t ia = idx8[i * 3], ib = idx8[i * 3 + 1], ic = idx8[i * 3 + 2];
 							const float4 pa = clipv[ia & 63u], pb = clipv[ib & 63u], pc = clipv[ic & 63u];
