@@ -190,6 +190,12 @@ int nv_profile_read(nv_context* ctx, float out_ms[NV_PROF_SLOTS], uint32_t out_c
  * the launch boundary that goes with it.  With 0 the reference contract holds: the append starts at the value found in
  * the count word, which the caller zeroes (nv_reset_count or any memset). */
 #define NV_OPT_FUSED_COUNT_RESET 1
+/* NV_OPT_FUSED_SUBMIT (default 0): when 1, nv_drawcull (task = 1) also leaves what tasksubmit.comp.glsl:27-47 writes — the
+ * {X, 64, 1} dispatch words and the zeroed dummy commands up to the next multiple of 64 — and nv_clustercull what
+ * clustersubmit.comp.glsl:25-45 writes (the {16, Y, 16} words and the ~0 padding up to the next multiple of 256): the
+ * last workgroup of their scatter launches knows the final count.  nv_tasksubmit / nv_clustersubmit can then be
+ * skipped (calling them anyway is harmless: they are idempotent); two launches less per frame phase. */
+#define NV_OPT_FUSED_SUBMIT 2
 int nv_set_option(nv_context* ctx, int option, int value);
 
 /* ---- scene upload hook (next to uploadBuffer(mlb), src/niagara.cpp:1055) ----

@@ -49,6 +49,7 @@ struct ClusterArgs
 	float* __restrict__ probeOut;
 	uint32_t debugMode; // tuning experiments only (NV_DEBUG_MODE); 0 in production
 	uint32_t fusedReset; // NV_OPT_FUSED_COUNT_RESET
+	uint32_t fusedSubmit; // NV_OPT_FUSED_SUBMIT
 };
 
 struct DrawArgs
@@ -64,6 +65,7 @@ struct DrawArgs
 	ClusterCounts* tileCounts; // per-scatter-tile command counts (own instance, same two-bank scheme as clustercull)
 	uint32_t scatterTiles;     // grid of the scatter kernel (<= CC_MAX_SCATTER_TILES)
 	uint32_t fusedReset; // NV_OPT_FUSED_COUNT_RESET
+	uint32_t fusedSubmit; // NV_OPT_FUSED_SUBMIT
 	uint32_t meshCount;  // > 0 when nv_upload_meshes registered `meshes`: the table may be staged in LDS
 	uint32_t debugMode;  // tuning experiments only (NV_DEBUG_MODE); 0 in production
 };

@@ -1069,7 +1069,25 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs
 	for (uint32_t i = tile * CC_THREADS + tid; i < CC_MAX_SCATTER_TILES; i += gridDim.x * CC_THREADS)
 		a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE] = 0;
 	if (tile == 0 && tid == 0)
+	{
 		a.tileCounts->parity = bank ^ 1u;
+		if (numTiles == 0) // no commands at all: the count word keeps its base, the submit words describe an empty grid
+		{
+			if (a.fusedReset)
+				a.clusterCount4[0] = 0;
+			if (a.fusedSubmit)
+			{
+				const uint32_t raw = a.fusedReset ? 0u : a.clusterCount4[0];
+				const uint32_t count = raw < NV_CLUSTER_LIMIT ? raw : NV_CLUSTER_LIMIT;
+				const uint32_t gy = (count + 255u) / 256u;
+				a.clusterCount4[1] = NV_CLUSTER_TILE;
+				a.clusterCount4[2] = gy < 65535u ? gy : 65535u;
+				a.clusterCount4[3] = 256u / NV_CLUSTER_TILE;
+				for (uint32_t i = count; i < ((count + 255u) & ~255u); ++i)
+					a.clusterIndices[i] = ~0u;
+			}
+		}
+	}
 	if (tile >= numTiles)
 		return;
 
@@ -1098,6 +1116,22 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs
 	}
 	if (tid == 0 && tile == numTiles - 1)
 		a.clusterCount4[0] = total; // what the chain of atomicAdds leaves in clusterCount
+	if (a.fusedSubmit && tile == numTiles - 1)
+	{
+		// NV_OPT_FUSED_SUBMIT: clustersubmit.comp.glsl:25-45 from the workgroup that knows the final count.  The padding
+		// slots [count, next multiple of 256) are past every survivor, so no other workgroup writes there.
+		const uint32_t count = total < NV_CLUSTER_LIMIT ? total : NV_CLUSTER_LIMIT;
+		if (tid == 0)
+		{
+			const uint32_t gy = (count + 255u) / 256u;
+			a.clusterCount4[1] = NV_CLUSTER_TILE;
+			a.clusterCount4[2] = gy < 65535u ? gy : 65535u;
+			a.clusterCount4[3] = 256u / NV_CLUSTER_TILE;
+		}
+		const uint32_t boundary = (count + 255u) & ~255u;
+		if (count + tid < boundary)
+			a.clusterIndices[count + tid] = ~0u;
+	}
 
 	// ---- ordered scatter, 1024 commands per step: one scan per step, then one command per iteration for the
 	// (coalesced) stores; clustercull.comp.glsl:137-138 drops entries past CLUSTER_LIMIT

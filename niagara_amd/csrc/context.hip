@@ -71,6 +71,7 @@ struct nv_context
 	volatile uint32_t* hintHost;
 	uint32_t* hintDevice;
 	uint32_t fusedReset;
+	uint32_t fusedSubmit;
 	// nv_profile_*: event pairs recorded on the launch stream, drained by nv_profile_read
 	int profiling;
 	std::vector<ProfRecord>* prof;
@@ -275,6 +276,9 @@ int nv_set_option(nv_context* ctx, int option, int value)
 	case NV_OPT_FUSED_COUNT_RESET:
 		ctx->fusedReset = value ? 1u : 0u;
 		return NV_OK;
+	case NV_OPT_FUSED_SUBMIT:
+		ctx->fusedSubmit = value ? 1u : 0u;
+		return NV_OK;
 	default:
 		return NV_EINVAL;
 	}
@@ -407,6 +411,7 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 	a.scatterTiles = scatter_grid(ctx);
 	a.debugMode = ctx->debugMode;
 	a.fusedReset = ctx->fusedReset;
+	a.fusedSubmit = ctx->fusedSubmit;
 	a.meshCount = ctx->meshesFrom == d_meshes ? ctx->meshCount : 0u;
 	hipEvent_t e0 = prof_mark(ctx, (hipStream_t)stream);
 	rc = nv::launch_drawcull((hipStream_t)stream, a, late, task);
@@ -476,6 +481,7 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	a.clusterCount4 = d_clusterCount4;
 	a.debugMode = ctx->debugMode;
 	a.fusedReset = ctx->fusedReset;
+	a.fusedSubmit = ctx->fusedSubmit;
 	if (ctx->debugMode & 8u)
 	{
 		if (!ctx->timing)

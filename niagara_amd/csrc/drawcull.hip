@@ -326,6 +326,17 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 		a.tileCounts->parity = bank ^ 1u;
 		if (numTiles == 0 && a.fusedReset)
 			a.count4[0] = 0; // no draws: the fused reset still leaves a zero count
+		if (numTiles == 0 && TASK && a.fusedSubmit)
+		{
+			const uint32_t raw = a.fusedReset ? 0u : a.count4[0];
+			const uint32_t count = raw < NV_TASK_WGLIMIT ? raw : NV_TASK_WGLIMIT;
+			const uint32_t gx = (count + 63u) / 64u;
+			a.count4[1] = gx < 65535u ? gx : 65535u;
+			a.count4[2] = 64;
+			a.count4[3] = 1;
+			for (uint32_t i = count; i < ((count + 63u) & ~63u); ++i)
+				static_cast<NvMeshTaskCommand*>(a.commands)[i] = NvMeshTaskCommand{ 0, 0, 0, 0, 0 };
+		}
 	}
 	if (tile >= numTiles)
 		return;
@@ -357,6 +368,22 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 	}
 	if (tid == 0 && tile == numTiles - 1)
 		a.count4[0] = total; // what the chain of atomicAdds leaves in the count word
+	if (TASK && a.fusedSubmit && tile == numTiles - 1)
+	{
+		// NV_OPT_FUSED_SUBMIT: tasksubmit.comp.glsl:27-47 from the workgroup that knows the final count.  The dummy commands
+		// [count, next multiple of 64) lie past every emitted command, so no other workgroup writes there.
+		const uint32_t count = total < NV_TASK_WGLIMIT ? total : NV_TASK_WGLIMIT;
+		if (tid == 0)
+		{
+			const uint32_t gx = (count + 63u) / 64u;
+			a.count4[1] = gx < 65535u ? gx : 65535u;
+			a.count4[2] = 64;
+			a.count4[3] = 1;
+		}
+		const uint32_t boundary = (count + 63u) & ~63u;
+		if (tid < 64u && count + tid < boundary)
+			static_cast<NvMeshTaskCommand*>(a.commands)[count + tid] = NvMeshTaskCommand{ 0, 0, 0, 0, 0 };
+	}
 
 	for (uint32_t c0 = 0; c0 < n; c0 += DC_STEP)
 	{

@@ -36,6 +36,7 @@ def from_device(t, dtype, count=None):
 
 
 NV_OPT_FUSED_COUNT_RESET = 1
+NV_OPT_FUSED_SUBMIT = 2
 
 
 class Context:
@@ -144,8 +145,13 @@ class DepthPyramid:
 class VisibilityPipeline:
     """niagara's GPU-driven visibility front-end for one scene on one device."""
 
-    def __init__(self, meshes, meshlets, draws, depth_size, ctx=None, task_capacity=None, cluster_capacity=None, use_soa=True):
+    def __init__(self, meshes, meshlets, draws, depth_size, ctx=None, task_capacity=None, cluster_capacity=None, use_soa=True, fused=False):
         self.ctx = ctx or Context()
+        # fused=True: the passes absorb the count-word resets and the tasksubmit / clustersubmit fix-ups (same buffer
+        # contents, four launches less per phase); fused=False issues the reference's dispatch sequence one to one
+        self.fused = bool(fused)
+        self.ctx.set_option(NV_OPT_FUSED_COUNT_RESET, int(self.fused))
+        self.ctx.set_option(NV_OPT_FUSED_SUBMIT, int(self.fused))
         dev = self.ctx.device
         self.mesh_count, self.meshlet_count, self.draw_count = len(meshes), len(meshlets), len(draws)
         self.draws_host = draws.copy()
@@ -169,21 +175,24 @@ class VisibilityPipeline:
 
     # src/niagara.cpp:1530-1574
     def cull(self, cull_data, late, task=True, post_pass=0):
-        self.ctx.reset_count(self.dccb)                             # vkCmdFillBuffer(dccb, 0, 4, 0)  (:1541)
+        if not self.fused:
+            self.ctx.reset_count(self.dccb)                         # vkCmdFillBuffer(dccb, 0, 4, 0)  (:1541)
         pass_data = cull_data.copy()
         pass_data["clusterBackfaceEnabled"] = 1 if post_pass == 0 else 0   # (:1549)
         pass_data["postPass"] = post_pass
         self.ctx.drawcull(pass_data, late, task, self.db, self.mb, self.dcb, self.dccb, self.dvb, self.pyramid.desc)
-        if task:
+        if task and not self.fused:
             self.ctx.tasksubmit(self.dccb, self.dcb)                # (:1563-1568)
 
     # src/niagara.cpp:1582-1611 (cluster branch of render())
     def render_clusters(self, cull_data, late, post_pass=0):
-        self.ctx.reset_count(self.ccb)                              # vkCmdFillBuffer(ccb, 0, 4, 0)  (:1586)
+        if not self.fused:
+            self.ctx.reset_count(self.ccb)                          # vkCmdFillBuffer(ccb, 0, 4, 0)  (:1586)
         pass_data = cull_data.copy()
         pass_data["postPass"] = post_pass                           # (:1595-1596)
         self.ctx.clustercull(pass_data, late, self.dcb, self.dccb, self.db, self.mlb, self.mvb, self.pyramid.desc, self.cib, self.ccb)
-        self.ctx.clustersubmit(self.ccb, self.cib)
+        if not self.fused:
+            self.ctx.clustersubmit(self.ccb, self.cib)
 
     # src/niagara.cpp:1703-1733
     def build_pyramid(self, depth):

@@ -11,8 +11,10 @@ from scenes import task_capacity
 class GpuScene:
     """device copies of a scenes.make_scene() dict"""
 
-    def __init__(self, ctx, scene, use_soa=True):
+    def __init__(self, ctx, scene, use_soa=True, fused=False):
         self.ctx, self.scene = ctx, scene
+        # fused: NV_OPT_FUSED_COUNT_RESET + NV_OPT_FUSED_SUBMIT — the count words start dirty and no submit launch is issued
+        self.fused = fused
         dev = ctx.device
         self.mb = P.to_device(scene["meshes"], dev)
         self.mlb = P.to_device(scene["meshlets"], dev)
@@ -34,7 +36,7 @@ class GpuScene:
         cap = task_capacity(self.scene) if task else len(self.scene["draws"]) + 1
         dt = L.TASKCMD if task else L.DRAWCMD
         dcb = torch.zeros(cap * dt.itemsize, dtype=torch.uint8, device=dev)
-        dccb = torch.zeros(4, dtype=torch.int32, device=dev)
+        dccb = torch.full((4,), 12345 if self.fused else 0, dtype=torch.int32, device=dev)
         dvb = torch.from_numpy(dvb_host.view(np.int32).copy()).to(dev)
         pd = cd.copy()
         pd["postPass"] = post_pass
@@ -45,11 +47,12 @@ class GpuScene:
         dev = self.ctx.device
         ncmd = int(dccb[1].item()) * 64
         cib = torch.zeros(ncmd * 64 + 256, dtype=torch.int32, device=dev)
-        ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+        ccb = torch.full((4,), 54321 if self.fused else 0, dtype=torch.int32, device=dev)
         pd = cd.copy()
         pd["postPass"] = post_pass
         self.ctx.clustercull(pd, late, dcb, dccb, self.db, self.mlb, mvb, self.pyramid.desc, cib, ccb)
-        self.ctx.clustersubmit(ccb, cib)
+        if not self.fused:
+            self.ctx.clustersubmit(ccb, cib)
         return cib, ccb
 
 
@@ -57,10 +60,12 @@ def host_u32(t):
     return t.cpu().numpy().view(np.uint32)
 
 
-def run_frames(ctx, scene, flags, frames=2, use_soa=True):
+def run_frames(ctx, scene, flags, frames=2, use_soa=True, fused=False):
     """same record structure as passes.run_frames, produced by the HIP passes"""
     from passes import set_flags
-    g = GpuScene(ctx, scene, use_soa)
+    g = GpuScene(ctx, scene, use_soa, fused)
+    ctx.set_option(P.NV_OPT_FUSED_COUNT_RESET, int(fused))
+    ctx.set_option(P.NV_OPT_FUSED_SUBMIT, int(fused))
     dev = ctx.device
     cd = set_flags(scene["cull"], flags)
     n = len(scene["draws"])
@@ -74,7 +79,8 @@ def run_frames(ctx, scene, flags, frames=2, use_soa=True):
                 depth = scene["depth"] if f > 0 else np.zeros_like(scene["depth"])
                 rec["pyramid"] = g.depthreduce(depth).copy()
             dcb, dccb, dvb = g.drawcull(cd, late, 1, dvb_host)
-            ctx.tasksubmit(dccb, dcb)
+            if not fused:
+                ctx.tasksubmit(dccb, dcb)
             cib, ccb = g.clustercull(cd, late, dcb, dccb, mvb)
             dvb_host = host_u32(dvb).copy()
             c4, cc4 = host_u32(dccb), host_u32(ccb)
@@ -83,4 +89,6 @@ def run_frames(ctx, scene, flags, frames=2, use_soa=True):
                               mvb=host_u32(mvb).copy())
         out.append(rec)
     ctx.status()
+    ctx.set_option(P.NV_OPT_FUSED_COUNT_RESET, 0)
+    ctx.set_option(P.NV_OPT_FUSED_SUBMIT, 0)
     return out

@@ -132,14 +132,15 @@ def test_submit_kernels(ctx):
         assert (G.host_u32(d_c4) == c4a).all() and (G.host_u32(d_cib) == a).all()
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("use_soa", [True, False])
 @pytest.mark.parametrize("seed", [21, 22])
-def test_two_frame_protocol(ctx, seed, use_soa):
+def test_two_frame_protocol(ctx, seed, use_soa, fused):
     """early -> pyramid -> late over three frames, every intermediate buffer bit-identical to the oracle"""
     scene = make_scene(seed=seed, n_draws=1500, meshlets_lod0=130, zero_radius_fraction=0.02)
     for flags in [(1, 1, 1, 1, 1), (1, 1, 1, 0, 1), (1, 0, 0, 0, 0), (0, 1, 1, 1, 0), (1, 1, 0, 1, 1)]:
         fo = passes.run_frames(oracle, scene, flags, frames=3)
-        fg = G.run_frames(ctx, scene, flags, frames=3, use_soa=use_soa)
+        fg = G.run_frames(ctx, scene, flags, frames=3, use_soa=use_soa, fused=fused)
         for a, b in zip(fo, fg):
             assert a["pyramid"].tobytes() == b["pyramid"].tobytes()
             for phase in ("early", "late"):
@@ -505,6 +506,45 @@ def test_fused_count_reset_option(ctx):
         assert int(ccb[0].item()) == total and (G.host_u32(cib)[:total] == cib_o[:total]).all()
     finally:
         ctx.set_option(P.NV_OPT_FUSED_COUNT_RESET, 0)
+    ctx.status()
+
+
+@pytest.mark.parametrize("empty", [False, True])
+def test_fused_submit_option(ctx, empty):
+    """NV_OPT_FUSED_SUBMIT: nv_drawcull(task) / nv_clustercull leave the dispatch words and the padding that tasksubmit /
+    clustersubmit write; compared word for word with the oracle's separate submit passes (also for an empty frame)"""
+    scene = make_scene(seed=77, n_draws=700, meshlets_lod0=100)
+    cd = scene["cull"].copy()
+    cd["clusterBackfaceEnabled"] = 1
+    dvb_host = np.zeros(len(scene["draws"]), np.uint32) if empty else np.ones(len(scene["draws"]), np.uint32)
+    # oracle: drawcull<0,1> -> tasksubmit -> clustercull<0> -> clustersubmit
+    cmds_o, c4_o = passes.run_drawcull(oracle, scene, cd, 0, 1, dvb_host.copy(), None)
+    oracle.tasksubmit(c4_o, cmds_o)
+    cib_o, cc4_o = passes.run_cluster(oracle, scene, cd, 0, cmds_o, c4_o, None, None)
+    g = G.GpuScene(ctx, scene, True)
+    ctx.set_option(P.NV_OPT_FUSED_SUBMIT, 1)
+    try:
+        cap = task_capacity(scene)
+        dev = ctx.device
+        dcb = torch.full((cap * L.TASKCMD.itemsize,), 0x5a, dtype=torch.uint8, device=dev)  # stale bytes: the padding must really be written
+        dccb = torch.tensor([0, 99, 99, 99], dtype=torch.int32, device=dev)
+        dvb = torch.from_numpy(dvb_host.view(np.int32).copy()).to(dev)
+        ctx.drawcull(cd, 0, 1, g.db, g.mb, dcb, dccb, dvb, None)
+        c4 = G.host_u32(dccb)
+        assert c4.tolist() == c4_o.tolist()
+        padded = int(c4[1]) * 64
+        assert P.from_device(dcb, L.TASKCMD)[:padded].tobytes() == cmds_o[:padded].tobytes()
+        cib = torch.full((padded * 64 + 256,), 0x12345678, dtype=torch.int32, device=dev)
+        ccb = torch.tensor([0, 77, 77, 77], dtype=torch.int32, device=dev)
+        ctx.clustercull(cd, 0, dcb, dccb, g.db, g.mlb, None, None, cib, ccb)
+        cc4 = G.host_u32(ccb)
+        assert cc4.tolist() == cc4_o.tolist()
+        slots = (int(cc4[0]) + 255) // 256 * 256
+        assert (G.host_u32(cib)[:slots] == cib_o[:slots]).all()
+        if not empty:
+            assert int(cc4[0]) > 100
+    finally:
+        ctx.set_option(P.NV_OPT_FUSED_SUBMIT, 0)
     ctx.status()
 
 

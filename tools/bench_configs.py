@@ -66,7 +66,7 @@ def config2(ctx, iters, n_draws=1_000_000, copies=6):
                 algorithmic_bytes=algo, achieved_GBs=algo / k_us / 1e3, frac=algo / k_us / 1e3 / HBM)
 
 
-def config3b(ctx, iters, n_draws=15625 * 4):
+def config3b(ctx, iters, n_draws=15625 * 4, fused=False):
     """contract path: drawcull<0,TASK> (LOD on, 64 meshes x 4 LODs) -> tasksubmit -> clustercull<0>"""
     dev = ctx.device
     meshes, total = synth.make_meshes(64, 4, 640)
@@ -75,7 +75,7 @@ def config3b(ctx, iters, n_draws=15625 * 4):
     slots, _ = host.assign_visibility_offsets(draws, meshes)
     cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, lodEnabled=1, clusterBackfaceEnabled=1)
     cd["cullingEnabled"] = 0  # every draw emits commands: the cluster pass sees the whole pool
-    pipe = P.VisibilityPipeline(meshes, meshlets, draws, (1024, 768), ctx=ctx, task_capacity=n_draws * 10 + 64, cluster_capacity=1 << 22)
+    pipe = P.VisibilityPipeline(meshes, meshlets, draws, (1024, 768), ctx=ctx, task_capacity=n_draws * 10 + 64, cluster_capacity=1 << 22, fused=fused)
     pipe.dvb.fill_(1)
 
     def step(i):
@@ -85,7 +85,7 @@ def config3b(ctx, iters, n_draws=15625 * 4):
     wall, k_us, prof = timed(ctx, step, iters, "cluster_cull")
     cmds = int(pipe.dccb[0].item())
     tested = int((P.from_device(pipe.dcb, L.TASKCMD)[:cmds]["taskCount"]).sum())
-    return dict(config="3B: drawcull<0,1> -> tasksubmit -> clustercull<0>", draws=n_draws, task_commands=cmds, meshlets_tested=tested,
+    return dict(config="3B: drawcull<0,1> -> tasksubmit -> clustercull<0> -> clustersubmit" + (" (NV_OPT_FUSED_SUBMIT + FUSED_COUNT_RESET: 4 launches)" if fused else " (8 launches)"), draws=n_draws, task_commands=cmds, meshlets_tested=tested,
                 visible=int(pipe.ccb[0].item()), step_us=wall, cluster_cull_us=k_us, cluster_scatter_us=prof["cluster_scatter"][0] / max(1, prof["cluster_scatter"][1]) * 1e3,
                 drawcull_us=prof["drawcull"][0] / max(1, prof["drawcull"][1]) * 1e3, meshlets_per_s=tested / (wall * 1e-6))
 
@@ -200,7 +200,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     ctx = P.Context(0)
-    runs = {"2": lambda: config2(ctx, a.iters), "3b": lambda: config3b(ctx, a.iters), "4": lambda: config4(ctx, a.iters),
+    runs = {"2": lambda: config2(ctx, a.iters), "3b": lambda: config3b(ctx, a.iters), "3b_fused": lambda: config3b(P.Context(0), a.iters, fused=True), "4": lambda: config4(ctx, a.iters),
             "4b": lambda: config4(ctx, a.iters, size=1024), "n4": lambda: config_n4(ctx, a.iters),
             "big": lambda: roofline_size(ctx, max(5, a.iters // 3)), "big_aos": lambda: roofline_size(P.Context(0), max(5, a.iters // 3), aos=True)}
     for k, fn in runs.items():
