@@ -22,15 +22,33 @@ from niagara_amd._lib import lib  # noqa: E402
 ctx = P.Context(0)
 dev = ctx.device
 draws, meshlets, commands, n = synth.cluster_scene(15625, 10)
-cd = host.build_cull_data(draw_count=len(draws), cullingEnabled=1, clusterBackfaceEnabled=1)
+LATE = int(os.environ.get("NV_TL_LATE", "0"))  # 1: the late pass of tools/bench_configs.py config 4 (HiZ, visibility bits)
+if LATE:
+    size = 4096
+    depth = torch.from_numpy(synth.make_depth(size, size)).to(dev)
+    pyr = P.DepthPyramid(dev, size, size)
+    ctx.depthreduce(depth, size, size, pyr.desc)
+    cd = host.build_cull_data(draw_count=len(draws), viewport=(size, size), pyramid=(pyr.width, pyr.height), cullingEnabled=1,
+                              clusterBackfaceEnabled=1, clusterOcclusionEnabled=1, occlusionEnabled=1)
+    rng = np.random.default_rng(7)
+    commands["lateDrawVisibility"][:n] = rng.integers(0, 2, n)
+else:
+    cd = host.build_cull_data(draw_count=len(draws), cullingEnabled=1, clusterBackfaceEnabled=1)
 db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
 ctx.upload_meshlets(mlb, len(meshlets))
 dccb = torch.from_numpy(synth.count4_for(n).view(np.int32).copy()).to(dev)
 cib = torch.zeros(n * 64 + 256, dtype=torch.int32, device=dev)
 ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+if LATE:
+    mvb0 = torch.from_numpy(rng.integers(0, 2 ** 32, n * 2 + 4, dtype=np.uint64).astype(np.uint32).view(np.int32)).to(dev)
+    mvb = mvb0.clone()
 for _ in range(5):
     ccb.zero_()
-    ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
+    if LATE:
+        mvb.copy_(mvb0)
+        ctx.clustercull(cd, 1, dcb, dccb, db, mlb, mvb, pyr.desc, cib, ccb)
+    else:
+        ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
 torch.cuda.synchronize()
 waves = 256 * int(os.environ.get("NV_CC_BLOCKS_PER_CU", "6")) * 4
 out = np.zeros((waves, 8), np.uint64)
