@@ -21,9 +21,21 @@ struct ClusterCounts
 {
 	uint32_t parity;   // read by the cull kernel; flipped by one thread of the scatter kernel
 	uint32_t k2parity; // the parity of the running pass, written by the cull kernel for the scatter kernel
-	uint32_t pad[30];
+	uint32_t base;     // the count word as the pass found it (0 with the fused reset), snapshot by the cull kernel: the scatter
+	                   // kernel's last tile overwrites the live word while other tiles may not have started yet
+	uint32_t pad[29];
 	uint32_t counts[2][CC_MAX_SCATTER_TILES * CC_COUNT_STRIDE];
 };
+
+// Wave-uniform words every wave of a launch needs (counts, parity): read through the constant address space, i.e. with a
+// scalar load served by the scalar cache of the CU — as vector (or agent-scope atomic) loads they are thousands of
+// requests for ONE line of one L2 channel.  Only for words written by an EARLIER launch (the scalar cache is invalidated
+// per dispatch, not within one).
+typedef __attribute__((address_space(4))) const uint32_t* nv_uniform_u32p;
+__device__ __forceinline__ uint32_t load_uniform_u32(const uint32_t* p)
+{
+	return *(nv_uniform_u32p)(uintptr_t)p;
+}
 
 struct ClusterArgs
 {

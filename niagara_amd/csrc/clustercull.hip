@@ -239,6 +239,52 @@ NV_DEV uint64_t cull_command(const ClusterArgs& a, const NvMeshTaskCommand& cmd,
 	return __ballot(visible && !skip);
 }
 
+// The late pass with HiZ in two halves, so that the exact pass can keep several commands' texel fetches in flight (the
+// texel addresses depend on the projection, so one command after the other costs a full memory latency each — measured:
+// the waves that own the visible part of the scene spent 10-27 us there while two thirds of the waves had nothing to do).
+// late_prepare = cull_command up to hiz_prepare; flags: bits 0..4 HizProbe::use, bit 5 visible so far, bit 6 skip.
+template <bool BITS>
+NV_DEV HizProbe late_prepare(const ClusterArgs& a, const NvMeshTaskCommand& cmd, const DrawUniform& u, const LaneData& l, uint32_t lane, uint32_t& flags,
+                             const uint32_t* mipOffsets)
+{
+	const NvCullData& cd = a.cd;
+	bool visible = lane < cmd.taskCount;
+	bool skip = false;
+	if (BITS)
+	{
+		const uint32_t mvi = lane + cmd.meshletVisibilityOffset;
+		const bool bit = (l.mvbWord & (1u << (mvi & 31))) != 0;
+		if (cmd.lateDrawVisibility == 1 && bit)
+			skip = true;
+	}
+	HizProbe p = { 0, 0, 0, 0, 0, 0.0f };
+	if (__ballot(visible) != 0)
+	{
+		f3 c;
+		float r;
+		lane_sphere(cd, u, l, c, r);
+		visible = visible && frustum_test(cd, c, r);
+		if (cd.clusterBackfaceEnabled != 0 && __ballot(visible) != 0)
+		{
+			f3 axis;
+			float cutoff;
+			lane_cone(cd, u, l, axis, cutoff);
+			visible = visible && !cone_cull(c, r, axis, cutoff);
+		}
+		if (visible && !(a.debugMode & 512u)) // bit 9 (experiments): no HiZ
+			p = hiz_prepare(cd, a.pyr, c, r, mipOffsets);
+	}
+	flags = p.use | (visible ? 32u : 0u) | (skip ? 64u : 0u);
+	return p;
+}
+
+// second half: `visible` of clustercull.comp.glsl:110-123 from the four texels
+NV_DEV bool late_finish(uint32_t flags, float depthSphere, float t00, float t10, float t01, float t11)
+{
+	HizProbe p = { 0, 0, 0, 0, flags & 31u, depthSphere };
+	return (flags & 32u) != 0 && hiz_finish(p, t00, t10, t01, t11);
+}
+
 // Late pass, lane-parallel form of the same update for a whole segment: lane c owns the segment's c-th command and
 // holds its `visible` ballot in vis (0 for commands the filter rejected).  Runs after the load rings have drained, so
 // its stores and atomics never sit between counted loads (a store issued inside a ring lengthens every s_waitcnt
@@ -299,7 +345,8 @@ NV_DEV uint32_t indirect_command_count(const ClusterArgs& a)
 	// vkCmdDispatchIndirect(dccb, 4): grid = (groupCountX, 64, 1), commandId = x*64 + y (clustercull.comp.glsl:59).
 	// groupCountX is at most 65535 in a valid dispatch (tasksubmit.comp.glsl:36 clamps to it; maxComputeWorkGroupCount);
 	// a larger word is clamped rather than trusted, because the ballot scratch is sized for TASK_WGLIMIT commands
-	const uint32_t groups = a.count4[1] < 65535u ? a.count4[1] : 65535u;
+	const uint32_t raw = load_uniform_u32(a.count4 + 1);
+	const uint32_t groups = raw < 65535u ? raw : 65535u;
 	return a.commandCountOverride ? a.commandCountOverride : groups * 64u;
 }
 
@@ -606,6 +653,39 @@ NV_DEV void ringB_wait(SlotB& s)
 		asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.bounds), "+v"(s.cone) : "i"(YOUNGER * 2) : "memory");
 }
 
+// the same wait with the number of younger LOADS given directly (exact pass with texel fetches between the ring issues)
+template <bool BITS, int LOADS>
+NV_DEV void ringB_wait_loads(SlotB& s)
+{
+	static_assert(LOADS < 64, "vmcnt is a 6-bit counter");
+	if (BITS)
+		asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s.bounds), "+v"(s.cone), "+v"(s.mvbWord) : "i"(LOADS) : "memory");
+	else
+		asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.bounds), "+v"(s.cone) : "i"(LOADS) : "memory");
+}
+
+// the four HiZ texels of one command in flight (late pass): offsets in floats from the pyramid base, always in range
+struct SlotT
+{
+	float t00, t10, t01, t11;
+};
+
+NV_DEV void ringT_issue(SlotT& s, const float* base, uint32_t o00, uint32_t o10, uint32_t o01, uint32_t o11, uint64_t order)
+{
+	const uint32_t b00 = o00 * 4u, b10 = o10 * 4u, b01 = o01 * 4u, b11 = o11 * 4u;
+	asm volatile("s_nop 4\n\tglobal_load_dword %0, %4, %8\n\tglobal_load_dword %1, %5, %8\n\tglobal_load_dword %2, %6, %8\n\tglobal_load_dword %3, %7, %8"
+	             : "=&v"(s.t00), "=&v"(s.t10), "=&v"(s.t01), "=&v"(s.t11)
+	             : "v"(b00), "v"(b10), "v"(b01), "v"(b11), "s"(base), "s"(order)
+	             : "memory");
+}
+
+template <int LOADS>
+NV_DEV void ringT_wait(SlotT& s)
+{
+	static_assert(LOADS < 64, "vmcnt is a 6-bit counter");
+	asm volatile("s_waitcnt vmcnt(%4)" : "+v"(s.t00), "+v"(s.t10), "+v"(s.t01), "+v"(s.t11) : "i"(LOADS) : "memory");
+}
+
 // commands per scatter tile: the same function of the indirect words in both kernels
 NV_DEV uint32_t scatter_tile_commands(uint32_t numCmds, uint32_t tiles)
 {
@@ -686,6 +766,21 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t w = blockIdx.x * CC_WAVES + wave;
 
+	// late pass: the pyramid's level offsets in LDS, one copy per wave (written and read by the same wave: no barrier).
+	// Built from the scalar kernel arguments with constant indices — a per-lane index into the argument array would be
+	// a vector load, per probe a full memory latency in front of the texel fetch.
+	__shared__ uint32_t s_mipTable[CC_WAVES][NV_MAX_MIPS];
+	const uint32_t* s_mipOffset = s_mipTable[wave];
+	if (LATE)
+	{
+		uint32_t off = 0;
+#pragma unroll
+		for (uint32_t i = 0; i < NV_MAX_MIPS; ++i)
+			off = lane == i ? a.pyr.mipOffset[i] : off;
+		if (lane < NV_MAX_MIPS)
+			s_mipTable[wave][lane] = off;
+	}
+
 	// the start-up chain (count -> commands -> draws / first bounds) is latency-critical and a few dozen instructions
 	// long: it must not queue behind the older waves' filter arithmetic (measured: without this the sixth workgroup of
 	// a CU got its first data 11 k cycles after the first one)
@@ -701,9 +796,12 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 	const uint32_t myChunks = make_dealing(numChunks, wave, lane, a.generations, gen, !LATE && !(a.debugMode & 32768u), a.dealScale, &chunkOf, &dealtWeighted); // (late pass: even — the weights are calibrated on the early pass, and the extra state costs the late variants two resident workgroups per CU) // bit 15 (experiments): even dealing
 	const uint32_t myCmds = myChunks * CC_CHUNK; // the last chunk of the pass may run past numCmds: guarded below
 	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles);
-	const uint32_t bank = __hip_atomic_load(&a.tileCounts->parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
+	const uint32_t bank = load_uniform_u32(&a.tileCounts->parity) & 1u;
 	if (w == 0 && lane == 0)
-		__hip_atomic_store(&a.tileCounts->k2parity, bank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	{
+		a.tileCounts->k2parity = bank;
+		a.tileCounts->base = a.fusedReset ? 0u : a.clusterCount4[0];
+	}
 
 	// debugMode bit 3: per-wave s_memtime stamps into probeOut (tools/wave_timeline.py); never set in production
 	const bool dbgTime = (a.debugMode & 8u) && a.probeOut;
@@ -859,7 +957,116 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 			NV_STAMP(3);
 
 			// ---- pass B: exact tests (reference arithmetic) for the commands that can have survivors, bounds + cone
-			if (candMask && !(a.debugMode & 1024u)) // bit 10 (experiments): no exact pass
+			if (LATE && candMask && a.cd.clusterOcclusionEnabled == 1 && !(a.debugMode & (1024u | 524288u))) // bit 19 (experiments): texels fetched per command
+			{
+				// Late pass with HiZ: the same ring for bounds + cone, and behind it the texel fetches of CC_PT commands in
+				// flight.  A visit = wait for the slot's bounds, first half of the test (up to the texel addresses), second
+				// half of the command visited CC_PT visits ago, issue this command's texels, reissue the slot.  Every visit
+				// issues the same CC_UL loads (inactive probes and empty slots fetch texel 0 / re-read the last command), so
+				// all waits are counted; the first round, which follows CC_DL ring issues without texels, has its own counts.
+				constexpr int CC_DL = 4, CC_PT = 2;                  // ring slots, texel sets in flight
+				constexpr int CC_RL = BITS ? 3 : 2, CC_UL = 4 + CC_RL; // loads per ring issue, per visit
+				static_assert(CC_DL % CC_PT == 0, "the texel set of a visit is chosen statically");
+				uint32_t curDraw = ~0u;
+				DrawUniform du = {};
+				uint64_t pending = candMask;
+				uint32_t cIssued[CC_DL];
+				SlotB ring[CC_DL];
+				SlotT tex[CC_PT];
+				uint32_t tFlags[CC_PT], tCmd[CC_PT];
+				float tDepth[CC_PT];
+				uint32_t last = (uint32_t)__builtin_ctzll(candMask);
+#pragma unroll
+				for (int j = 0; j < CC_PT; ++j)
+				{
+					tFlags[j] = 0;
+					tCmd[j] = ~0u;
+					tDepth[j] = 0.0f;
+					tex[j] = { 0.0f, 0.0f, 0.0f, 0.0f };
+				}
+				bool firstRound = true;
+#pragma unroll
+				for (int k = 0; k < CC_DL; ++k)
+				{
+					if (pending)
+					{
+						last = (uint32_t)__builtin_ctzll(pending);
+						pending &= pending - 1;
+						cIssued[k] = last;
+					}
+					else
+						cIssued[k] = ~0u;
+					ringB_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, last), __builtin_amdgcn_readlane(r.taskCount, last),
+					                  __builtin_amdgcn_readlane(r.meshletVisibilityOffset, last), lane, 0);
+				}
+				for (bool more = true; more;)
+				{
+					more = false;
+#pragma unroll
+					for (int k = 0; k < CC_DL; ++k)
+					{
+						const int j = k % CC_PT; // static after unrolling
+						if (firstRound) // younger than this slot's issue: the later slots of the prologue and k full visits
+							asm volatile("s_waitcnt vmcnt(%0)" ::"i"(CC_RL * (CC_DL - 1 - k) + k * CC_UL) : "memory");
+						ringB_wait_loads<BITS, (CC_DL - 1) * CC_UL>(ring[k]);
+						const uint32_t c = cIssued[k];
+						HizProbe probe = { 0, 0, 0, 0, 0, 0.0f };
+						uint32_t flags = 0;
+						if (c != ~0u)
+						{
+							const NvMeshTaskCommand cmd = segment_command(r, c);
+							if (cmd.drawId != curDraw)
+							{
+								curDraw = cmd.drawId;
+								du = segment_draw(r, c);
+							}
+							LaneData cur;
+							cur.b0 = (uint32_t)ring[k].bounds;
+							cur.b1 = (uint32_t)(ring[k].bounds >> 32);
+							cur.cone = ring[k].cone;
+							cur.mvbWord = ring[k].mvbWord;
+							probe = late_prepare<BITS>(a, cmd, du, cur, lane, flags, s_mipOffset);
+						}
+						// second half of the command whose texels were requested CC_PT visits ago
+						ringT_wait<CC_RL + (CC_PT - 1) * CC_UL>(tex[j]);
+						uint64_t m = 0;
+						if (tCmd[j] != ~0u)
+						{
+							const bool visible = late_finish(tFlags[j], tDepth[j], tex[j].t00, tex[j].t10, tex[j].t01, tex[j].t11);
+							const uint64_t vis = __ballot(visible);
+							m = __ballot(visible && !(tFlags[j] & 64u));
+							maskLo = writelane_u32(maskLo, (uint32_t)m, tCmd[j]);
+							maskHi = writelane_u32(maskHi, (uint32_t)(m >> 32), tCmd[j]);
+							visLo = writelane_u32(visLo, (uint32_t)vis, tCmd[j]);
+							visHi = writelane_u32(visHi, (uint32_t)(vis >> 32), tCmd[j]);
+						}
+						tFlags[j] = flags;
+						tDepth[j] = probe.depthSphere;
+						tCmd[j] = c;
+						ringT_issue(tex[j], a.pyr.d_base, probe.o00, probe.o10, probe.o01, probe.o11, m);
+						if (c != ~0u)
+							more = true; // its second half is still to come
+						if (pending)
+						{
+							last = (uint32_t)__builtin_ctzll(pending);
+							pending &= pending - 1;
+							cIssued[k] = last;
+							more = true;
+						}
+						else
+							cIssued[k] = ~0u;
+						ringB_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, last), __builtin_amdgcn_readlane(r.taskCount, last),
+						                  __builtin_amdgcn_readlane(r.meshletVisibilityOffset, last), lane, m);
+					}
+					firstRound = false;
+					if (!more)
+#pragma unroll
+						for (int k = 0; k < CC_DL; ++k)
+							more = more || cIssued[k] != ~0u;
+				}
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			}
+			else if (candMask && !(a.debugMode & 1024u)) // bit 10 (experiments): no exact pass
 			{
 				uint32_t curDraw = ~0u;
 				DrawUniform du = {};
@@ -1030,8 +1237,8 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs
 
 	// Everything below was written by the cull kernel, i.e. before this launch: plain loads, all issued together.
 	// Both banks of tile counts are read speculatively so that no load waits for the parity word.
-	const uint32_t k2parity = a.tileCounts->k2parity;
-	const uint32_t base0 = a.fusedReset ? 0u : a.clusterCount4[0];
+	const uint32_t k2parity = load_uniform_u32(&a.tileCounts->k2parity);
+	const uint32_t base0 = load_uniform_u32(&a.tileCounts->base);
 	uint32_t cnt0[2] = { 0, 0 }, cnt1[2] = { 0, 0 }; // this thread's tiles tid and tid + 256, per bank
 #pragma unroll
 	for (int j = 0; j < 2; ++j)

@@ -258,7 +258,9 @@ struct HizProbe
 	float depthSphere;
 };
 
-NV_DEV HizProbe hiz_prepare(const NvCullData& cd, const NvPyramidDesc& pyr, f3 c, float r)
+// mipOffsets = pyr.mipOffset, or a copy of it in LDS: indexed per lane, the kernel-argument array costs a vector load
+// (and a full memory latency) per probe
+NV_DEV HizProbe hiz_prepare(const NvCullData& cd, const NvPyramidDesc& pyr, f3 c, float r, const uint32_t* mipOffsets)
 {
 	HizProbe p = { 0, 0, 0, 0, 0, 0.0f };
 	float aabb[4];
@@ -274,7 +276,7 @@ NV_DEV HizProbe hiz_prepare(const NvCullData& cd, const NvPyramidDesc& pyr, f3 c
 		bool ux0, ux1, uy0, uy1;
 		footprint(u * (float)w - 0.5f, w, x0, x1, ux0, ux1);
 		footprint(v * (float)h - 0.5f, h, y0, y1, uy0, uy1);
-		const uint32_t base = pyr.mipOffset[l];
+		const uint32_t base = mipOffsets[l];
 		p.o00 = base + (uint32_t)y0 * w + (uint32_t)x0;
 		p.o10 = base + (uint32_t)y0 * w + (uint32_t)x1;
 		p.o01 = base + (uint32_t)y1 * w + (uint32_t)x0;
@@ -317,7 +319,7 @@ NV_DEV bool hiz_finish(const HizProbe& p, float t00, float t10, float t01, float
 // drawcull.comp.glsl:86-99 / clustercull.comp.glsl:110-123: returns the sphere's visibility against the pyramid
 NV_DEV bool hiz_test(const NvCullData& cd, const NvPyramidDesc& pyr, f3 c, float r)
 {
-	const HizProbe p = hiz_prepare(cd, pyr, c, r);
+	const HizProbe p = hiz_prepare(cd, pyr, c, r, pyr.mipOffset);
 	if (!(p.use & 16u))
 		return true;
 	const float* base = pyr.d_base;

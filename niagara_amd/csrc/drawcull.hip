@@ -190,9 +190,12 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 
 	const uint32_t drawCount = a.cd.drawCount;
 	const uint32_t T2 = scatter_tile_draws(drawCount, a.scatterTiles);
-	const uint32_t bank = __hip_atomic_load(&a.tileCounts->parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
+	const uint32_t bank = load_uniform_u32(&a.tileCounts->parity) & 1u;
 	if (blockIdx.x == 0 && tid == 0)
-		__hip_atomic_store(&a.tileCounts->k2parity, bank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	{
+		a.tileCounts->k2parity = bank;
+		a.tileCounts->base = a.fusedReset ? 0u : a.count4[0];
+	}
 
 	const uint32_t first = blockIdx.x * DC_TILE;
 	if (first >= drawCount)
@@ -297,8 +300,8 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 
 	// Everything below was written by the decide kernel, i.e. before this launch: plain loads, all issued together.
 	// Both banks of tile counts are read speculatively so that no load waits for the parity word.
-	const uint32_t k2parity = a.tileCounts->k2parity;
-	const uint32_t base0 = a.fusedReset ? 0u : a.count4[0];
+	const uint32_t k2parity = load_uniform_u32(&a.tileCounts->k2parity);
+	const uint32_t base0 = load_uniform_u32(&a.tileCounts->base);
 	uint32_t cnt0[2] = { 0, 0 }, cnt1[2] = { 0, 0 }; // this thread's tiles tid and tid + 256, per bank
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
