@@ -745,9 +745,10 @@ NV_DEV uint32_t make_dealing(uint32_t numChunks, uint32_t wave, uint32_t lane, u
 	if (weightedTotal > numChunks) // cannot happen (floors of targets that sum to less than the total); stay safe
 		return even;
 	const uint32_t rest = numChunks - weightedTotal;
-	const uint32_t mine = rounds + rest / W + (w < rest % W ? 1u : 0u);
-	if (mine > 64u)
+	// the lane-parallel table holds 64 chunks; decided for the whole grid at once (every wave must take the same branch)
+	if (roundsOf[0] + rest / W + 1u > 64u)
 		return even;
+	const uint32_t mine = rounds + rest / W + (w < rest % W ? 1u : 0u);
 	// lane j: round j of the weighted part (chunks of earlier rounds = genWaves * sum over generations of min(j, roundsOf)),
 	// then the even remainder
 	uint32_t before = 0;
