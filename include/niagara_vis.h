@@ -40,6 +40,8 @@ extern "C" {
 
 /* ---- compile-time contract (src/config.h:2-28) ---- */
 #define NV_TASK_WGSIZE 64u           /* src/config.h:2  */
+#define NV_MESH_MAXVTX 64u           /* src/config.h:14 */
+#define NV_MESH_MAXTRI 96u           /* src/config.h:15 */
 #define NV_CLUSTER_TILE 16u          /* src/config.h:22 */
 #define NV_TASK_WGLIMIT (1u << 22)   /* src/config.h:25 */
 #define NV_CLUSTER_LIMIT (1u << 24)  /* src/config.h:28 */
@@ -52,6 +54,8 @@ extern "C" {
 #define NV_ENOMEM (-2)   /* scratch allocation failed */
 #define NV_ESTATE (-3)   /* device-side protocol error (look-back spin bound hit) */
 #define NV_ENODEV (-4)   /* no HIP device */
+#define NV_EIO (-5)      /* file cannot be opened / read */
+#define NV_EFORMAT (-6)  /* not a scene cache this build understands (magic, version, meshlet limits, truncated) */
 
 /* ---- layouts ---- */
 
@@ -328,6 +332,32 @@ void nv_shard_range(uint64_t total, uint32_t rank, uint32_t world, uint64_t* beg
 int nv_pack_counts(nv_context* ctx, void* stream, const uint32_t* d_countA, const uint32_t* d_countB,
                    const uint32_t* d_countC, uint64_t* d_out3);
 
+/* ---- scene cache ingestion ----
+ * niagara's `.cache` file (src/scenecache.cpp: header :16-55, section order :163-203, load-time checks :273-293) holds
+ * the three arrays the visibility path consumes — Meshlet, Mesh, MeshDraw — as RAW struct arrays even in compressed mode
+ * (:170, :181, :183); only the vertex / index / meshlet-data / RT-vertex streams are meshopt-coded, and their byte sizes
+ * are in the header, so they can be stepped over without a decoder.  nv_scenecache_info validates the header like
+ * loadSceneCache does (magic 'SCNC', version 7, MESH_MAXVTX / MESH_MAXTRI; hashMeta, clrtMode and ommStates are
+ * returned for the caller to compare with its own settings) and locates the arrays; nv_scenecache_read copies them
+ * out (any destination may be NULL).  Host-only: no device work. */
+typedef struct NvSceneCacheInfo
+{
+	uint32_t version, compressed, clrtMode, ommStates;
+	uint64_t hashMeta;
+	uint32_t meshletMaxVertices, meshletMaxTriangles;
+	uint32_t vertexCount, indexCount, meshletCount, meshletdataCount, meshletvtx0Count, meshCount;
+	uint32_t materialCount, drawCount, texturePathCount, lightCount, animationCount, keyframeCount;
+	float cameraPosition[3];    /* Camera (src/scene.h:111-117) */
+	float cameraOrientation[4]; /* quat x, y, z, w */
+	float cameraFovY, cameraZnear;
+	float sunDirection[3];
+	uint64_t fileSize;
+	uint64_t vertexOffset, indexOffset, meshletOffset, meshletdataOffset, meshOffset, drawOffset; /* byte offsets in the file */
+	uint64_t vertexBytes, indexBytes, meshletdataBytes; /* stored (possibly compressed) sizes of those streams */
+} NvSceneCacheInfo;
+int nv_scenecache_info(const char* path, NvSceneCacheInfo* out);
+int nv_scenecache_read(const char* path, const NvSceneCacheInfo* info, NvMesh* meshes, NvMeshlet* meshlets, NvMeshDraw* draws);
+
 /* ---- verification probe (tests only): per-meshlet scalar intermediates of the cluster cull
  * (view-space centre xyz, radius, cone lhs, cone rhs, aabb[4], mip level, sampled depth,
  * depthSphere, flags) = 16 floats per lane, for the <=1-ULP scalar parity tests. */
@@ -353,6 +383,7 @@ static_assert(offsetof(NvCullData, cullingEnabled) == 112 && offsetof(NvCullData
 static_assert(sizeof(NvVertex) == 16, "Vertex layout (src/shaders/mesh.h:3-9)");
 static_assert(sizeof(NvGlobals) == 224 && offsetof(NvGlobals, cullData) == 64 && offsetof(NvGlobals, screenWidth) == 208, "Globals layout (src/shaders/mesh.h:46-51)");
 static_assert(sizeof(NvTriangleMask) == 16, "one mask per grid slot");
+static_assert(sizeof(NvSceneCacheInfo) == 208, "NvSceneCacheInfo is mirrored by niagara_amd/_lib.py");
 #endif
 
 #endif /* NIAGARA_VIS_H */

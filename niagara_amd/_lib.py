@@ -27,6 +27,18 @@ class PyramidDesc(C.Structure):
                 ("mipOffset", C.c_uint32 * 16), ("totalTexels", C.c_uint32)]
 
 
+class SceneCacheInfo(C.Structure):
+    """NvSceneCacheInfo (include/niagara_vis.h)"""
+    _fields_ = ([(n, C.c_uint32) for n in ("version", "compressed", "clrtMode", "ommStates")] + [("hashMeta", C.c_uint64)] +
+                [(n, C.c_uint32) for n in ("meshletMaxVertices", "meshletMaxTriangles", "vertexCount", "indexCount", "meshletCount",
+                                           "meshletdataCount", "meshletvtx0Count", "meshCount", "materialCount", "drawCount",
+                                           "texturePathCount", "lightCount", "animationCount", "keyframeCount")] +
+                [("cameraPosition", C.c_float * 3), ("cameraOrientation", C.c_float * 4), ("cameraFovY", C.c_float),
+                 ("cameraZnear", C.c_float), ("sunDirection", C.c_float * 3)] +
+                [(n, C.c_uint64) for n in ("fileSize", "vertexOffset", "indexOffset", "meshletOffset", "meshletdataOffset", "meshOffset",
+                                           "drawOffset", "vertexBytes", "indexBytes", "meshletdataBytes")])
+
+
 if not os.path.exists(SO_PATH):
     raise ImportError("niagara_amd: %s is missing — build it with `make -C niagara_amd/csrc` (or __graft_entry__.build()); "
                       "there is no fallback path" % SO_PATH)
@@ -61,6 +73,8 @@ _SIGS = {
     "nv_synth_draws": (_i, [_vp, _u32, _u32, _f]),
     "nv_shard_range": (None, [C.c_uint64, _u32, _u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "nv_pack_counts": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "nv_scenecache_info": (_i, [C.c_char_p, C.POINTER(SceneCacheInfo)]),
+    "nv_scenecache_read": (_i, [C.c_char_p, C.POINTER(SceneCacheInfo), _vp, _vp, _vp]),
     "nv_probe_cluster_scalars": (_i, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, C.POINTER(PyramidDesc), _vp]),
 }
 EXPORTS = sorted(_SIGS)
@@ -72,5 +86,5 @@ for _name, (_res, _args) in _SIGS.items():
 
 def check(rc, what):
     if rc != 0:
-        names = {-1: "NV_EINVAL", -2: "NV_ENOMEM", -3: "NV_ESTATE", -4: "NV_ENODEV"}
+        names = {-1: "NV_EINVAL", -2: "NV_ENOMEM", -3: "NV_ESTATE", -4: "NV_ENODEV", -5: "NV_EIO", -6: "NV_EFORMAT"}
         raise NvError("%s failed: %s" % (what, names.get(rc, "hipError %d" % rc)))

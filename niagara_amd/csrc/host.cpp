@@ -2,6 +2,7 @@
 // cull passes consume.  Plain C++; arithmetic is fp32 in the order written so that results are reproducible.
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 
 #include "../../include/niagara_vis.h"
@@ -192,6 +193,129 @@ int nv_synth_draws(NvMeshDraw* draws, uint32_t drawCount, uint32_t meshCount, fl
 		d.meshIndex = meshIndex;
 	}
 	return NV_OK;
+}
+
+// ---- scene cache (src/scenecache.cpp) ----
+// SceneHeader, src/scenecache.cpp:16-55, as the reference's compiler lays it out (vec3 / quat are plain floats; the
+// uint64_t makes the struct 8-aligned): 160 bytes.
+namespace
+{
+struct SceneCacheHeader
+{
+	uint32_t magic, version;
+	uint64_t hashMeta;
+	uint32_t meshletMaxVertices, meshletMaxTriangles;
+	uint8_t clrtMode, compressed, pad[2];
+	uint32_t compressedVertexBytes, compressedIndexBytes, compressedMeshletDataBytes, compressedMeshletVtx0Bytes;
+	uint32_t vertexCount, indexCount, meshletCount, meshletdataCount, meshletvtx0Count, meshCount;
+	uint32_t materialCount, drawCount, texturePathCount, lightCount, animationCount, keyframeCount;
+	uint32_t ommArrayDataSize, ommIndexDataSize, ommDescCount, ommStates;
+	float cameraPosition[3], cameraOrientation[4], cameraFovY, cameraZnear;
+	float sunDirection[3];
+	uint32_t tail;
+};
+static_assert(sizeof(SceneCacheHeader) == 160, "SceneHeader layout (src/scenecache.cpp:16-55)");
+static_assert(offsetof(SceneCacheHeader, vertexCount) == 44 && offsetof(SceneCacheHeader, cameraPosition) == 108, "SceneHeader offsets");
+
+const uint32_t kSceneCacheMagic = 0x434E4353u; // 'SCNC', src/scenecache.cpp:12
+const uint32_t kSceneCacheVersion = 7;         // src/scenecache.cpp:13
+const uint64_t kVertexBytes = 16;              // Vertex, src/scene.h:60-66
+const uint64_t kMaterialBytes = 64;            // Material, src/scene.h:25-37
+} // namespace
+
+int nv_scenecache_info(const char* path, NvSceneCacheInfo* out)
+{
+	if (!path || !out)
+		return NV_EINVAL;
+	FILE* f = fopen(path, "rb");
+	if (!f)
+		return NV_EIO;
+	SceneCacheHeader h;
+	const size_t got = fread(&h, 1, sizeof(h), f);
+	uint64_t fileSize = 0;
+	if (fseek(f, 0, SEEK_END) == 0)
+		fileSize = (uint64_t)ftell(f);
+	fclose(f);
+	// src/scenecache.cpp:276-293 (the caller-dependent fields are handed back instead of compared)
+	if (got < sizeof(h) || h.magic != kSceneCacheMagic || h.version != kSceneCacheVersion || h.meshletMaxVertices != NV_MESH_MAXVTX ||
+	    h.meshletMaxTriangles != NV_MESH_MAXTRI)
+		return NV_EFORMAT;
+
+	memset(out, 0, sizeof(*out));
+	out->version = h.version;
+	out->compressed = h.compressed;
+	out->clrtMode = h.clrtMode;
+	out->ommStates = h.ommStates;
+	out->hashMeta = h.hashMeta;
+	out->meshletMaxVertices = h.meshletMaxVertices;
+	out->meshletMaxTriangles = h.meshletMaxTriangles;
+	out->vertexCount = h.vertexCount;
+	out->indexCount = h.indexCount;
+	out->meshletCount = h.meshletCount;
+	out->meshletdataCount = h.meshletdataCount;
+	out->meshletvtx0Count = h.meshletvtx0Count;
+	out->meshCount = h.meshCount;
+	out->materialCount = h.materialCount;
+	out->drawCount = h.drawCount;
+	out->texturePathCount = h.texturePathCount;
+	out->lightCount = h.lightCount;
+	out->animationCount = h.animationCount;
+	out->keyframeCount = h.keyframeCount;
+	memcpy(out->cameraPosition, h.cameraPosition, sizeof(h.cameraPosition));
+	memcpy(out->cameraOrientation, h.cameraOrientation, sizeof(h.cameraOrientation));
+	out->cameraFovY = h.cameraFovY;
+	out->cameraZnear = h.cameraZnear;
+	memcpy(out->sunDirection, h.sunDirection, sizeof(h.sunDirection));
+	out->fileSize = fileSize;
+
+	// section order of saveSceneCache, src/scenecache.cpp:163-186
+	uint64_t off = sizeof(h);
+	out->vertexOffset = off;
+	out->vertexBytes = h.compressed ? h.compressedVertexBytes : (uint64_t)h.vertexCount * kVertexBytes;
+	off += out->vertexBytes;
+	out->indexOffset = off;
+	out->indexBytes = h.compressed ? h.compressedIndexBytes : (uint64_t)h.indexCount * 4u;
+	off += out->indexBytes;
+	out->meshletOffset = off;
+	off += (uint64_t)h.meshletCount * sizeof(NvMeshlet);
+	out->meshletdataOffset = off;
+	out->meshletdataBytes = h.compressed ? h.compressedMeshletDataBytes : (uint64_t)h.meshletdataCount * 4u;
+	off += out->meshletdataBytes;
+	off += h.compressed ? h.compressedMeshletVtx0Bytes : (uint64_t)h.meshletvtx0Count * 2u;
+	out->meshOffset = off;
+	off += (uint64_t)h.meshCount * sizeof(NvMesh);
+	off += (uint64_t)h.materialCount * kMaterialBytes;
+	out->drawOffset = off;
+	off += (uint64_t)h.drawCount * sizeof(NvMeshDraw);
+	if (off > fileSize)
+		return NV_EFORMAT; // truncated
+	return NV_OK;
+}
+
+int nv_scenecache_read(const char* path, const NvSceneCacheInfo* info, NvMesh* meshes, NvMeshlet* meshlets, NvMeshDraw* draws)
+{
+	if (!path || !info)
+		return NV_EINVAL;
+	FILE* f = fopen(path, "rb");
+	if (!f)
+		return NV_EIO;
+	int rc = NV_OK;
+	const struct
+	{
+		void* dst;
+		uint64_t offset, bytes;
+	} parts[3] = { { meshlets, info->meshletOffset, (uint64_t)info->meshletCount * sizeof(NvMeshlet) },
+		           { meshes, info->meshOffset, (uint64_t)info->meshCount * sizeof(NvMesh) },
+		           { draws, info->drawOffset, (uint64_t)info->drawCount * sizeof(NvMeshDraw) } };
+	for (int i = 0; i < 3 && rc == NV_OK; ++i)
+	{
+		if (!parts[i].dst || !parts[i].bytes)
+			continue;
+		if (fseek(f, (long)parts[i].offset, SEEK_SET) != 0 || fread(parts[i].dst, 1, parts[i].bytes, f) != parts[i].bytes)
+			rc = NV_EIO;
+	}
+	fclose(f);
+	return rc;
 }
 
 // contiguous ranges, remainder spread over the first ranks

@@ -4,6 +4,7 @@ Mirrors the parts of niagara's main() that prepare cull inputs: CullData (src/ni
 pyramid geometry (:1340-1344), the synthetic scene (:969-998) and the visibility-slot prefix (:1002-1020).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -59,3 +60,21 @@ def shard_range(total, rank, world):
     b, e = C.c_uint64(0), C.c_uint64(0)
     lib.nv_shard_range(total, rank, world, C.byref(b), C.byref(e))
     return b.value, e.value
+
+
+def scenecache_info(path):
+    """header of a niagara .cache file (src/scenecache.cpp:16-55) + where its Meshlet / Mesh / MeshDraw arrays sit"""
+    from ._lib import SceneCacheInfo
+    info = SceneCacheInfo()
+    check(lib.nv_scenecache_info(os.fsencode(path), C.byref(info)), "nv_scenecache_info")
+    return info
+
+
+def scenecache_read(path):
+    """(info, meshes, meshlets, draws) of a niagara .cache file; the arrays are the raw struct arrays of the file"""
+    info = scenecache_info(path)
+    meshes = np.zeros(info.meshCount, dtype=L.MESH)
+    meshlets = np.zeros(info.meshletCount, dtype=L.MESHLET)
+    draws = np.zeros(info.drawCount, dtype=L.MESHDRAW)
+    check(lib.nv_scenecache_read(os.fsencode(path), C.byref(info), _p(meshes), _p(meshlets), _p(draws)), "nv_scenecache_read")
+    return info, meshes, meshlets, draws
