@@ -206,7 +206,10 @@ int nv_set_option(nv_context* ctx, int option, int value);
  * Builds the library-owned SoA mirror of the 12 cull bytes of every meshlet
  * (bounds: 4 x fp16 = 8 B, cone: 4 x s8 = 4 B).  nv_clustercull uses the mirror when
  * its d_meshlets argument equals the pointer registered here, and reads the 24-B AoS
- * records directly otherwise. */
+ * records directly otherwise.  The registration is by device pointer and the mirror is a
+ * snapshot: call again after the buffer's contents change, and before the allocation is
+ * freed or reused for something else — (NULL, 0) drops the registration (likewise for
+ * nv_upload_meshes). */
 int nv_upload_meshlets(nv_context* ctx, void* stream, const NvMeshlet* d_meshlets, uint32_t meshletCount);
 
 /* Upload hook next to uploadBuffer(mb) (src/niagara.cpp:1049): registers the Mesh table's pointer and size.  nv_drawcull

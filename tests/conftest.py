@@ -24,3 +24,14 @@ def pytest_configure(config):
 def has_gpu():
     import torch
     return torch.cuda.is_available()
+
+
+@pytest.fixture(autouse=True)
+def _drop_scene_registrations(request):
+    """nv_upload_meshlets / nv_upload_meshes register buffers by device pointer.  A context that is shared between tests
+    must not carry one test's registration into the next: torch's allocator hands the same addresses out again."""
+    if "ctx" in request.fixturenames:
+        c = request.getfixturevalue("ctx")
+        c.upload_meshlets(None, 0)
+        c.upload_meshes(None, 0)
+    yield

@@ -25,6 +25,11 @@ class GpuScene:
         if use_soa:
             ctx.upload_meshlets(self.mlb, len(scene["meshlets"]))
             ctx.upload_meshes(self.mb, len(scene["meshes"]))  # Mesh table staged in LDS; the other variant gathers it
+        else:
+            # the registrations are by device pointer: a context shared between scenes must drop the previous scene's, or a
+            # reused allocation would be taken for the buffer the mirror was built from
+            ctx.upload_meshlets(None, 0)
+            ctx.upload_meshes(None, 0)
 
     def depthreduce(self, depth):
         d = torch.from_numpy(np.ascontiguousarray(depth)).to(self.ctx.device)

@@ -83,3 +83,15 @@ def make_triangle_scene(seed=0, n_draws=60, commands_per_draw=3, viewport=(640, 
     cd = host.build_cull_data(cam_pos=cam_pos, cam_quat=cam_quat, draw_count=n_draws, viewport=viewport, cullingEnabled=1, clusterBackfaceEnabled=0)
     return dict(draws=draws, meshlets=meshlets, commands=commands, n=n, cull=cd, data=data, vertices=vertices,
                 globals=synth.make_globals(cd, viewport), count4=synth.count4_for(n), viewport=viewport)
+
+
+def random_case(seed):
+    """(make_scene kwargs, flags, use_soa, fused) drawn from a wide range: tiny and ragged draw counts, 1-8 meshes and LODs,
+    up to six task groups per draw, odd viewports down to 2 pixels, post-pass draws, zero-radius meshlets"""
+    rng = np.random.default_rng(seed)
+    kw = dict(seed=seed, n_draws=int(rng.integers(1, 3000)), n_meshes=int(rng.integers(1, 9)), lods=int(rng.integers(1, 9)),
+              meshlets_lod0=int(rng.integers(1, 400)), scene_radius=float(rng.uniform(5, 60)),
+              viewport=(int(rng.integers(2, 700)), int(rng.integers(2, 500))), post_pass_fraction=float(rng.choice([0.0, 0.0, 0.3])),
+              zero_radius_fraction=float(rng.choice([0.0, 0.05])))
+    flags = tuple(int(x) for x in rng.integers(0, 2, 5))
+    return kw, flags, bool(rng.integers(0, 2)), bool(rng.integers(0, 2))

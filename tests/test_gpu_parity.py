@@ -149,6 +149,22 @@ def test_two_frame_protocol(ctx, seed, use_soa, fused):
         assert fo[0]["late"]["cc4"][0] > 0
 
 
+def test_randomised_scenes(ctx):
+    """64 random cases of tools/experiments/fuzz_frames.py (which soaks thousands): sizes, LOD counts, viewports, flags,
+    layouts and fusion options drawn at random, three frames each, every buffer compared"""
+    from scenes import random_case
+    for seed in range(3000, 3064):
+        kw, flags, use_soa, fused = random_case(seed)
+        scene = make_scene(**kw)
+        fo = passes.run_frames(oracle, scene, flags, frames=3)
+        fg = G.run_frames(ctx, scene, flags, frames=3, use_soa=use_soa, fused=fused)
+        for a, b in zip(fo, fg):
+            assert a["pyramid"].tobytes() == b["pyramid"].tobytes(), (seed, kw)
+            for phase in ("early", "late"):
+                for key in ("count4", "commands", "cc4", "cib", "dvb", "mvb"):
+                    assert a[phase][key].tobytes() == b[phase][key].tobytes(), (seed, kw, flags, use_soa, fused, phase, key)
+
+
 def test_taskcull_payloads(ctx):
     scene = make_scene(seed=23, n_draws=800, meshlets_lod0=130)
     g = G.GpuScene(ctx, scene)
