@@ -50,7 +50,17 @@ NV_DEV uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
 }
 
 // drawcull.comp.glsl:56-118 + :154-155 for one draw
-template <bool LATE, bool TASK>
+// What a decision needs of a Mesh, 20 words (the decide kernel's LDS table when the Mesh table is registered):
+//   [0..3] center.xyz, radius   [4] lodCount   [5..11] lods[1..7].error   [12..19] lods[0..7].meshletCount
+constexpr uint32_t DC_LOD_WORDS = 20;
+// word k of that record = word lod_table_source(k) of the 52-word NvMesh
+NV_DEV uint32_t lod_table_source(uint32_t k)
+{
+	return k < 4u ? k : (k == 4u ? 8u : (k < 12u ? 12u + 5u * (k - 4u) + 4u : 12u + 5u * (k - 12u) + 3u));
+}
+
+// drawcull.comp.glsl:56-118 + :154-155 for one draw.  COMPACT: meshBase is the LDS table above, else the NvMesh array.
+template <bool LATE, bool TASK, bool COMPACT>
 NV_DEV DrawResult decide_draw(const DrawArgs& a, const char* meshBase, uint32_t di, const float4& d0, const float4& d1, const uint4& d2, uint32_t oldVis)
 {
 	const NvCullData& cd = a.cd;
@@ -62,7 +72,7 @@ NV_DEV DrawResult decide_draw(const DrawArgs& a, const char* meshBase, uint32_t 
 		return res;
 
 	const uint32_t meshIndex = d2.x;
-	const char* mesh = meshBase + (size_t)meshIndex * sizeof(NvMesh);
+	const char* mesh = meshBase + (size_t)meshIndex * (COMPACT ? DC_LOD_WORDS * 4u : sizeof(NvMesh));
 	const float4 cr = *reinterpret_cast<const float4*>(mesh); // center.xyz, radius
 
 	f3 q = { d1.x, d1.y, d1.z };
@@ -83,18 +93,34 @@ NV_DEV DrawResult decide_draw(const DrawArgs& a, const char* meshBase, uint32_t 
 		{
 			float distance = gl_max(length3(c) - radius, 0.0f);
 			float threshold = distance * cd.lodTarget / d0.w;
-			const uint32_t lodCount = *reinterpret_cast<const uint32_t*>(mesh + 32);
-			for (uint32_t i = 1; i < lodCount; ++i)
+			// drawcull.comp.glsl:108-110: the last LOD below the threshold.  All eight slots exist in the struct, so the
+			// errors are fetched together and the loop bound becomes part of the condition.
+			uint32_t lodCount;
+			float err[NV_MAX_LODS];
+			if (COMPACT)
 			{
-				float err = *reinterpret_cast<const float*>(mesh + 48 + 20 * i + 16);
-				if (err < threshold)
-					lodIndex = i;
+				const float4 e0 = reinterpret_cast<const float4*>(mesh)[1], e1 = reinterpret_cast<const float4*>(mesh)[2];
+				lodCount = __float_as_uint(e0.x);
+				err[1] = e0.y, err[2] = e0.z, err[3] = e0.w;
+				err[4] = e1.x, err[5] = e1.y, err[6] = e1.z, err[7] = e1.w;
 			}
+			else
+			{
+				lodCount = *reinterpret_cast<const uint32_t*>(mesh + 32);
+#pragma unroll
+				for (uint32_t i = 1; i < NV_MAX_LODS; ++i)
+					err[i] = *reinterpret_cast<const float*>(mesh + 48 + 20 * i + 16);
+			}
+#pragma unroll
+			for (uint32_t i = 1; i < NV_MAX_LODS; ++i)
+				if (i < lodCount && err[i] < threshold)
+					lodIndex = i;
 		}
 		res.lodWord = lodIndex | 0x100u;
 		if (TASK)
 		{
-			uint32_t meshletCount = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * lodIndex + 12);
+			uint32_t meshletCount = COMPACT ? reinterpret_cast<const uint32_t*>(mesh)[12 + lodIndex]
+			                                : *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * lodIndex + 12);
 			res.count = (meshletCount + NV_TASK_WGSIZE - 1) / NV_TASK_WGSIZE;
 		}
 		else
@@ -176,13 +202,57 @@ NV_DEV const char* stage_mesh_commit(const DrawArgs& a, const MeshStage& st, uin
 	return reinterpret_cast<const char*>(s_meshTable);
 }
 
+// The decide kernel's table: only the 20 words per mesh a decision reads (DC_LOD_WORDS), gathered from the NvMesh records
+// — 5 loads per thread instead of 13, and the LOD errors of a mesh in two 16-byte LDS reads.
+constexpr uint32_t DC_LOD_STAGE_WORDS = (DC_MESH_LDS * DC_LOD_WORDS + DC_THREADS - 1) / DC_THREADS;
+struct LodStage
+{
+	uint32_t w[DC_LOD_STAGE_WORDS];
+};
+
+template <bool MESH_LDS>
+NV_DEV LodStage stage_lod_issue(const DrawArgs& a)
+{
+	LodStage st;
+	if (MESH_LDS)
+	{
+		const uint32_t words = a.meshCount * DC_LOD_WORDS;
+		const uint32_t* src = reinterpret_cast<const uint32_t*>(a.meshes);
+#pragma unroll
+		for (uint32_t k = 0; k < DC_LOD_STAGE_WORDS; ++k)
+		{
+			const uint32_t i = k * DC_THREADS + threadIdx.x;
+			const uint32_t j = i < words ? i : 0u; // clamped: unconditional loads
+			st.w[k] = src[(j / DC_LOD_WORDS) * (uint32_t)(sizeof(NvMesh) / 4) + lod_table_source(j % DC_LOD_WORDS)];
+		}
+	}
+	return st;
+}
+
+template <bool MESH_LDS>
+NV_DEV const char* stage_lod_commit(const DrawArgs& a, const LodStage& st, uint32_t* s_lodTable)
+{
+	if (!MESH_LDS)
+		return reinterpret_cast<const char*>(a.meshes);
+	const uint32_t words = a.meshCount * DC_LOD_WORDS;
+#pragma unroll
+	for (uint32_t k = 0; k < DC_LOD_STAGE_WORDS; ++k)
+	{
+		const uint32_t i = k * DC_THREADS + threadIdx.x;
+		if (i < words)
+			s_lodTable[i] = st.w[k];
+	}
+	__syncthreads();
+	return reinterpret_cast<const char*>(s_lodTable);
+}
+
 // K1
 template <bool LATE, bool TASK, bool MESH_LDS>
 __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 {
 	// the Mesh table (center/radius, LOD errors, LOD ranges) is read by every draw: staged once per workgroup when
 	// nv_upload_meshes registered a table of at most DC_MESH_LDS meshes, otherwise gathered from global memory
-	__shared__ __attribute__((aligned(16))) uint32_t s_meshTable[MESH_LDS ? DC_MESH_LDS * sizeof(NvMesh) / 4 : 4];
+	__shared__ __attribute__((aligned(16))) uint32_t s_lodTable[MESH_LDS ? DC_MESH_LDS * DC_LOD_WORDS : 4];
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
@@ -204,7 +274,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 
 	// Indices past the tile are clamped, not branched, so that the loads are unconditional and the compiler can count
 	// them (s_waitcnt vmcnt(N)) instead of draining after each one.
-	const MeshStage st = stage_mesh_issue<MESH_LDS>(a);
+	const LodStage st = stage_lod_issue<MESH_LDS>(a);
 	DrawLoad ld[DC_BATCH];
 #pragma unroll
 	for (int j = 0; j < DC_BATCH; ++j)
@@ -212,7 +282,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 		const uint32_t c = j * DC_THREADS + tid;
 		ld[j] = load_draw_record(a, first + (c < n ? c : n - 1));
 	}
-	const char* meshBase = stage_mesh_commit<MESH_LDS>(a, st, s_meshTable);
+	const char* meshBase = stage_lod_commit<MESH_LDS>(a, st, s_lodTable);
 
 	// per wave-batch command counts -> LDS; merged per scatter tile below
 	__shared__ uint32_t s_waveCount[DC_BATCH * DC_WAVES];
@@ -227,7 +297,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 			if (a.debugMode & 1u) // experiments: loads only
 				res.lodWord = __float_as_uint(ld[j].d0.x + ld[j].d1.x) + ld[j].d2.x + ld[j].oldVis == 12345u ? 0x100u : 0u;
 			else
-				res = decide_draw<LATE, TASK>(a, meshBase, first + c, ld[j].d0, ld[j].d1, ld[j].d2, ld[j].oldVis);
+				res = decide_draw<LATE, TASK, MESH_LDS>(a, meshBase, first + c, ld[j].d0, ld[j].d1, ld[j].d2, ld[j].oldVis);
 			a.results[first + c] = (uint8_t)((res.lodWord & 7u) | ((res.lodWord >> 8 & 1u) << 3) | ((ld[j].oldVis != 0 ? 1u : 0u) << 4));
 			count = res.count;
 		}
