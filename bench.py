@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=4.0)
     ap.add_argument("--aos", action="store_true", help="read the 24-B AoS meshlets in place (no SoA mirror)")
+    ap.add_argument("--counts-batch", type=int, default=8, help="N > 1: passes whose counts share one all-reduce (1 = one collective per pass)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for functional tests)")
     ap.add_argument("--shared-device", action="store_true", help="functional test only: all ranks use cuda:0 (needs --backend gloo)")
     ap.add_argument("--explicit-reset", action="store_true",
@@ -92,14 +93,14 @@ def main():
     dccb = torch.from_numpy(count4.view(np.int32).copy()).to(dev)
     cib = torch.zeros(min(n_meshlets, L.CLUSTER_LIMIT) + 256, dtype=torch.int32, device=dev)
     ccb = torch.zeros(4, dtype=torch.int32, device=dev)
-    # N > 1: the pass's counts are summed over the ranks with one 24-byte all-reduce per pass.  It is
-    # latency-bound (tens of microseconds, comparable to the pass itself), so it is issued asynchronously on the
-    # collective's own stream and only waited for COUNTS_RING passes later, when its buffer is reused: the reduction of
-    # pass i overlaps the cull of passes i+1.. instead of serialising with them.
-    COUNTS_RING = 8
-    counts_ring = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(COUNTS_RING)]
-    pending = [None] * COUNTS_RING
-    counts = counts_ring[0]
+    # N > 1: the passes' counts are summed over the ranks.  Nothing on the data path waits for them, so
+    # they are (a) written by the scatter launch itself (nv_set_counts_sink: no extra launch per pass) into row i % B of a
+    # [B, 3] int64 block and (b) reduced B passes at a time — one asynchronous all-reduce of the block on the
+    # collective's own stream, waited for only when its block comes round again (two blocks alternate).  Every pass's
+    # counts are reduced inside the timed region; per pass that is 1/B of a latency-bound collective instead of one.
+    B = max(1, args.counts_batch)
+    blocks = [torch.zeros((B, 3), dtype=torch.int64, device=dev) for _ in range(2)]
+    pending = [None, None]
     if not args.aos:
         ctx.upload_meshlets(mlb, copies * n_meshlets)
     torch.cuda.synchronize()
@@ -107,23 +108,30 @@ def main():
     def step(i):
         if args.explicit_reset:
             ctx.reset_count(ccb)  # the caller's vkCmdFillBuffer(ccb, 0, 4, 0) as its own launch
-        ctx.clustercull(cd, 0, dcbs[i % copies], dccb, db, mlb, None, None, cib, ccb)
         if world > 1:
-            slot = i % COUNTS_RING
-            if pending[slot] is not None:
-                pending[slot].wait()
-            ctx.pack_counts(None, dccb, ccb, counts_ring[slot])
-            pending[slot] = dist.all_reduce(counts_ring[slot], async_op=True)
+            blk, row = (i // B) % 2, i % B
+            if row == 0 and pending[blk] is not None:
+                pending[blk].wait()  # the block's previous reduction (issued 2 B passes ago)
+                pending[blk] = None
+            ctx.set_counts_sink(blocks[blk][row])
+        ctx.clustercull(cd, 0, dcbs[i % copies], dccb, db, mlb, None, None, cib, ccb)
+        if world > 1 and i % B == B - 1:
+            pending[(i // B) % 2] = dist.all_reduce(blocks[(i // B) % 2], async_op=True)
 
-    def drain():
-        for k in range(COUNTS_RING):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
+    def drain(n_steps):
+        """reduces the rows of a batch the loop left unfinished, then waits for everything in flight"""
+        if world > 1:
+            if n_steps % B:
+                blk = (n_steps // B) % 2
+                pending[blk] = dist.all_reduce(blocks[blk], async_op=True)
+            for k in range(2):
+                if pending[k] is not None:
+                    pending[k].wait()
+                    pending[k] = None
 
     for i in range(args.warmup):
         step(i)
-    drain()
+    drain(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -133,13 +141,13 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    drain()  # every pass's reduction has completed inside the timed region
+    drain(args.steps)  # every pass's reduction has completed inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    last_counts = counts_ring[(args.steps - 1) % COUNTS_RING].clone() if world > 1 else None
+    last_counts = blocks[((args.steps - 1) // B) % 2][(args.steps - 1) % B].clone() if world > 1 else None
 
     # ---- roofline leg: the same `steps` passes again with the library's HIP events bracketing each kernel on the
     # launch stream (nv_profile_*).  It is a separate loop because an event record is itself a barrier packet: three
@@ -148,7 +156,7 @@ def main():
     t1 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    drain()
+    drain(args.steps)
     torch.cuda.synchronize()
     profiled = time.perf_counter() - t1
     prof = ctx.profile_read()
@@ -197,7 +205,8 @@ def main():
                                    % (n_meshlets, n_cmd, n_draws),
                        "meshlets_per_gpu": n_meshlets, "commands_per_gpu": n_cmd, "draws_per_gpu": n_draws,
                        "input_copies_rotated": copies, "count_reset": "explicit launch" if args.explicit_reset else "fused (NV_OPT_FUSED_COUNT_RESET)", "meshlet_layout": "AoS24" if args.aos else "SoA12",
-                       "visible_per_gpu": visible, "visible_total": total_visible, "sharding": "commands x%d" % world},
+                       "visible_per_gpu": visible, "visible_total": total_visible, "sharding": "commands x%d" % world,
+                       "counts_allreduce": ("none (N=1)" if world == 1 else "one async all-reduce of [%d, 3] int64 per %d passes, rows written by the scatter launch" % (B, B))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_note, "kernel": "cluster_mask_kernel", "kernel_avg_us": kernel_avg_s * 1e6,
                          "algorithmic_bytes": algo_bytes, "launches_timed": cull_n,

@@ -330,6 +330,10 @@ int nv_synth_draws(NvMeshDraw* draws, uint32_t drawCount, uint32_t meshCount, fl
 
 /* ---- multi-GPU helper: contiguous shard of `total` units for `rank` ---- */
 void nv_shard_range(uint64_t total, uint32_t rank, uint32_t world, uint64_t* begin, uint64_t* end);
+/* Where the next nv_clustercull calls also leave {0, d_count4[0], final cluster count} as three u64 — the words
+ * nv_pack_counts(NULL, d_count4, d_clusterCount4, d_out3) would write, from the scatter launch that computes the count,
+ * so a sharded caller feeds its all-reduce without one more launch per pass.  NULL (the default) turns it off. */
+int nv_set_counts_sink(nv_context* ctx, uint64_t* d_out3);
 /* packs {count4a[0], count4b[0], count4c[0]} (any may be NULL -> 0) into d_out[3] as u64,
  * the payload of the one ncclAllReduce(sum) per phase */
 int nv_pack_counts(nv_context* ctx, void* stream, const uint32_t* d_countA, const uint32_t* d_countB,

@@ -73,6 +73,7 @@ _SIGS = {
     "nv_synth_draws": (_i, [_vp, _u32, _u32, _f]),
     "nv_shard_range": (None, [C.c_uint64, _u32, _u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "nv_pack_counts": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "nv_set_counts_sink": (_i, [_vp, _vp]),
     "nv_scenecache_info": (_i, [C.c_char_p, C.POINTER(SceneCacheInfo)]),
     "nv_scenecache_read": (_i, [C.c_char_p, C.POINTER(SceneCacheInfo), _vp, _vp, _vp]),
     "nv_probe_cluster_scalars": (_i, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, C.POINTER(PyramidDesc), _vp]),

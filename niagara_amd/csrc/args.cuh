@@ -62,6 +62,7 @@ struct ClusterArgs
 	uint32_t debugMode; // tuning experiments only (NV_DEBUG_MODE); 0 in production
 	uint32_t fusedReset; // NV_OPT_FUSED_COUNT_RESET
 	uint32_t fusedSubmit; // NV_OPT_FUSED_SUBMIT
+	unsigned long long* countsSink; // nv_set_counts_sink (nullptr: off)
 };
 
 struct DrawArgs

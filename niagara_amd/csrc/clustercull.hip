@@ -1283,6 +1283,12 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs
 		{
 			if (a.fusedReset)
 				a.clusterCount4[0] = 0;
+			if (a.countsSink)
+			{
+				a.countsSink[0] = 0;
+				a.countsSink[1] = a.count4[0];
+				a.countsSink[2] = a.fusedReset ? 0u : a.clusterCount4[0];
+			}
 			if (a.fusedSubmit)
 			{
 				const uint32_t raw = a.fusedReset ? 0u : a.clusterCount4[0];
@@ -1323,7 +1329,15 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs
 		total += s_sum[w];
 	}
 	if (tid == 0 && tile == numTiles - 1)
+	{
 		a.clusterCount4[0] = total; // what the chain of atomicAdds leaves in clusterCount
+		if (a.countsSink) // nv_set_counts_sink: the payload of a sharded caller's all-reduce
+		{
+			a.countsSink[0] = 0;
+			a.countsSink[1] = a.count4[0];
+			a.countsSink[2] = total;
+		}
+	}
 	if (a.fusedSubmit && tile == numTiles - 1)
 	{
 		// NV_OPT_FUSED_SUBMIT: clustersubmit.comp.glsl:25-45 from the workgroup that knows the final count.  The padding

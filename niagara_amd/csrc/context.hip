@@ -72,6 +72,7 @@ struct nv_context
 	uint32_t* hintDevice;
 	uint32_t fusedReset;
 	uint32_t fusedSubmit;
+	uint64_t* countsSink; // nv_set_counts_sink
 	// nv_profile_*: event pairs recorded on the launch stream, drained by nv_profile_read
 	int profiling;
 	std::vector<ProfRecord>* prof;
@@ -482,6 +483,7 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	a.debugMode = ctx->debugMode;
 	a.fusedReset = ctx->fusedReset;
 	a.fusedSubmit = ctx->fusedSubmit;
+	a.countsSink = reinterpret_cast<unsigned long long*>(ctx->countsSink);
 	if (ctx->debugMode & 8u)
 	{
 		if (!ctx->timing)
@@ -588,6 +590,14 @@ int nv_debug_read_timing(nv_context* ctx, unsigned long long* out, uint32_t maxW
 	if (waves > maxWaves)
 		waves = maxWaves;
 	return (int)hipMemcpy(out, ctx->timing, (size_t)waves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+
+int nv_set_counts_sink(nv_context* ctx, uint64_t* d_out3)
+{
+	if (!ctx)
+		return NV_EINVAL;
+	ctx->countsSink = d_out3;
+	return NV_OK;
 }
 
 int nv_pack_counts(nv_context* ctx, void* stream, const uint32_t* d_countA, const uint32_t* d_countB,

@@ -117,6 +117,10 @@ class Context:
     def depthreduce(self, depth, width, height, pyramid):
         check(lib.nv_depthreduce(self.h, _stream(), _ptr(depth), width, height, C.byref(pyramid)), "nv_depthreduce")
 
+    def set_counts_sink(self, out3):
+        """the next clustercull calls also write {0, dccb[0], cluster count} (3 x u64) to out3; None turns it off"""
+        check(lib.nv_set_counts_sink(self.h, _ptr(out3)), "nv_set_counts_sink")
+
     def pack_counts(self, a, b, c, out3):
         check(lib.nv_pack_counts(self.h, _stream(), _ptr(a), _ptr(b), _ptr(c), _ptr(out3)), "nv_pack_counts")
 

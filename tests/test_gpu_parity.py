@@ -564,6 +564,33 @@ def test_fused_submit_option(ctx, empty):
     ctx.status()
 
 
+@pytest.mark.parametrize("n_draws", [0, 900])
+def test_counts_sink_equals_pack_counts(ctx, n_draws):
+    """nv_set_counts_sink: the scatter launch leaves what nv_pack_counts(NULL, dccb, ccb) would write; off again afterwards"""
+    draws, meshlets, commands, n, cd = _cluster_inputs(max(n_draws, 1), 3)
+    if n_draws == 0:
+        n = 0
+        commands = commands[:64].copy()
+        commands["taskCount"] = 0
+    dev = ctx.device
+    db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+    dccb = torch.from_numpy(synth.count4_for(n).view(np.int32).copy()).to(dev)
+    cib = torch.zeros(n * 64 + 256, dtype=torch.int32, device=dev)
+    ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+    sink = torch.full((3,), -1, dtype=torch.int64, device=dev)
+    packed = torch.zeros(3, dtype=torch.int64, device=dev)
+    ctx.set_counts_sink(sink)
+    ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
+    ctx.set_counts_sink(None)
+    ctx.pack_counts(None, dccb, ccb, packed)
+    assert sink.cpu().tolist() == packed.cpu().tolist() == [0, n, int(ccb[0].item())]
+    sink.fill_(-1)
+    ctx.reset_count(ccb)
+    ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
+    assert sink.cpu().tolist() == [-1, -1, -1]
+    ctx.status()
+
+
 def test_cluster_expand_decodes_the_lists_like_the_mesh_stage(ctx):
     """§8f N1: the consumer's view of the output (meshlet.mesh.glsl:91-116): grid {16,Y,16} walk, ~0 padding, command /
     meshlet decode, header fields and totals — HIP vs oracle on a full drawcull -> tasksubmit -> clustercull ->
