@@ -69,6 +69,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        # communicator set-up (lazy in RCCL) belongs to neither the warm-up nor the timed steps
+        dist.all_reduce(torch.zeros(1, dtype=torch.int64, device=dev))
+        torch.cuda.synchronize()
 
     # ---- inputs: rank r owns commands [r*C, (r+1)*C) of a world*C command pool; weak scaling
     n_draws, cpd = args.draws, args.commands_per_draw
