@@ -186,9 +186,9 @@ NV_DEV void update_visibility_words(const ClusterArgs& a, uint32_t off, uint32_t
 // applies the visibility-bit update (or hands the visible ballot to the caller through visOut).  All arguments except `l` are wave-uniform.
 // BITS = (clusterOcclusionEnabled == 1 && postPass == 0), resolved on the host so that the variant without
 // visibility bits carries no load for them.
-template <bool LATE, bool BITS>
+template <bool LATE, bool BITS, bool TABLE = false>
 NV_DEV uint64_t cull_command(const ClusterArgs& a, const NvMeshTaskCommand& cmd, const DrawUniform& u, const LaneData& l, uint32_t lane,
-                             uint64_t* visOut = nullptr)
+                             uint64_t* visOut = nullptr, const uint32_t* mipOffsets = nullptr)
 {
 	const NvCullData& cd = a.cd;
 	const bool valid = lane < cmd.taskCount;
@@ -223,7 +223,7 @@ NV_DEV uint64_t cull_command(const ClusterArgs& a, const NvMeshTaskCommand& cmd,
 		}
 
 		if (LATE && cd.clusterOcclusionEnabled == 1 && visible && !(a.debugMode & 512u)) // bit 9 (experiments): no HiZ
-			visible = hiz_test(cd, a.pyr, c, r);
+			visible = hiz_test<TABLE>(cd, a.pyr, c, r, mipOffsets); // TABLE: the pyramid's level offsets from LDS
 	}
 
 	const uint64_t visMask = __ballot(visible);
@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 							cur.mvbWord = ring[k].mvbWord;
 							uint64_t vis = 0;
 							if (!(a.debugMode & 4096u)) // bit 12 (experiments): exact pass loads only
-								m = cull_command<LATE, BITS>(a, cmd, du, cur, lane, &vis);
+								m = cull_command<LATE, BITS, LATE>(a, cmd, du, cur, lane, &vis, s_mipOffset);
 							maskLo = writelane_u32(maskLo, (uint32_t)m, c);
 							maskHi = writelane_u32(maskHi, (uint32_t)(m >> 32), c);
 							if (updateBits)
@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 						du = segment_draw(r, c);
 					}
 					uint64_t vis = 0;
-					m = cull_command<LATE, BITS>(a, cmd, du, cur, lane, &vis);
+					m = cull_command<LATE, BITS, LATE>(a, cmd, du, cur, lane, &vis, s_mipOffset);
 					if (updateBits)
 					{
 						visLo = writelane_u32(visLo, (uint32_t)vis, c);

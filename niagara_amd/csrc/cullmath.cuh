@@ -317,9 +317,13 @@ NV_DEV bool hiz_finish(const HizProbe& p, float t00, float t10, float t01, float
 }
 
 // drawcull.comp.glsl:86-99 / clustercull.comp.glsl:110-123: returns the sphere's visibility against the pyramid
-NV_DEV bool hiz_test(const NvCullData& cd, const NvPyramidDesc& pyr, f3 c, float r)
+// TABLE: mipOffsets is a copy of pyr.mipOffset in LDS (see hiz_prepare); otherwise the descriptor's own array is indexed.
+// A compile-time choice: selecting between the two pointers at run time would make the access a flat load and put the
+// kernel-argument array in scratch.
+template <bool TABLE = false>
+NV_DEV bool hiz_test(const NvCullData& cd, const NvPyramidDesc& pyr, f3 c, float r, const uint32_t* mipOffsets = nullptr)
 {
-	const HizProbe p = hiz_prepare(cd, pyr, c, r, pyr.mipOffset);
+	const HizProbe p = TABLE ? hiz_prepare(cd, pyr, c, r, mipOffsets) : hiz_prepare(cd, pyr, c, r, pyr.mipOffset);
 	if (!(p.use & 16u))
 		return true;
 	const float* base = pyr.d_base;

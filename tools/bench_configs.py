@@ -66,6 +66,37 @@ def config2(ctx, iters, n_draws=1_000_000, copies=6):
                 algorithmic_bytes=algo, achieved_GBs=algo / k_us / 1e3, frac=algo / k_us / 1e3 / HBM)
 
 
+def config2_late(ctx, iters, n_draws=1_000_000, copies=6, size=2048):
+    """the same 1 M draws through drawcull<LATE=1,TASK=0> with the HiZ test against a 2048^2 pyramid"""
+    dev = ctx.device
+    meshes, _ = synth.make_meshes(1, 8, 1 << 12)
+    meshes["center"] = (-0.016, -0.028, -0.034)
+    meshes["radius"] = 0.598
+    draws = host.synth_draws(n_draws, 1, 300.0)
+    host.assign_visibility_offsets(draws, meshes)
+    depth = torch.from_numpy(synth.make_depth(size, size)).to(dev)
+    pyr = P.DepthPyramid(dev, size, size)
+    ctx.depthreduce(depth, size, size, pyr.desc)
+    cd = host.build_cull_data(draw_count=n_draws, viewport=(size, size), pyramid=(pyr.width, pyr.height), cullingEnabled=1, lodEnabled=1, occlusionEnabled=1)
+    mb = P.to_device(meshes, dev)
+    ctx.upload_meshes(mb, len(meshes))
+    dbs = [P.to_device(draws, dev) for _ in range(copies)]
+    rng = np.random.default_rng(3)
+    dvb0 = torch.from_numpy(rng.integers(0, 2, n_draws).astype(np.int32)).to(dev)
+    dvbs = [dvb0.clone() for _ in range(copies)]
+    dcb = torch.zeros(n_draws * 24 + 64, dtype=torch.uint8, device=dev)
+    dccb = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    def step(i):
+        dvbs[i % copies].copy_(dvb0)
+        ctx.reset_count(dccb)
+        ctx.drawcull(cd, 1, 0, dbs[i % copies], mb, dcb, dccb, dvbs[i % copies], pyr.desc)
+
+    wall, k_us, _ = timed(ctx, step, iters, "drawcull")
+    return dict(config="2L: 1M draws, drawcull<1,0> with HiZ", draws=n_draws, visible=int(dccb[0].item()), kernel_us=k_us, step_us=wall,
+                draws_per_s=n_draws / (k_us * 1e-6))
+
+
 def config3b(ctx, iters, n_draws=15625 * 4, fused=False):
     """contract path: drawcull<0,TASK> (LOD on, 64 meshes x 4 LODs) -> tasksubmit -> clustercull<0>"""
     dev = ctx.device
@@ -200,7 +231,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     ctx = P.Context(0)
-    runs = {"2": lambda: config2(ctx, a.iters), "3b": lambda: config3b(ctx, a.iters), "3b_fused": lambda: config3b(P.Context(0), a.iters, fused=True), "4": lambda: config4(ctx, a.iters),
+    runs = {"2": lambda: config2(ctx, a.iters), "2l": lambda: config2_late(ctx, a.iters), "3b": lambda: config3b(ctx, a.iters), "3b_fused": lambda: config3b(P.Context(0), a.iters, fused=True), "4": lambda: config4(ctx, a.iters),
             "4b": lambda: config4(ctx, a.iters, size=1024), "n4": lambda: config_n4(ctx, a.iters),
             "big": lambda: roofline_size(ctx, max(5, a.iters // 3)), "big_aos": lambda: roofline_size(P.Context(0), max(5, a.iters // 3), aos=True)}
     for k, fn in runs.items():
