@@ -261,9 +261,12 @@ def cpu_baseline(args, cd, draws, meshlets, n_cmd, gpu_visible):
         spent += dt
     if int(cc4[0]) != gpu_visible:
         raise SystemExit("parity failure: CPU oracle sees %d visible meshlets, GPU %d" % (int(cc4[0]), gpu_visible))
-    med = sorted(times)[len(times) // 2]
-    return {"value": n_cmd * 64 / med, "unit": "meshlets/s", "cores": threads, "kind": "port",
-            "sample": "%d passes of the full %d-meshlet config3A batch, OpenMP oracle, median pass" % (len(times), n_cmd * 64)}
+    # the host is shared: passes scatter between the quiet-machine time and 20x that.  The baseline is the BEST pass (what
+    # the cores can do), the median is reported next to it.
+    best, med = min(times), sorted(times)[len(times) // 2]
+    return {"value": n_cmd * 64 / best, "unit": "meshlets/s", "cores": threads, "kind": "port",
+            "sample": "%d passes of the full %d-meshlet config3A batch, OpenMP oracle, best pass (%.1f ms; median %.1f ms)"
+                      % (len(times), n_cmd * 64, best * 1e3, med * 1e3)}
 
 
 if __name__ == "__main__":

@@ -29,10 +29,12 @@ json.dump(res, open("$out/traffic_raw.json", "w"), indent=1)
 # tallies the 128-B read requests of wide coalesced loads at 64 B -> x2.  Calibrated in this very run on soa_split_kernel,
 # whose byte counts are known exactly (reads 24 B, writes 12 B per meshlet of the 4 x 10 M-meshlet upload).
 def kern(sub):
+    """the template instance of the kernel with the most profiled launches (the first launch of a process runs another one)"""
+    best = {}
     for k, v in res.items():
-        if sub in k:
-            return v
-    return {}
+        if sub in k and max(x["launches"] for x in v.values()) > max([x["launches"] for x in best.values()] or [0]):
+            best = v
+    return best
 def mean(v, c):
     return v.get(c, {}).get("mean_per_launch")
 summary = {"command": "python bench.py --steps 20 --warmup 3 --no-cpu-baseline", "meshlets_per_gpu": 10000000, "meshlet_layout": "SoA12",
