@@ -193,6 +193,12 @@ inline uint atomicAdd(uint& mem, uint v)
 	mem = old + v;
 	return old;
 }
+inline int atomicAdd(int& mem, int v) /* shared int sharedCount (meshlet.task.glsl:50) */
+{
+	int old = mem;
+	mem = old + v;
+	return old;
+}
 inline uint atomicOr(uint& mem, uint v)
 {
 	uint old = mem;

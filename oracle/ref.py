@@ -56,6 +56,11 @@ def meshlet_mesh(globals_, commands, draws, meshlets, meshlet_data, vertices, ci
                            C.c_uint32(len(masks)), _p(totals3))
 
 
+def meshlet_task(cd, late, commands, count4, draws, meshlets, mvb, pyr, payloads, payload_counts):
+    """src/shaders/meshlet.task.glsl (TASK_CULL = 1) over the grid in count4; see oracle/ref_runner.cpp"""
+    lib().ref_meshlet_task(_p(cd), int(late), _p(commands), _p(count4), _p(draws), _p(meshlets), _p(mvb), _pyr(pyr), _p(payloads), _p(payload_counts))
+
+
 def clustersubmit(cc4, cib):
     lib().ref_clustersubmit(_p(cc4), _p(cib))
 

@@ -36,6 +36,15 @@ static void SetMeshOutputsEXT(uint vertexCount, uint primitiveCount)
 static void barrier() {} /* the runner executes the workgroup twice instead (see ref_meshlet_mesh) */
 #endif
 
+#ifdef REF_MESHLET_TASK
+/* GL_EXT_mesh_shader built-ins of the task stage.  Invocations are serialised in ascending order, so the last one's
+ * EmitMeshTasksEXT carries the workgroup's final sharedCount; barrier() is honoured by the translator's --once rewrite of
+ * the shared counter's initialisation (oracle/Makefile) and by that ordering. */
+static uint ref_emitCount;
+static void EmitMeshTasksEXT(uint x, uint, uint) { ref_emitCount = x; }
+static void barrier() {}
+#endif
+
 namespace REF_NS
 {
 #include REF_GEN
@@ -53,7 +62,7 @@ struct RefPyramid
 	uint32_t totalTexels;
 };
 
-#if defined(REF_DRAWCULL) || defined(REF_CLUSTERCULL)
+#if defined(REF_DRAWCULL) || defined(REF_CLUSTERCULL) || defined(REF_MESHLET_TASK)
 static texture2D bind_pyramid(const RefPyramid* p)
 {
 	texture2D t = { 0, 0, 0, 0, 0 };
@@ -322,5 +331,38 @@ extern "C" void ref_meshlet_mesh(const void* globals_, void* commands, void* dra
 				if (index < capacity)
 					memcpy(masks4 + (size_t)index * 4, out, sizeof(out));
 			}
+}
+#endif
+
+#ifdef REF_MESHLET_TASK
+/* vkCmdDrawMeshTasksIndirectEXT(dccb, 4) of meshlet.task.glsl: grid (count4[1], count4[2] = 64, 1), one workgroup of
+ * TASK_WGSIZE = 64 invocations per task command (src/niagara.cpp:1660).  Per workgroup the payload's first
+ * EmitMeshTasksEXT-count entries and that count are handed back. */
+extern "C" void ref_meshlet_task(const void* cull, int late, void* commands, const uint32_t* count4, void* draws_, void* meshlets_, uint32_t* mvb,
+                                 const RefPyramid* pyr, uint32_t* payloads, uint32_t* payloadCounts)
+{
+	memcpy(&globals.cullData, cull, sizeof(CullData));
+	LATE = late != 0;
+	taskCommands = (MeshTaskCommand*)commands;
+	draws = (MeshDraw*)draws_;
+	meshlets = (Meshlet*)meshlets_;
+	meshletVisibility = mvb;
+	depthPyramid = bind_pyramid(pyr);
+	for (uint gx = 0; gx < count4[1]; ++gx)
+		for (uint gy = 0; gy < count4[2]; ++gy)
+		{
+			ref_emitCount = 0;
+			for (uint l = 0; l < 64; ++l)
+			{
+				gl_WorkGroupID.x = gx;
+				gl_WorkGroupID.y = gy;
+				gl_LocalInvocationID.x = l;
+				shader_main();
+			}
+			const uint commandId = gx * 64 + gy;
+			for (uint i = 0; i < ref_emitCount; ++i)
+				payloads[(size_t)commandId * 64 + i] = payload.clusterIndices[i];
+			payloadCounts[commandId] = ref_emitCount;
+		}
 }
 #endif

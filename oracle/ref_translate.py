@@ -23,6 +23,9 @@ Rewrites (nothing semantic):
     name[];` -> `T name[256];`, `taskPayloadSharedEXT` / `shared` qualifiers dropped (the runner serialises a workgroup).
 `--limit math.h:49` keeps only the first 49 lines of that include (the cull helpers; the rest is shading).
 `--define NAME=V` flips one of the reference's own `#define NAME ...` configuration switches (MESH_CULL, src/config.h:10-11).
+`--once "stmt;"` guards ONE statement with `if (gl_LocalInvocationID.x == 0u)`: a workgroup-shared variable that every
+invocation initialises in front of a barrier() (meshlet.task.glsl:64-65) is initialised once when the runner serialises
+the invocations of a workgroup — the only way barrier() can be honoured without threads.
 Also extracts line ranges of host C++ (PCG32, previousPow2, projection) with --lines.
 """
 import os
@@ -32,6 +35,7 @@ import sys
 
 LIMITS = {}  # basename -> number of leading lines to keep (e.g. math.h:49 = the cull helpers only)
 DEFINES = {}  # NAME -> value: rewrites the reference's own `#define NAME x` line
+ONCE = []  # statements executed by the first invocation of a workgroup only (barrier emulation)
 
 
 def inline_includes(path, seen=None):
@@ -66,6 +70,11 @@ def translate(src):
         src, n = re.subn(r"^(\s*#define\s+%s)\s+\S+[^\n]*$" % re.escape(name), r"\1 %s" % value, src, flags=re.M)
         if n != 1:
             raise SystemExit("--define %s: expected exactly one #define in the reference, found %d" % (name, n))
+
+    for stmt in ONCE:
+        if src.count(stmt) != 1:
+            raise SystemExit("--once %r: expected exactly one occurrence in the reference, found %d" % (stmt, src.count(stmt)))
+        src = src.replace(stmt, "if (gl_LocalInvocationID.x == 0u) " + stmt)
 
     def block(m):
         name, body = m.group(1), m.group(2)
@@ -105,10 +114,12 @@ def main():
             chunks.append("\n".join(lines[int(a) - 1:int(b)]))
         open(out, "w").write("\n\n".join(chunks) + "\n")
         return
-    while args[0] in ("--limit", "--define"):
+    while args[0] in ("--limit", "--define", "--once"):
         if args[0] == "--limit":
             name, n = args[1].split(":")
             LIMITS[name] = int(n)
+        elif args[0] == "--once":
+            ONCE.append(args[1])
         else:
             name, v = args[1].split("=")
             DEFINES[name] = v

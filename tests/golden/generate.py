@@ -62,6 +62,34 @@ def mesh_fixture():
     print("%-28s %6d bytes, clusters %d, triangles %d, kept %d" % ("mesh/trianglecull.npz", os.path.getsize(path), *totals))
 
 
+def task_fixture():
+    """tests/golden/mesh/taskcull.npz: task commands of a frame scene + what the reference TASK shader (meshlet.task.glsl, TASK_CULL = 1)
+    emits for them in the early and in the late pass: EmitMeshTasksEXT counts, payload entries, visibility words"""
+    scene = make_scene(seed=105, n_draws=900, meshlets_lod0=110, zero_radius_fraction=0.02)
+    from oracle import Pyramid
+    pyr = Pyramid(*scene["viewport"])
+    R.depthreduce(scene["depth"], pyr)
+    cd = passes.set_flags(scene["cull"], (1, 1, 1, 1, 1))
+    cmds, c4 = passes.run_drawcull(R, scene, cd, 0, 1, np.ones(len(scene["draws"]), np.uint32), pyr)
+    R.tasksubmit(c4, cmds)
+    rng = np.random.default_rng(9)
+    cmds["lateDrawVisibility"][:int(c4[0])] = rng.integers(0, 2, int(c4[0]))
+    ncmd = int(c4[1]) * 64
+    mvb0 = rng.integers(0, 2 ** 32, (scene["slots"] + 31) // 32 + 2, dtype=np.uint64).astype(np.uint32)
+    out = dict(meshlets=scene["meshlets"], draws=scene["draws"], cull=cd, depth=scene["depth"], viewport=np.array(scene["viewport"], np.uint32),
+               commands=cmds[:ncmd], count4=c4, mvb0=mvb0)
+    for late in (0, 1):
+        pay, cnt, mvb = np.zeros((ncmd, 64), np.uint32), np.zeros(ncmd, np.uint32), mvb0.copy()
+        R.meshlet_task(cd, late, cmds, c4, scene["draws"], scene["meshlets"], mvb, pyr, pay, cnt)
+        pay[np.arange(64)[None, :] >= cnt[:, None]] = 0  # entries past the emitted count are not part of the result
+        out["late%d_payloads" % late], out["late%d_counts" % late], out["late%d_mvb" % late] = pay, cnt, mvb
+    path = os.path.join(HERE, "mesh", "taskcull.npz")
+    np.savez_compressed(path, **out)
+    print("%-28s %6d bytes, %d commands, emitted early %d late %d" % ("mesh/taskcull.npz", os.path.getsize(path), ncmd, int(out["late0_counts"].sum()),
+                                                                     int(out["late1_counts"].sum())))
+
+
 if __name__ == "__main__":
     main()
     mesh_fixture()
+    task_fixture()

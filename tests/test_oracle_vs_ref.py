@@ -1,7 +1,7 @@
 """Pins the CPU oracle against the reference's own shader sources executing on the CPU (oracle/_ref).
 
 oracle/_ref = /root/reference/src/shaders/{drawcull,tasksubmit,clustercull,clustersubmit,depthreduce}.comp.glsl and
-math.h, rewritten syntactically by oracle/ref_translate.py and compiled against oracle/glsl_shim.h; plus verbatim
+math.h (and meshlet.task.glsl, meshlet.mesh.glsl), rewritten syntactically by oracle/ref_translate.py and compiled against oracle/glsl_shim.h; plus verbatim
 host helpers (src/niagara.cpp:424-481, src/resources.cpp:280-292).  Bit-exact agreement is required everywhere except
 the one documented place where the oracle deliberately differs: ceil(log2(x)) is exact in the oracle and libm-rounded
 in the shim (test_occlusion_mip_differs_only_just_above_powers_of_two).
@@ -267,3 +267,49 @@ def test_cluster_pass_postpass_matrix():
                         outs.append((cib, cc4, mvb))
                     for a, b in zip(*outs):
                         assert a.tobytes() == b.tobytes(), (late, coe, cbe, post)
+
+
+def test_taskcull_equals_the_reference_task_shader():
+    """meshlet.task.glsl (TASK_CULL = 1, src/config.h:8) executing on the CPU vs the oracle's taskcull: EmitMeshTasksEXT count,
+    payload entries and visibility words over LATE x clusterOcclusion x backface x postPass, on a scene's own task commands and on
+    the config-3 style command list"""
+    from niagara_amd import host, synth
+    rng = np.random.default_rng(17)
+    cases = []
+    # (a) commands produced by drawcull<TASK> -> tasksubmit of a frame scene
+    scene = make_scene(seed=23, n_draws=500, meshlets_lod0=130, zero_radius_fraction=0.02)
+    pyr = oracle.Pyramid(*scene["viewport"])
+    oracle.depthreduce(scene["depth"], pyr)
+    cd = passes.set_flags(scene["cull"], (1, 1, 1, 1, 1))
+    cmds, c4 = passes.run_drawcull(oracle, scene, cd, 0, 1, np.ones(len(scene["draws"]), np.uint32), pyr)
+    oracle.tasksubmit(c4, cmds)
+    cmds["lateDrawVisibility"][:int(c4[0])] = rng.integers(0, 2, int(c4[0]))
+    cases.append((cd, cmds, c4, scene["draws"], scene["meshlets"], (scene["slots"] + 31) // 32 + 2, pyr))
+    # (b) dense command list
+    draws, meshlets, commands, n = synth.cluster_scene(150, 4, seed=8)
+    draws["position"] *= np.float32(0.2)
+    commands["lateDrawVisibility"][:n] = rng.integers(0, 2, n)
+    cd2 = host.build_cull_data(draw_count=len(draws), cullingEnabled=1, pyramid=(pyr.width, pyr.height))
+    cases.append((cd2, commands, synth.count4_for(n), draws, meshlets, n * 2 + 3, pyr))
+    emitted = 0
+    for cd0, cmds, c4, draws, meshlets, words, pyr in cases:
+        ncmd = int(c4[1]) * 64
+        mvb0 = rng.integers(0, 2 ** 32, words, dtype=np.uint64).astype(np.uint32)
+        for late in (0, 1):
+            for coe in (0, 1):
+                for cbe in (0, 1):
+                    for post in (0, 1):
+                        c = cd0.copy()
+                        c["clusterOcclusionEnabled"], c["clusterBackfaceEnabled"], c["postPass"] = coe, cbe, post
+                        outs = []
+                        for fn in (oracle.taskcull, R.meshlet_task):
+                            pay, cnt, mvb = np.zeros((ncmd, 64), np.uint32), np.zeros(ncmd, np.uint32), mvb0.copy()
+                            fn(c, late, cmds, c4, draws, meshlets, mvb, pyr, pay, cnt)
+                            outs.append((pay, cnt, mvb))
+                        (po, co, mo), (pr, cr, mr) = outs
+                        assert (co == cr).all(), (late, coe, cbe, post)
+                        assert mo.tobytes() == mr.tobytes(), (late, coe, cbe, post)
+                        live = np.arange(64)[None, :] < co[:, None]
+                        assert (po[live] == pr[live]).all(), (late, coe, cbe, post)
+                        emitted += int(co.sum())
+    assert emitted > 10000
