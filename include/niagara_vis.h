@@ -52,7 +52,7 @@ extern "C" {
 #define NV_OK 0
 #define NV_EINVAL (-1)   /* bad argument */
 #define NV_ENOMEM (-2)   /* scratch allocation failed */
-#define NV_ESTATE (-3)   /* device-side protocol error (look-back spin bound hit) */
+#define NV_ESTATE (-3)   /* reserved (no pass has a device-side protocol any more); never returned */
 #define NV_ENODEV (-4)   /* no HIP device */
 #define NV_EIO (-5)      /* file cannot be opened / read */
 #define NV_EFORMAT (-6)  /* not a scene cache this build understands (magic, version, meshlet limits, truncated) */
