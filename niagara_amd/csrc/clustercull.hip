@@ -358,11 +358,15 @@ NV_DEV uint32_t indirect_command_count(const ClusterArgs& a)
 //                             of CC_CHUNK and wave w takes chunks w, w+W, w+2W, ...  (a tile-per-workgroup assignment
 //                             measured 2.5x spread between the fastest and slowest wave, because the commands of a
 //                             visible draw run the cone test on top of the frustum test and visible draws cluster).
-//   K2 cluster_scatter_kernel one workgroup per CU owns a contiguous range of commands, sums its ballots' popcounts,
-//                             runs the chained scan across the (<= 256, co-resident) workgroups — one 256-wide
-//                             look-back round — and scatters the IDs in command-major, lane-minor order.
+//                             Besides the ballot, K1 adds each command's survivor count to the counter of the scatter
+//                             tile the command falls in (one counter per 64-byte line, quad-aggregated adds).
+//   K2 cluster_scatter_kernel one workgroup per scatter tile (a contiguous range of commands, <= 512 tiles): its append
+//                             base = the count word as K1 found it + the counters of all earlier tiles, so no workgroup
+//                             waits on another; one scan over the tile's ballots, then the IDs are stored in
+//                             command-major, lane-minor order.  The last tile writes the final count (and, on request,
+//                             clustersubmit's words and the all-reduce payload).
 //
-// The ballots cost 8 B per 64 meshlets of extra traffic (1 %), the extra launch boundary ~2 us.
+// The ballots cost 8 B per 64 meshlets of extra traffic (1 %), the extra launch boundary ~4 us.
 constexpr uint32_t CC_CHUNK = 4; // consecutive commands per dealt chunk
 // CC_DA (template parameter of the cull kernel) = ring slots of the filter pass: CC_DA - 1 commands' bounds in flight behind
 // the one being filtered.  8 keep HBM saturated through the segment boundaries of a long stream (100 M meshlets: 198 us
