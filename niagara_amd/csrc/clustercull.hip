@@ -1567,7 +1567,7 @@ int launch_cluster_mask(hipStream_t stream, const ClusterArgs& a, int late, bool
 
 bool clustercull_prefers_shallow(uint32_t previousCommandCount) { return previousCommandCount != 0 && previousCommandCount <= CC_SHALLOW_COMMANDS; }
 
-// scatterBlocks workgroups wait on each other: the grid must be co-resident (context.hip launches one per CU)
+// one workgroup per scatter tile (context.hip: one per CU, at most CC_MAX_SCATTER_TILES); no workgroup waits on another
 int launch_cluster_scatter(hipStream_t stream, const ClusterArgs& a, uint32_t scatterBlocks)
 {
 	hipLaunchKernelGGL((cluster_scatter_kernel<0>), dim3(scatterBlocks), dim3(CC_THREADS), 0, stream, a);
