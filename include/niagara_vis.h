@@ -328,6 +328,11 @@ int nv_assign_visibility_offsets(NvMeshDraw* draws, uint32_t drawCount, const Nv
 /* src/niagara.cpp:449-481,969-998: PCG32-seeded synthetic scene (state 0x42) */
 int nv_synth_draws(NvMeshDraw* draws, uint32_t drawCount, uint32_t meshCount, float sceneRadius);
 
+/* src/scene.cpp:207-220: Mesh.center = mean of the positions (fp32, accumulated in array order), Mesh.radius = the
+ * largest distance from it — the bounding sphere drawcull tests (the part of the asset pipeline that is the reference's
+ * own arithmetic; meshlet bounds are meshoptimizer's).  positions = vertexCount x {x, y, z}. */
+int nv_mesh_bounds(const float* positions, uint32_t vertexCount, float out_center[3], float* out_radius);
+
 /* ---- multi-GPU helper: contiguous shard of `total` units for `rank` ---- */
 void nv_shard_range(uint64_t total, uint32_t rank, uint32_t world, uint64_t* begin, uint64_t* end);
 /* Where the next nv_clustercull calls also leave {0, d_count4[0], final cluster count} as three u64 — the words

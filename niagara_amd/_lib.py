@@ -71,6 +71,7 @@ _SIGS = {
     "nv_build_cull_data": (_i, [_vp, _vp, _vp, _f, _f, _f, _u32, _u32, _u32, _u32, _u32, _i]),
     "nv_assign_visibility_offsets": (_i, [_vp, _u32, _vp, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
     "nv_synth_draws": (_i, [_vp, _u32, _u32, _f]),
+    "nv_mesh_bounds": (_i, [_vp, _u32, _vp, _vp]),
     "nv_shard_range": (None, [C.c_uint64, _u32, _u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "nv_pack_counts": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "nv_set_counts_sink": (_i, [_vp, _vp]),

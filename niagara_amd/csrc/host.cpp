@@ -195,6 +195,38 @@ int nv_synth_draws(NvMeshDraw* draws, uint32_t drawCount, uint32_t meshCount, fl
 	return NV_OK;
 }
 
+// src/scene.cpp:207-220 with glm's component-wise forms: center += v; center /= float(n); radius = max(radius,
+// distance(center, v)), distance = sqrt((dx*dx + dy*dy) + dz*dz).  Sequential on purpose: the sum's rounding is part of
+// the result.
+int nv_mesh_bounds(const float* positions, uint32_t vertexCount, float out_center[3], float* out_radius)
+{
+	if (!positions || !out_center || !out_radius || vertexCount == 0)
+		return NV_EINVAL;
+	float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+	for (uint32_t i = 0; i < vertexCount; ++i)
+	{
+		cx += positions[3 * i + 0];
+		cy += positions[3 * i + 1];
+		cz += positions[3 * i + 2];
+	}
+	const float n = (float)vertexCount;
+	cx /= n;
+	cy /= n;
+	cz /= n;
+	float radius = 0.0f;
+	for (uint32_t i = 0; i < vertexCount; ++i)
+	{
+		const float dx = cx - positions[3 * i + 0], dy = cy - positions[3 * i + 1], dz = cz - positions[3 * i + 2];
+		const float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+		radius = radius < d ? d : radius; // std::max(radius, d)
+	}
+	out_center[0] = cx;
+	out_center[1] = cy;
+	out_center[2] = cz;
+	*out_radius = radius;
+	return NV_OK;
+}
+
 // ---- scene cache (src/scenecache.cpp) ----
 // SceneHeader, src/scenecache.cpp:16-55, as the reference's compiler lays it out (vec3 / quat are plain floats; the
 // uint64_t makes the struct 8-aligned): 160 bytes.

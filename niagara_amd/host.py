@@ -78,3 +78,11 @@ def scenecache_read(path):
     draws = np.zeros(info.drawCount, dtype=L.MESHDRAW)
     check(lib.nv_scenecache_read(os.fsencode(path), C.byref(info), _p(meshes), _p(meshlets), _p(draws)), "nv_scenecache_read")
     return info, meshes, meshlets, draws
+
+
+def mesh_bounds(positions):
+    """Mesh.center / Mesh.radius of src/scene.cpp:207-220 over an (n, 3) float32 array"""
+    pos = np.ascontiguousarray(positions, np.float32)
+    center, radius = np.zeros(3, np.float32), np.zeros(1, np.float32)
+    check(lib.nv_mesh_bounds(_p(pos), len(pos), _p(center), _p(radius)), "nv_mesh_bounds")
+    return center, radius[0]

@@ -156,6 +156,22 @@ inline mat4 transpose(const mat4& m)
 inline vec3 cross(vec3 a, vec3 b) { return vec3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 inline float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 inline float length(vec3 a) { return sqrtf(dot(a, a)); }
+/* glm forms used by the host lines compiled verbatim (src/scene.cpp:207-220): component-wise, division is division */
+inline float distance(vec3 a, vec3 b) { return length(vec3(a.x - b.x, a.y - b.y, a.z - b.z)); }
+inline vec3& operator+=(vec3& a, vec3 b)
+{
+	a.x += b.x;
+	a.y += b.y;
+	a.z += b.z;
+	return a;
+}
+inline vec3& operator/=(vec3& a, float s)
+{
+	a.x /= s;
+	a.y /= s;
+	a.z /= s;
+	return a;
+}
 inline float sqrt(float x) { return sqrtf(x); }
 inline float abs(float x) { return fabsf(x); }
 inline float ceil(float x) { return ceilf(x); }

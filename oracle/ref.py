@@ -61,6 +61,15 @@ def meshlet_task(cd, late, commands, count4, draws, meshlets, mvb, pyr, payloads
     lib().ref_meshlet_task(_p(cd), int(late), _p(commands), _p(count4), _p(draws), _p(meshlets), _p(mvb), _pyr(pyr), _p(payloads), _p(payload_counts))
 
 
+def mesh_bounds(positions):
+    """src/scene.cpp:207-220 (mean centre, max distance) over an (n, 3) float32 array -> (center[3], radius)"""
+    import numpy as np
+    pos = np.ascontiguousarray(positions, np.float32)
+    center, radius = np.zeros(3, np.float32), np.zeros(1, np.float32)
+    lib().ref_mesh_bounds(_p(pos), C.c_uint32(len(pos)), _p(center), _p(radius))
+    return center, radius[0]
+
+
 def clustersubmit(cc4, cib):
     lib().ref_clustersubmit(_p(cc4), _p(cib))
 

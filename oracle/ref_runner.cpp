@@ -274,6 +274,30 @@ extern "C" void ref_perspective(float fovY, float aspect, float znear, float out
 }
 #endif
 
+#ifdef REF_HOST
+#include <algorithm>
+#include <vector>
+/* src/scene.cpp:207-220 compiled verbatim inside a function that supplies the names those statements use: `positions`
+ * (the de-quantised vertex positions), `vertices` (only its size), `mesh` (center, radius) */
+extern "C" void ref_mesh_bounds(const float* xyz, uint32_t count, float out_center[3], float* out_radius)
+{
+	std::vector<vec3> positions(count);
+	for (uint32_t i = 0; i < count; ++i)
+		positions[i] = vec3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+	std::vector<int> vertices(count);
+	struct
+	{
+		vec3 center;
+		float radius;
+	} mesh;
+#include "_ref/host_bounds.gen.h"
+	out_center[0] = mesh.center.x;
+	out_center[1] = mesh.center.y;
+	out_center[2] = mesh.center.z;
+	*out_radius = mesh.radius;
+}
+#endif
+
 #ifdef REF_MESHLET_MESH
 /* vkCmdDrawMeshTasksIndirectEXT(ccb, 4) of meshlet.mesh.glsl without a task stage (TASK = false): one workgroup of
  * MESH_WGSIZE = 64 invocations per grid cell {x < cc4[1], y < cc4[2], z < cc4[3]} (src/niagara.cpp:1664).  The shader

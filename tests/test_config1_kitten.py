@@ -39,11 +39,7 @@ def bounds_from_obj(path):
     key = np.concatenate([half.view(np.uint16).astype(np.int64), q.astype(np.int64)], axis=1)
     _, first = np.unique(key, axis=0, return_index=True)
     uniq = half[np.sort(first)].astype(np.float32)               # src/scene.cpp:193-198
-    center = np.zeros(3, np.float32)
-    for p in uniq:                                               # src/scene.cpp:207-212 (float accumulation)
-        center += p
-    center = center / np.float32(len(uniq))
-    radius = np.float32(np.sqrt(((uniq - center) ** 2).sum(axis=1, dtype=np.float32)).max())
+    center, radius = host.mesh_bounds(uniq)                      # src/scene.cpp:207-220 through the C ABI (nv_mesh_bounds)
     return dict(vertices=int(len(pos)), triangles=int(len(corners) // 3), unique_vertices=int(len(uniq)),
                 center=[float(x) for x in center], radius=float(radius))
 
@@ -57,6 +53,28 @@ def kitten_bounds():
         assert b["vertices"] == ref["vertices"] == 14472 and b["triangles"] == ref["triangles"] == 28944
         assert np.allclose(b["center"], ref["center"], atol=1e-6) and abs(b["radius"] - ref["radius"]) < 1e-6
     return json.load(open(JSON))
+
+
+def test_mesh_bounds_equal_the_reference_statements():
+    """nv_mesh_bounds == src/scene.cpp:207-220 compiled verbatim (oracle/_ref), bit for bit: random clouds of every size
+    class (the fp32 sum is order- and size-sensitive), values that cancel, and the kitten where the reference tree is mounted"""
+    import oracle.ref as R
+    if not R.available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(12)
+    clouds = [rng.normal(0, s, (n, 3)).astype(np.float32) + np.float32(o) for n, s, o in
+              [(1, 1, 0), (2, 1, 5), (3, 1e-3, 0), (17, 10, -3), (1000, 1, 100), (14856, 0.3, 0), (200000, 50, 1e4), (65536, 1e-6, 1)]]
+    clouds.append(np.array([[1e8, -1e8, 1], [-1e8, 1e8, 1], [1, 1, 1]], np.float32))
+    clouds.append(rng.normal(0, 1, (5000, 3)).astype(np.float16).astype(np.float32))  # de-quantised halves, like the real input
+    if os.path.exists(OBJ):
+        pos = np.array([[float(x) for x in l.split()[1:4]] for l in open(OBJ) if l.startswith("v ")], np.float32)
+        clouds.append(pos.astype(np.float16).astype(np.float32))
+    for pos in clouds:
+        c, r = host.mesh_bounds(pos)
+        cr, rr = R.mesh_bounds(pos)
+        assert c.tobytes() == cr.tobytes() and np.float32(r).tobytes() == np.float32(rr).tobytes(), len(pos)
+    with pytest.raises(RuntimeError, match="NV_EINVAL"):
+        host.mesh_bounds(np.zeros((0, 3), np.float32))
 
 
 def kitten_scene(n_draws=1024):
