@@ -7,7 +7,8 @@ clusterBackfaceEnabled = 1) with ordered compaction of the visible IDs.  One "st
 one batch: reset of the count word (the caller's vkCmdFillBuffer, src/niagara.cpp:1586; fused into the pass through
 NV_OPT_FUSED_COUNT_RESET unless --explicit-reset) + nv_clustercull, with inputs resident in HBM.  Steps rotate over `--copies` distinct input sets so that every pass streams from HBM rather
 than from the 256 MiB Infinity Cache.  N > 1: the pool shards by contiguous command ranges, every rank culls its own
-10 M meshlets (weak scaling) and the only collective is one all-reduce of the visible counts per step (RCCL).
+10 M meshlets (weak scaling) and the only collective is the all-reduce of the passes' visible counts (RCCL; the rows of
+`--counts-batch` passes, written by the scatter launches, share one asynchronous all-reduce; 1 = one collective per pass).
 
 Prints ONE JSON line (rank 0):  metric/value/unit as in BASELINE.json + "roofline" (dominant kernel, HIP events on
 the launch stream) + "cpu_baseline" (the CPU oracle timed on this host's cores; a reported baseline, not a target).
