@@ -1,14 +1,53 @@
-// args.cuh — kernel argument blocks shared by the launchers (context.hip) and the kernels.
+// args.h — kernel argument blocks shared by the launchers (context.hip) and the kernels, and the ordered-append scheme
+// both cull passes use.
+//
+// Ordered append — deterministic (invocation-ordered) append for gfx950: the scheme shared by clustercull.hip and drawcull.hip.
+//
+// niagara appends survivors with one global atomicAdd per invocation (drawcull.comp.glsl:123,143;
+// clustercull.comp.glsl:135 — "TODO: potentially slow global atomic"), so its output order is whatever the hardware
+// serialises.  Here the append index of an item is the exclusive prefix sum of the emit counts of all items before it
+// in invocation order: one valid serialisation of the reference's atomics, and bit-reproducible.
+//
+// Both passes compute it with TWO launches on the stream and no inter-workgroup wait at all:
+//   1. the cull / decide kernel is a pure map.  It writes a compact per-item result (a 64-bit ballot per task command,
+//      a byte per draw) and adds each wave's emit count to the count of the scatter tile the wave's items fall in
+//      (one fire-and-forget atomicAdd per wave that emits anything; tiles = contiguous item ranges, one per CU);
+//   2. the scatter kernel runs one workgroup per tile.  Its append base = count word + counts of the tiles before it
+//      (<= 512 values, one load per lane), then one scan over the tile's results and the ordered stores.
+// Measured on MI355X this beat both alternatives that keep a single launch: ticket-ordered tiles (one hot atomic word
+// serialises at ~10 ns per returning atomic) and a chained decoupled look-back over co-resident tiles (needs a grid
+// that is co-resident by construction, 2-4 dependent look-back rounds of ~1.5 us each, and bounded spins).  The launch
+// boundary costs ~2 us and buys: no co-residency requirement, no spinning, nothing to re-arm after a fault.
+//
+// The per-tile counts live in two banks (ClusterCounts below): a pass adds into counts[parity] and the scatter
+// kernel clears counts[parity ^ 1] and flips the parity, so nothing is memset between passes and a captured hipGraph
+// replays correctly.
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/niagara_vis.h"
-#include "ordered.cuh"
+
+// Tuning experiments (wave stamps, partial passes, alternative dealing ...) exist only in a separate build
+// (-DNV_EXPERIMENTS -> libniagara_vis_exp.so, tools/): the product library carries no switch that could change a result
+// or cost an instruction in a hot loop.
+#ifdef NV_EXPERIMENTS
+#define NV_DBG(args, bits) (((args).debugMode & (bits)) != 0)
+#else
+#define NV_DBG(args, bits) false
+#endif
 
 namespace nv
 {
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1)
+		v += __shfl_xor(v, o, 64);
+	return v;
+}
 
 // Per-tile survivor counts handed from the cull kernel to the scatter kernel (clustercull.hip).  Two banks: a pass adds
 // into counts[parity] and clears counts[parity ^ 1] for the next one, so nothing is memset between passes and a
@@ -56,10 +95,13 @@ struct ClusterArgs
 	uint32_t scatterTiles; // grid of the scatter kernel (<= CC_MAX_SCATTER_TILES)
 	uint32_t generations;  // workgroups of the cull kernel per CU (its grid = generations x CUs)
 	uint32_t dealScale;    // percent of the nominal start-delay compensation of the dealing (tuning; 100)
+	float filterK;         // 4 K u S of the conservative filter / certified test (clustercull.hip make_filter); 0 = both off
 	uint32_t* hostHint;    // mapped host word: the cull kernel leaves its command count here for the next launch's tuning
 	uint32_t commandCountOverride; // probe/taskcull: explicit command count (0 = use count4[1]*64)
 	float* __restrict__ probeOut;
-	uint32_t debugMode; // tuning experiments only (NV_DEBUG_MODE); 0 in production
+#ifdef NV_EXPERIMENTS
+	uint32_t debugMode; // NV_DEBUG_MODE of the experiments build
+#endif
 	uint32_t fusedReset; // NV_OPT_FUSED_COUNT_RESET
 	uint32_t fusedSubmit; // NV_OPT_FUSED_SUBMIT
 	unsigned long long* countsSink; // nv_set_counts_sink (nullptr: off)
@@ -80,7 +122,9 @@ struct DrawArgs
 	uint32_t fusedReset; // NV_OPT_FUSED_COUNT_RESET
 	uint32_t fusedSubmit; // NV_OPT_FUSED_SUBMIT
 	uint32_t meshCount;  // > 0 when nv_upload_meshes registered `meshes`: the table may be staged in LDS
-	uint32_t debugMode;  // tuning experiments only (NV_DEBUG_MODE); 0 in production
+#ifdef NV_EXPERIMENTS
+	uint32_t debugMode; // NV_DEBUG_MODE of the experiments build
+#endif
 };
 
 // trianglecull.hip

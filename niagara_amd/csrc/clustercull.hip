@@ -3,22 +3,25 @@
 // Replaces src/shaders/clustercull.comp.glsl:56-149 (and the cull half of src/shaders/meshlet.task.glsl:53-149).
 //
 // Mapping to CDNA4 (not a translation of the one-workgroup-per-command Vulkan grid):
-//   * TASK_WGSIZE = 64 = one wavefront: a MeshTaskCommand and its MeshDraw are wave-uniform, so they are fetched
-//     with scalar loads into SGPRs together with CullData (kernarg); only the 12 cull bytes of each meshlet travel
-//     through the vector memory path: bounds (4 x fp16, 8 B/lane = 512 B/wave) and cone (4 x s8, 4 B/lane), both
-//     perfectly coalesced from the SoA mirror built by nv_upload_meshlets (the 24-B AoS records are read in place
-//     when no mirror exists);
-//   * a wave walks its commands with a ring of CC_D commands' meshlet loads in flight (counted vmcnt waits); a
-//     command's result is one 64-bit ballot — no per-survivor atomics, no LDS staging of survivors;
-//   * survivors are appended in command-major, lane-minor order by a second small kernel (scheme: ordered.cuh)
-//     (chained scan across <= 256 workgroups), instead of 1 global atomic per survivor;
-//   * visibility bits (late pass) are updated with <= 3 word-level atomics per wave built from the ballots
-//     instead of one atomicOr/atomicAnd per lane (clustercull.comp.glsl:125-131);
-//   * tests are pure predicates ANDed together, so the cheap frustum test runs first and the cone / HiZ tests are
-//     skipped wave-wide when no lane survives — identical result, fewer VALU cycles.
-#include "cullmath.cuh"
-#include "ordered.cuh"
-#include "args.cuh"
+//   * TASK_WGSIZE = 64 = one wavefront, so a MeshTaskCommand and its MeshDraw are wave-uniform.  A wave fetches 64 of
+//     its commands with one coalesced vector load (lane = command), gathers their MeshDraws the same way and derives
+//     the per-draw quantities lane-parallel; fields are broadcast with v_readlane where a command is visited.  Only the
+//     12 cull bytes of a meshlet travel per lane: bounds (4 x fp16, 512 B per wave) and cone (4 x s8), both perfectly
+//     coalesced from the SoA mirror built by nv_upload_meshlets (the 24-B AoS records are read in place otherwise);
+//   * two launches, no workgroup ever waits on another (scheme: args.h).  K1 cluster_mask_kernel is a pure map dealt for
+//     balance: every command becomes one 64-bit ballot, and the survivors per scatter tile are counted on the way;
+//     K2 cluster_scatter_kernel owns contiguous command ranges and stores the IDs in command-major, lane-minor order;
+//   * K1 works in two passes per 64-command segment.  Pass A streams the 8 bounds bytes through a conservative frustum
+//     filter (23 VALU per command) with CC_DA commands' loads in flight (counted vmcnt waits); pass B visits only the
+//     commands that may have survivors: a certified two-sided test (frustum + cone evaluated through one affine map
+//     per draw with proven error margins: ~60 VALU) decides almost all of them, and the reference's own un-fused
+//     arithmetic (~190 VALU) runs for a command only when some lane falls inside a margin — the result is the
+//     reference's for every lane either way;
+//   * visibility bits (late pass) are updated lane-parallel per segment from the ballots — <= 3 words per command, a
+//     plain store for a word the command owns, an atomic only for a shared edge word — instead of one atomicOr/And per
+//     lane (clustercull.comp.glsl:125-131).
+#include "cullmath.h"
+#include "args.h"
 
 namespace nv
 {
@@ -222,7 +225,7 @@ NV_DEV uint64_t cull_command(const ClusterArgs& a, const NvMeshTaskCommand& cmd,
 			visible = visible && !cone_cull(c, r, axis, cutoff);
 		}
 
-		if (LATE && cd.clusterOcclusionEnabled == 1 && visible && !(a.debugMode & 512u)) // bit 9 (experiments): no HiZ
+		if (LATE && cd.clusterOcclusionEnabled == 1 && visible && !NV_DBG(a, 512u)) // bit 9 (experiments): no HiZ
 			visible = hiz_test<TABLE>(cd, a.pyr, c, r, mipOffsets); // TABLE: the pyramid's level offsets from LDS
 	}
 
@@ -245,7 +248,7 @@ NV_DEV uint64_t cull_command(const ClusterArgs& a, const NvMeshTaskCommand& cmd,
 // late_prepare = cull_command up to hiz_prepare; flags: bits 0..4 HizProbe::use, bit 5 visible so far, bit 6 skip.
 template <bool BITS>
 NV_DEV HizProbe late_prepare(const ClusterArgs& a, const NvMeshTaskCommand& cmd, const DrawUniform& u, const LaneData& l, uint32_t lane, uint32_t& flags,
-                             const uint32_t* mipOffsets)
+                             const uint32_t* mipOffsets, const uint64_t* decided = nullptr)
 {
 	const NvCullData& cd = a.cd;
 	bool visible = lane < cmd.taskCount;
@@ -258,20 +261,25 @@ NV_DEV HizProbe late_prepare(const ClusterArgs& a, const NvMeshTaskCommand& cmd,
 			skip = true;
 	}
 	HizProbe p = { 0, 0, 0, 0, 0, 0.0f };
+	if (decided) // frustum and cone already decided by the certified test: only the HiZ probe needs the reference's sphere
+		visible = (*decided >> lane & 1ull) != 0;
 	if (__ballot(visible) != 0)
 	{
 		f3 c;
 		float r;
 		lane_sphere(cd, u, l, c, r);
-		visible = visible && frustum_test(cd, c, r);
-		if (cd.clusterBackfaceEnabled != 0 && __ballot(visible) != 0)
+		if (!decided)
 		{
-			f3 axis;
-			float cutoff;
-			lane_cone(cd, u, l, axis, cutoff);
-			visible = visible && !cone_cull(c, r, axis, cutoff);
+			visible = visible && frustum_test(cd, c, r);
+			if (cd.clusterBackfaceEnabled != 0 && __ballot(visible) != 0)
+			{
+				f3 axis;
+				float cutoff;
+				lane_cone(cd, u, l, axis, cutoff);
+				visible = visible && !cone_cull(c, r, axis, cutoff);
+			}
 		}
-		if (visible && !(a.debugMode & 512u)) // bit 9 (experiments): no HiZ
+		if (visible && !NV_DBG(a, 512u)) // bit 9 (experiments): no HiZ
 			p = hiz_prepare(cd, a.pyr, c, r, mipOffsets);
 	}
 	flags = p.use | (visible ? 32u : 0u) | (skip ? 64u : 0u);
@@ -399,9 +407,14 @@ struct FilterDraw
 	float aK, bK; // 4 K u alpha, 4 K u beta (+ an absolute floor)
 	float aR;     // 2^-20 |scale|: covers the roundings of radius * scale, which the filter folds into its threshold
 	float scale;
+	float coneK;  // certified cone test: its margin is T * coneK (see certified_visible)
+	float is127;  // 1 / (127 scale): takes M = scale V R back to V R and the int8 axis to [-1, 1] in one factor
 };
 
-NV_DEV FilterDraw make_filter(const NvCullData& cd, const DrawUniform& u)
+// filterK = 4 K u S (rounded up), S = max(1, |f0| + |f1|, |f2| + |f3|) of the frustum coefficients: the margins above
+// assume |f| <= 1; the host scales them for other coefficients and passes 0 (no filter, no certified test) for
+// non-finite or absurd ones (fill_cluster_args).
+NV_DEV FilterDraw make_filter(const NvCullData& cd, const DrawUniform& u, float filterK)
 {
 	const float x = u.q.x, y = u.q.y, z = u.q.z, w = u.qw, s = u.scale;
 	// R = (1 - 2|q_xyz|^2) I + 2 q q^T + 2 w [q]x  (valid for any q, unit or not) — same map as rotateQuat
@@ -437,11 +450,22 @@ NV_DEV FilterDraw make_filter(const NvCullData& cd, const DrawUniform& u)
 	const float pn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(u.pos.x), __builtin_fabsf(u.pos.y)), __builtin_fabsf(u.pos.z));
 	const float alpha = Vn * __builtin_fabsf(s) * rotAbs;
 	const float beta = Vn * pn + V3n;
-	const float k4u = 4.0f * 48.0f * 5.9604644775390625e-8f * 1.001f; // 4 K u, rounded up
-	f.aK = k4u * alpha;
-	f.bK = k4u * beta + 1e-30f;
+	// The analysis assumes finite inputs and no overflow / harmful underflow in either evaluation.  fmaxf drops NaNs, so
+	// non-finite draw or view fields are caught by a sum that is 0 or NaN, and magnitudes outside a generous range
+	// (every intermediate of both chains, including the certified cone test's products, then stays far from the fp32
+	// limits) make the margin infinite: nothing is certain for such a draw and the reference arithmetic decides.
+	float sumV = 0.0f;
+#pragma unroll
+	for (int i = 0; i < 15; ++i)
+		sumV += (i & 3) == 3 ? 0.0f : V[i];
+	const float poison = 0.0f * ((((x + y) + (z + w)) + (s + ((u.pos.x + u.pos.y) + u.pos.z))) + sumV); // 0, or NaN
+	const bool sane = alpha <= 1e12f && beta <= 1e12f && __builtin_fabsf(s) >= 1e-15f;
+	f.aK = filterK * alpha;
+	f.bK = sane ? (filterK * beta + 1e-30f) + poison : __builtin_inff();
 	f.aR = 9.5367431640625e-7f * __builtin_fabsf(s);
 	f.scale = s;
+	f.coneK = 2.02f * (Vn * rotAbs) + 1.0f;
+	f.is127 = (1.0f / s) * 0.00787401574803149606f;
 	return f;
 }
 
@@ -554,6 +578,98 @@ NV_DEV DrawUniform segment_draw(const SegmentRegs& r, uint32_t c)
 	return u;
 }
 
+// ---- certified two-sided test (pass B)
+// The filter's approximation  c~ = M v + b  decides a predicate of the reference in BOTH directions once its distance to
+// the threshold exceeds the margin:  |c~ - c_ref| <= E,  every frustum predicate moves by at most 4E (above), so
+//     min_i g_i(c~) + r  < -T   =>  some predicate of the reference is false   (the filter),
+//     min_i g_i(c~) + r  >  T   =>  all four are true,
+// with T >= 4E + the roundings of radius * scale.  The cone test (math.h:41-44)  dot(c, axis) >= cutoff |c| + r  gets
+// the same treatment: axis~ = (M k) / (127 scale)  for the int8 axis k  (M / scale = V R, the linear part of the
+// reference's mat3(view) * rotateQuat(k / 127, q)), |c~| through v_sqrt_f32 (1 ulp), and
+//     D = dot(c~, axis~) - (cutoff~ |c~| + r~),    |D - (lhs_ref - rhs_ref)| <= E_cone,
+//     E_cone <= u (163 A Aax + 63 A) + 4.1 u |r|,   A = alpha max|v_i| + beta (the magnitude bound behind E = 48 u A),
+//     Aax = 1.01 ||V||_inf,row (1 + 2 Qa (Qa + |qw|))  (the same bound for the axis chain),
+// from the same forward analysis: the reference's axis chain is <= 9 roundings deep, its dot 3, its length 2.6 u relative
+// plus |c_ref - c*|_2, the approximation's M 7, its FMA chains 3 each, the factor 1 / (127 scale) 3.  With T = 192 u A + ...
+// the margin  T coneK,  coneK = 2.02 ||V|| (1 + 2 Qa (Qa + |qw|)) + 1,  is >= 2 E_cone.  D > T coneK: certainly culled;
+// D < -T coneK: certainly kept.  NaN / inf anywhere makes T NaN / inf (make_filter), every comparison false, the lane
+// undecided.  A command with an undecided lane that matters runs the reference arithmetic for the whole wave, so the
+// result is the reference's in every case; tests/test_gpu_parity.py places meshlets within ulps of the cone threshold
+// and of the planes, tools/experiments/cert_margin.py measures the bound's slack against exact rational arithmetic.
+struct CertUniform
+{
+	float m[9];
+	float aK, aR, scale, coneK, is127;
+	float b0, b1, b2, bK; // VGPR-resident (addends of the FMA chains)
+};
+
+NV_DEV CertUniform segment_cert(const SegmentRegs& r, uint32_t c)
+{
+	CertUniform f;
+#pragma unroll
+	for (int i = 0; i < 9; ++i)
+		f.m[i] = readlane_f(r.f.m[i], c);
+	f.aK = readlane_f(r.f.aK, c);
+	f.aR = readlane_f(r.f.aR, c);
+	f.scale = readlane_f(r.f.scale, c);
+	f.coneK = readlane_f(r.f.coneK, c);
+	f.is127 = readlane_f(r.f.is127, c);
+	f.b0 = pin_vgpr(readlane_f(r.f.b[0], c));
+	f.b1 = pin_vgpr(readlane_f(r.f.b[1], c));
+	f.b2 = pin_vgpr(readlane_f(r.f.b[2], c));
+	f.bK = pin_vgpr(readlane_f(r.f.bK, c));
+	return f;
+}
+
+NV_DEV float s8_to_float(uint32_t word, int byte)
+{
+	return (float)(int)(int8_t)(word >> (8 * byte));
+}
+
+// need = the lanes whose decision matters (valid, and for the early pass with visibility bits: bit set).  Returns true
+// when every such lane is decided; *vis = ballot of the lanes that pass frustum and cone (clustercull.comp.glsl:102-108).
+NV_DEV bool certified_visible(const NvCullData& cd, const CertUniform& f, uint32_t b0, uint32_t b1, uint32_t cone, uint64_t need, uint64_t* vis)
+{
+	const float vx = half_bits_to_float(b0 & 0xffffu), vy = half_bits_to_float(b0 >> 16), vz = half_bits_to_float(b1 & 0xffffu);
+	const float rad = half_bits_to_float(b1 >> 16);
+	const float cx = __builtin_fmaf(f.m[0], vx, __builtin_fmaf(f.m[1], vy, __builtin_fmaf(f.m[2], vz, f.b0)));
+	const float cy = __builtin_fmaf(f.m[3], vx, __builtin_fmaf(f.m[4], vy, __builtin_fmaf(f.m[5], vz, f.b1)));
+	const float cz = __builtin_fmaf(f.m[6], vx, __builtin_fmaf(f.m[7], vy, __builtin_fmaf(f.m[8], vz, f.b2)));
+	float T = __builtin_fmaf(f.aK, __builtin_fabsf(vx), f.bK);
+	T = __builtin_fmaf(f.aK, __builtin_fabsf(vy), T);
+	T = __builtin_fmaf(f.aK, __builtin_fabsf(vz), T);
+	T = __builtin_fmaf(f.aR, __builtin_fabsf(rad), T);
+	const float thrHi = __builtin_fmaf(f.scale, rad, T), thrLo = __builtin_fmaf(f.scale, rad, -T);
+	const float g1 = __builtin_fmaf(cz, cd.frustum[1], -(__builtin_fabsf(cx) * cd.frustum[0]));
+	const float g2 = __builtin_fmaf(cz, cd.frustum[3], -(__builtin_fabsf(cy) * cd.frustum[2]));
+	const float gn = cz - cd.znear;
+	const float gf = cd.zfar - cz;
+	// a finite T implies finite, bounded c~ and (host-checked) finite coefficients: no NaN is dropped by these minima
+	const float g = __builtin_fminf(__builtin_fminf(g1, g2), __builtin_fminf(gn, gf));
+	const uint64_t outM = __ballot(g < -thrHi), inM = __ballot(g > -thrLo);
+	if (need & ~(outM | inM))
+		return false;
+	uint64_t alive = need & inM;
+	if (cd.clusterBackfaceEnabled != 0 && alive)
+	{
+		const float kx = s8_to_float(cone, 0), ky = s8_to_float(cone, 1), kz = s8_to_float(cone, 2), kc = s8_to_float(cone, 3);
+		const float wx = __builtin_fmaf(f.m[0], kx, __builtin_fmaf(f.m[1], ky, f.m[2] * kz));
+		const float wy = __builtin_fmaf(f.m[3], kx, __builtin_fmaf(f.m[4], ky, f.m[5] * kz));
+		const float wz = __builtin_fmaf(f.m[6], kx, __builtin_fmaf(f.m[7], ky, f.m[8] * kz));
+		const float lhs = __builtin_fmaf(cx, wx, __builtin_fmaf(cy, wy, cz * wz)) * f.is127;
+		const float len = __builtin_amdgcn_sqrtf(__builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, cz * cz)));
+		const float rhs = __builtin_fmaf(kc * 0.00787401574803149606f, len, f.scale * rad);
+		const float D = lhs - rhs;
+		const float Tc = T * f.coneK;
+		const uint64_t cullM = __ballot(D > Tc), keepM = __ballot(D < -Tc);
+		if (alive & ~(cullM | keepM))
+			return false;
+		alive &= keepM;
+	}
+	*vis = alive;
+	return true;
+}
+
 // ---- software-pipelined meshlet stream (SoA mirror only)
 // hipcc's s_waitcnt insertion collapses a loop-carried prefetch ring to (almost) vmcnt(0): measured, every command then
 // costs one full memory latency.  The ring's loads are therefore issued from inline asm, which hipcc does not count,
@@ -596,9 +712,17 @@ NV_DEV uint32_t lane_meshlet(uint32_t taskOffset, uint32_t taskCount, uint32_t l
 }
 
 // off8 = byte offset of this lane's bounds record; offw = byte offset of its visibility word (BITS)
+// NV_PLAIN_LOADS (libniagara_vis_plain.so): the same kernels with ordinary loads and the compiler's own waits —
+// slower (hipcc waits for a loop-carried ring with ~vmcnt(0)), but free of every assumption the counted waits make about
+// register allocation and instruction order.  tests/test_plain_loads.py holds the asm build to its results.
 template <bool BITS>
 NV_DEV void ringA_issue(SlotA& s, const ClusterArgs& a, uint32_t off8, uint32_t offw, uint64_t order)
 {
+#ifdef NV_PLAIN_LOADS
+	(void)order;
+	s.bounds = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(a.soaBounds) + off8);
+	s.mvbWord = BITS ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.mvb) + offw) : 0u;
+#else
 	if (BITS)
 	{
 		asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %2, %3\n\tglobal_load_dword %1, %4, %5"
@@ -611,15 +735,23 @@ NV_DEV void ringA_issue(SlotA& s, const ClusterArgs& a, uint32_t off8, uint32_t 
 		asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(s.bounds) : "v"(off8), "s"(a.soaBounds), "s"(order) : "memory");
 		s.mvbWord = 0;
 	}
+#endif
 }
+
+// every counted wait of the file goes through here: a no-op in the plain build (the compiler waits where it must)
+#ifdef NV_PLAIN_LOADS
+#define NV_COUNTED_WAIT(...) do { } while (0)
+#else
+#define NV_COUNTED_WAIT(...) asm volatile(__VA_ARGS__)
+#endif
 
 template <bool BITS, int YOUNGER>
 NV_DEV void ringA_wait(SlotA& s)
 {
 	if (BITS)
-		asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.bounds), "+v"(s.mvbWord) : "i"(YOUNGER * 2) : "memory");
+		NV_COUNTED_WAIT("s_waitcnt vmcnt(%2) ; nv_ready %0 %1" : "+v"(s.bounds), "+v"(s.mvbWord) : "i"(YOUNGER * 2) : "memory");
 	else
-		asm volatile("s_waitcnt vmcnt(%1)" : "+v"(s.bounds) : "i"(YOUNGER) : "memory");
+		NV_COUNTED_WAIT("s_waitcnt vmcnt(%1) ; nv_ready %0" : "+v"(s.bounds) : "i"(YOUNGER) : "memory");
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -630,9 +762,15 @@ NV_DEV void ringB_issue(SlotB& s, const ClusterArgs& a, uint32_t taskOffset, uin
 	const uint32_t li = lane < taskCount ? lane : 0u;
 	const uint32_t mi = lane_meshlet(taskOffset, taskCount, lane);
 	const uint32_t off8 = mi * 8u, off4 = mi * 4u;
+	const uint32_t offw = BITS && taskCount ? ((mvo + li) >> 5) * 4u : 0u;
+#ifdef NV_PLAIN_LOADS
+	(void)order;
+	s.bounds = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(a.soaBounds) + off8);
+	s.cone = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.soaCones) + off4);
+	s.mvbWord = BITS ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.mvb) + offw) : 0u;
+#else
 	if (BITS)
 	{
-		const uint32_t offw = taskCount ? ((mvo + li) >> 5) * 4u : 0u;
 		asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %3, %4\n\tglobal_load_dword %1, %5, %6\n\tglobal_load_dword %2, %7, %8"
 		             : "=&v"(s.bounds), "=&v"(s.cone), "=&v"(s.mvbWord)
 		             : "v"(off8), "s"(a.soaBounds), "v"(off4), "s"(a.soaCones), "v"(offw), "s"(a.mvb), "s"(order)
@@ -646,15 +784,16 @@ NV_DEV void ringB_issue(SlotB& s, const ClusterArgs& a, uint32_t taskOffset, uin
 		             : "memory");
 		s.mvbWord = 0;
 	}
+#endif
 }
 
 template <bool BITS, int YOUNGER>
 NV_DEV void ringB_wait(SlotB& s)
 {
 	if (BITS)
-		asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s.bounds), "+v"(s.cone), "+v"(s.mvbWord) : "i"(YOUNGER * 3) : "memory");
+		NV_COUNTED_WAIT("s_waitcnt vmcnt(%3) ; nv_ready %0 %1 %2" : "+v"(s.bounds), "+v"(s.cone), "+v"(s.mvbWord) : "i"(YOUNGER * 3) : "memory");
 	else
-		asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.bounds), "+v"(s.cone) : "i"(YOUNGER * 2) : "memory");
+		NV_COUNTED_WAIT("s_waitcnt vmcnt(%2) ; nv_ready %0 %1" : "+v"(s.bounds), "+v"(s.cone) : "i"(YOUNGER * 2) : "memory");
 }
 
 // the same wait with the number of younger LOADS given directly (exact pass with texel fetches between the ring issues)
@@ -663,9 +802,9 @@ NV_DEV void ringB_wait_loads(SlotB& s)
 {
 	static_assert(LOADS < 64, "vmcnt is a 6-bit counter");
 	if (BITS)
-		asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s.bounds), "+v"(s.cone), "+v"(s.mvbWord) : "i"(LOADS) : "memory");
+		NV_COUNTED_WAIT("s_waitcnt vmcnt(%3) ; nv_ready %0 %1 %2" : "+v"(s.bounds), "+v"(s.cone), "+v"(s.mvbWord) : "i"(LOADS) : "memory");
 	else
-		asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.bounds), "+v"(s.cone) : "i"(LOADS) : "memory");
+		NV_COUNTED_WAIT("s_waitcnt vmcnt(%2) ; nv_ready %0 %1" : "+v"(s.bounds), "+v"(s.cone) : "i"(LOADS) : "memory");
 }
 
 // the four HiZ texels of one command in flight (late pass): offsets in floats from the pyramid base, always in range
@@ -677,18 +816,37 @@ struct SlotT
 NV_DEV void ringT_issue(SlotT& s, const float* base, uint32_t o00, uint32_t o10, uint32_t o01, uint32_t o11, uint64_t order)
 {
 	const uint32_t b00 = o00 * 4u, b10 = o10 * 4u, b01 = o01 * 4u, b11 = o11 * 4u;
+#ifdef NV_PLAIN_LOADS
+	(void)order;
+	const char* bp = reinterpret_cast<const char*>(base);
+	s.t00 = *reinterpret_cast<const float*>(bp + b00);
+	s.t10 = *reinterpret_cast<const float*>(bp + b10);
+	s.t01 = *reinterpret_cast<const float*>(bp + b01);
+	s.t11 = *reinterpret_cast<const float*>(bp + b11);
+#else
 	asm volatile("s_nop 4\n\tglobal_load_dword %0, %4, %8\n\tglobal_load_dword %1, %5, %8\n\tglobal_load_dword %2, %6, %8\n\tglobal_load_dword %3, %7, %8"
 	             : "=&v"(s.t00), "=&v"(s.t10), "=&v"(s.t01), "=&v"(s.t11)
 	             : "v"(b00), "v"(b10), "v"(b01), "v"(b11), "s"(base), "s"(order)
 	             : "memory");
+#endif
 }
 
 template <int LOADS>
 NV_DEV void ringT_wait(SlotT& s)
 {
 	static_assert(LOADS < 64, "vmcnt is a 6-bit counter");
-	asm volatile("s_waitcnt vmcnt(%4)" : "+v"(s.t00), "+v"(s.t10), "+v"(s.t01), "+v"(s.t11) : "i"(LOADS) : "memory");
+	NV_COUNTED_WAIT("s_waitcnt vmcnt(%4) ; nv_ready %0 %1 %2 %3" : "+v"(s.t00), "+v"(s.t10), "+v"(s.t01), "+v"(s.t11) : "i"(LOADS) : "memory");
 }
+
+// End of a ring: wait for everything, THEN release the slots.  The last loads of a ring are redundant (clamped re-reads
+// whose values nobody uses), so for the compiler the slots are dead as soon as their last consumer has run — and it
+// reuses their registers for whatever comes next (observed: a division sunk below the filter loop computed in two slot
+// registers while their loads were still in flight, and was overwritten when they landed).  Naming every slot in a
+// statement BEHIND the drain keeps the registers reserved until the loads have landed (tools/check_asm_hazards.py, check 2).
+NV_DEV void ring_drain() { asm volatile("s_waitcnt vmcnt(0) ; nv_ready all" ::: "memory"); }
+NV_DEV void ring_release(SlotA& s) { asm volatile("; released %0 %1" : "+v"(s.bounds), "+v"(s.mvbWord)); }
+NV_DEV void ring_release(SlotB& s) { asm volatile("; released %0 %1 %2" : "+v"(s.bounds), "+v"(s.cone), "+v"(s.mvbWord)); }
+NV_DEV void ring_release(SlotT& s) { asm volatile("; released %0 %1 %2 %3" : "+v"(s.t00), "+v"(s.t10), "+v"(s.t01), "+v"(s.t11)); }
 
 // commands per scatter tile: the same function of the indirect words in both kernels
 NV_DEV uint32_t scatter_tile_commands(uint32_t numCmds, uint32_t tiles)
@@ -765,7 +923,7 @@ NV_DEV uint32_t make_dealing(uint32_t numChunks, uint32_t wave, uint32_t lane, u
 }
 
 template <bool LATE, bool SOA, bool BITS, int CC_DA>
-__global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
+__global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs a)
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -789,7 +947,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 	// the start-up chain (count -> commands -> draws / first bounds) is latency-critical and a few dozen instructions
 	// long: it must not queue behind the older waves' filter arithmetic (measured: without this the sixth workgroup of
 	// a CU got its first data 11 k cycles after the first one)
-	if (!(a.debugMode & 262144u)) // bit 18 (experiments)
+	if (!NV_DBG(a, 262144u)) // bit 18 (experiments)
 		__builtin_amdgcn_s_setprio(3);
 	const uint32_t gen = blockIdx.x / (gridDim.x / 6u ? gridDim.x / 6u : 1u);
 	const uint32_t numCmds = indirect_command_count(a);
@@ -798,7 +956,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 	const uint32_t numChunks = (numCmds + CC_CHUNK - 1) / CC_CHUNK;
 	uint32_t chunkOf;
 	bool dealtWeighted;
-	const uint32_t myChunks = make_dealing(numChunks, wave, lane, a.generations, gen, !LATE && !(a.debugMode & 32768u), a.dealScale, &chunkOf, &dealtWeighted); // (late pass: even — the weights are calibrated on the early pass, and the extra state costs the late variants two resident workgroups per CU) // bit 15 (experiments): even dealing
+	const uint32_t myChunks = make_dealing(numChunks, wave, lane, a.generations, gen, !LATE && !NV_DBG(a, 32768u), a.dealScale, &chunkOf, &dealtWeighted); // (late pass: even — the weights are calibrated on the early pass, and the extra state costs the late variants two resident workgroups per CU) // bit 15 (experiments): even dealing
 	const uint32_t myCmds = myChunks * CC_CHUNK; // the last chunk of the pass may run past numCmds: guarded below
 	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles);
 	const uint32_t bank = load_uniform_u32(&a.tileCounts->parity) & 1u;
@@ -809,7 +967,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 	}
 
 	// debugMode bit 3: per-wave s_memtime stamps into probeOut (tools/wave_timeline.py); never set in production
-	const bool dbgTime = (a.debugMode & 8u) && a.probeOut;
+	const bool dbgTime = NV_DBG(a, 8u) && a.probeOut;
 	unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.probeOut) + (size_t)w * 8;
 #define NV_STAMP(i) do { if (dbgTime && lane == 0) stamps[i] = __builtin_readcyclecounter(); } while (0)
 	NV_STAMP(0);
@@ -842,7 +1000,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 				r.d0 = d[0];
 				r.d1 = d[1];
 			}
-			r.f = make_filter(a.cd, lane_draw(r)); // lane-parallel: one filter per command of the segment
+			r.f = make_filter(a.cd, lane_draw(r), a.filterK); // lane-parallel: one filter per command of the segment
 		}
 		NV_STAMP(1);
 
@@ -853,17 +1011,23 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 		auto gather_issue = [&]()
 		{
 			const char* dp = reinterpret_cast<const char*>(a.draws + (r.taskCount ? r.drawId : 0u));
+#ifdef NV_PLAIN_LOADS
+			g0 = reinterpret_cast<const u32x4*>(dp)[0];
+			g1 = reinterpret_cast<const u32x4*>(dp)[1];
+#else
 			asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(g0), "=&v"(g1) : "v"(dp) : "memory");
+#endif
 		};
 		auto gather_finish = [&]()
 		{
 			r.d0 = make_float4(__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w));
 			r.d1 = make_float4(__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z), __uint_as_float(g1.w));
-			r.f = make_filter(a.cd, lane_draw(r));
+			r.f = make_filter(a.cd, lane_draw(r), a.filterK);
 		};
 
-		const bool useFilter = !(a.debugMode & 32u);   // bit 5 (experiments): every valid command goes to the exact pass
-		const bool streamOnly = (a.debugMode & 64u) != 0; // bit 6 (experiments): no arithmetic at all
+		const bool useFilter = a.filterK > 0.0f && !NV_DBG(a, 32u);   // filterK 0: coefficients outside the proven range (host); bit 5 (experiments): every valid command goes to the exact pass
+		const bool useCert = a.filterK > 0.0f && !NV_DBG(a, 1048576u); // bit 20 (experiments): pass B with the reference arithmetic only
+		const bool streamOnly = NV_DBG(a, 64u); // bit 6 (experiments): no arithmetic at all
 		const bool updateBits = LATE && a.cd.clusterOcclusionEnabled == 1;
 		constexpr bool BITS_A = BITS && !LATE; // the filter pass needs the visibility words only for the early pass's bit test
 		uint32_t maskLo = 0, maskHi = 0; // lane c ends up holding the ballot of the segment's c-th command (v_writelane)
@@ -915,7 +1079,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 #pragma unroll
 				for (int k = 0; k < CC_DA; ++k)
 					issueA(ring[k], (uint32_t)k < cnt ? k : cnt - 1, 0); // clamped: redundant but unconditional loads
-				asm volatile("s_waitcnt vmcnt(%2)" : "+v"(g0), "+v"(g1) : "i"(CC_DA * (BITS_A ? 2 : 1)) : "memory"); // the gather
+				NV_COUNTED_WAIT("s_waitcnt vmcnt(%2) ; nv_ready %0 %1" : "+v"(g0), "+v"(g1) : "i"(CC_DA * (BITS_A ? 2 : 1)) : "memory"); // the gather
 				gather_finish();
 				NV_STAMP(2);
 				for (uint32_t i = 0; i < cnt; i += CC_DA)
@@ -924,9 +1088,9 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 					// the youngest to finish alone at single-wave issue rate.  Rotating the priority, offset by the
 					// workgroup's generation so that the workgroups sharing a CU hold different levels at any time,
 					// evens the progress of the waves that share a SIMD (speed only).
-					if (!(a.debugMode & 256u)) // bit 8 (experiments) turns the rotation off
+					if (!NV_DBG(a, 256u)) // bit 8 (experiments) turns the rotation off
 					{
-						switch (((a.debugMode & 131072u) ? blockIdx.x + i / CC_DA : gen + i / CC_DA) & 3u) // bit 17 (experiments): rotation without the generation offset
+						switch ((NV_DBG(a, 131072u) ? blockIdx.x + i / CC_DA : gen + i / CC_DA) & 3u) // bit 17 (experiments): rotation without the generation offset
 						{
 						case 0: __builtin_amdgcn_s_setprio(0); break;
 						case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -957,12 +1121,15 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 						issueA(ring[k], c + CC_DA < cnt ? c + CC_DA : cnt - 1, cand);
 					}
 				}
+				ring_drain();
+#pragma unroll
+				for (int k = 0; k < CC_DA; ++k)
+					ring_release(ring[k]);
 			}
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // drain: the ring's registers are reused below
 			NV_STAMP(3);
 
 			// ---- pass B: exact tests (reference arithmetic) for the commands that can have survivors, bounds + cone
-			if (LATE && candMask && a.cd.clusterOcclusionEnabled == 1 && !(a.debugMode & (1024u | 524288u))) // bit 19 (experiments): texels fetched per command
+			if (LATE && candMask && a.cd.clusterOcclusionEnabled == 1 && !NV_DBG(a, 1024u | 524288u)) // bit 19 (experiments): texels fetched per command
 			{
 				// Late pass with HiZ: the same ring for bounds + cone, and behind it the texel fetches of CC_PT commands in
 				// flight.  A visit = wait for the slot's bounds, first half of the test (up to the texel addresses), second
@@ -972,8 +1139,9 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 				constexpr int CC_DL = 4, CC_PT = 2;                  // ring slots, texel sets in flight
 				constexpr int CC_RL = BITS ? 3 : 2, CC_UL = 4 + CC_RL; // loads per ring issue, per visit
 				static_assert(CC_DL % CC_PT == 0, "the texel set of a visit is chosen statically");
-				uint32_t curDraw = ~0u;
+				uint32_t curDraw = ~0u, certDraw = ~0u;
 				DrawUniform du = {};
+				CertUniform cf = {};
 				uint64_t pending = candMask;
 				uint32_t cIssued[CC_DL];
 				SlotB ring[CC_DL];
@@ -1012,7 +1180,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 					{
 						const int j = k % CC_PT; // static after unrolling
 						if (firstRound) // younger than this slot's issue: the later slots of the prologue and k full visits
-							asm volatile("s_waitcnt vmcnt(%0)" ::"i"(CC_RL * (CC_DL - 1 - k) + k * CC_UL) : "memory");
+							NV_COUNTED_WAIT("s_waitcnt vmcnt(%0)" ::"i"(CC_RL * (CC_DL - 1 - k) + k * CC_UL) : "memory");
 						ringB_wait_loads<BITS, (CC_DL - 1) * CC_UL>(ring[k]);
 						const uint32_t c = cIssued[k];
 						HizProbe probe = { 0, 0, 0, 0, 0, 0.0f };
@@ -1020,17 +1188,32 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 						if (c != ~0u)
 						{
 							const NvMeshTaskCommand cmd = segment_command(r, c);
-							if (cmd.drawId != curDraw)
-							{
-								curDraw = cmd.drawId;
-								du = segment_draw(r, c);
-							}
 							LaneData cur;
 							cur.b0 = (uint32_t)ring[k].bounds;
 							cur.b1 = (uint32_t)(ring[k].bounds >> 32);
 							cur.cone = ring[k].cone;
 							cur.mvbWord = ring[k].mvbWord;
-							probe = late_prepare<BITS>(a, cmd, du, cur, lane, flags, s_mipOffset);
+							// frustum + cone through the certified test; the reference's sphere only where the HiZ probe needs it
+							uint64_t vis = 0;
+							bool decided = false;
+							if (useCert)
+							{
+								if (cmd.drawId != certDraw)
+								{
+									certDraw = cmd.drawId;
+									cf = segment_cert(r, c);
+								}
+								decided = certified_visible(a.cd, cf, cur.b0, cur.b1, cur.cone, cmd.taskCount >= 64u ? ~0ull : (1ull << cmd.taskCount) - 1ull, &vis);
+							}
+							if (!decided || vis)
+							{
+								if (cmd.drawId != curDraw)
+								{
+									curDraw = cmd.drawId;
+									du = load_draw(a.draws, cmd.drawId); // scalar loads: the gathered copy lives only until the filters are derived
+								}
+								probe = late_prepare<BITS>(a, cmd, du, cur, lane, flags, s_mipOffset, decided ? &vis : nullptr);
+							}
 						}
 						// second half of the command whose texels were requested CC_PT visits ago
 						ringT_wait<CC_RL + (CC_PT - 1) * CC_UL>(tex[j]);
@@ -1069,12 +1252,20 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 						for (int k = 0; k < CC_DL; ++k)
 							more = more || cIssued[k] != ~0u;
 				}
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				ring_drain();
+#pragma unroll
+				for (int k = 0; k < CC_DL; ++k)
+					ring_release(ring[k]);
+#pragma unroll
+				for (int j = 0; j < CC_PT; ++j)
+					ring_release(tex[j]);
 			}
-			else if (candMask && !(a.debugMode & 1024u)) // bit 10 (experiments): no exact pass
+			else if (candMask && !NV_DBG(a, 1024u)) // bit 10 (experiments): no exact pass
 			{
-				uint32_t curDraw = ~0u;
+				uint32_t curDraw = ~0u, certDraw = ~0u;
 				DrawUniform du = {};
+				CertUniform cf = {};
+				const bool certFinal = useCert && !(LATE && a.cd.clusterOcclusionEnabled == 1); // (HiZ decides after frustum and cone)
 				uint64_t pending = candMask; // commands not yet issued into the ring
 				uint32_t cIssued[CC_DB];
 				SlotB ring[CC_DB];
@@ -1105,19 +1296,41 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 						if (c != ~0u)
 						{
 							const NvMeshTaskCommand cmd = segment_command(r, c);
-							if (cmd.drawId != curDraw)
-							{
-								curDraw = cmd.drawId;
-								du = segment_draw(r, c);
-							}
 							LaneData cur;
 							cur.b0 = (uint32_t)ring[k].bounds;
 							cur.b1 = (uint32_t)(ring[k].bounds >> 32);
 							cur.cone = ring[k].cone;
 							cur.mvbWord = ring[k].mvbWord;
 							uint64_t vis = 0;
-							if (!(a.debugMode & 4096u)) // bit 12 (experiments): exact pass loads only
+							bool decided = NV_DBG(a, 4096u); // bit 12 (experiments): exact pass loads only
+							if (certFinal && !decided)
+							{
+								if (cmd.drawId != certDraw)
+								{
+									certDraw = cmd.drawId;
+									cf = segment_cert(r, c);
+								}
+								uint64_t need = cmd.taskCount >= 64u ? ~0ull : (1ull << cmd.taskCount) - 1ull, skipM = 0;
+								if (BITS) // clustercull.comp.glsl:86-99
+								{
+									const uint64_t bitM = __ballot((cur.mvbWord >> ((lane + cmd.meshletVisibilityOffset) & 31u) & 1u) != 0);
+									if (!LATE)
+										need &= bitM;
+									else if (cmd.lateDrawVisibility == 1)
+										skipM = bitM;
+								}
+								decided = certified_visible(a.cd, cf, cur.b0, cur.b1, cur.cone, need, &vis);
+								m = vis & ~skipM;
+							}
+							if (!decided) // some lane sits inside a margin (or the test is off): the reference arithmetic for the whole wave
+							{
+								if (cmd.drawId != curDraw)
+								{
+									curDraw = cmd.drawId;
+									du = load_draw(a.draws, cmd.drawId); // scalar loads: the gathered copy lives only until the filters are derived
+								}
 								m = cull_command<LATE, BITS, LATE>(a, cmd, du, cur, lane, &vis, s_mipOffset);
+							}
 							maskLo = writelane_u32(maskLo, (uint32_t)m, c);
 							maskHi = writelane_u32(maskHi, (uint32_t)(m >> 32), c);
 							if (updateBits)
@@ -1144,7 +1357,10 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 						for (int k = 0; k < CC_DB; ++k)
 							more = more || cIssued[k] != ~0u;
 				}
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				ring_drain();
+#pragma unroll
+				for (int k = 0; k < CC_DB; ++k)
+					ring_release(ring[k]);
 			}
 		}
 		else
@@ -1210,7 +1426,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_mask_kernel(ClusterArgs a)
 				if (lane & 3u)
 					pc = 0;
 			}
-			if (pc && !(a.debugMode & 2048u)) // bit 11 (experiments): no tile counts
+			if (pc && !NV_DBG(a, 2048u)) // bit 11 (experiments): no tile counts
 				atomicAdd(&a.tileCounts->counts[bank][tileOf * CC_COUNT_STRIDE], pc);
 		}
 	}
@@ -1238,7 +1454,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs
 	const uint32_t T = scatter_tile_commands(numCmds, a.scatterTiles);
 	const uint32_t numTiles = (numCmds + T - 1) / T; // <= gridDim.x
 	const uint32_t tile = blockIdx.x;
-	const bool dbgNoScatter = a.debugMode & 4u; // experiments only
+	const bool dbgNoScatter = NV_DBG(a, 4u); // experiments only
 
 	// Everything below was written by the cull kernel, i.e. before this launch: plain loads, all issued together.
 	// Both banks of tile counts are read speculatively so that no load waits for the parity word.

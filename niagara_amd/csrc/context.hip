@@ -8,11 +8,11 @@
 #include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
+#include <math.h>
 
 #include "../../include/niagara_vis.h"
-#include "cullmath.cuh"
-#include "ordered.cuh"
-#include "args.cuh"
+#include "cullmath.h"
+#include "args.h"
 
 namespace nv
 {
@@ -63,7 +63,8 @@ struct nv_context
 	// Mesh table registered by nv_upload_meshes (pointer identity + count): lets drawcull stage it in LDS
 	const NvMesh* meshesFrom;
 	uint32_t meshCount;
-	// tuning knobs (environment, read once in nv_create): NV_DEBUG_MODE bit mask, NV_CC_BLOCKS_PER_CU
+	// launch shape of the cull kernel (workgroups per CU) and the dealing's start-delay compensation in percent; constants
+	// in the product, environment-tunable (with the NV_DEBUG_MODE bit mask) only in the NV_EXPERIMENTS build
 	uint32_t debugMode;
 	uint32_t ccBlocksPerCU;
 	uint32_t dealScale;
@@ -134,8 +135,6 @@ int ensure_draw_results(nv_context* ctx, uint32_t drawCount)
 	hipError_t e = hipDeviceSynchronize();
 	if (e != hipSuccess)
 		return (int)e;
-	if (ctx->hintHost)
-		(void)hipHostFree(const_cast<uint32_t*>(ctx->hintHost));
 	if (ctx->drawResults)
 		(void)hipFree(ctx->drawResults);
 	ctx->drawResults = nullptr;
@@ -193,13 +192,16 @@ int nv_create(nv_context** out_ctx, int device)
 	}
 	ctx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	ctx->ccBlocksPerCU = 6;
+	ctx->dealScale = 100;
+#ifdef NV_EXPERIMENTS
+	// the experiments build only (tools/): the product library reads no environment variable
 	if (const char* v = getenv("NV_DEBUG_MODE"))
 		ctx->debugMode = (uint32_t)atoi(v);
-	ctx->dealScale = 100;
 	if (const char* v = getenv("NV_DEAL_SCALE"))
 		ctx->dealScale = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_CC_BLOCKS_PER_CU"))
 		ctx->ccBlocksPerCU = (uint32_t)atoi(v) ? (uint32_t)atoi(v) : 6;
+#endif
 
 	if (hipMalloc(&ctx->masks, nv::clustercull_mask_bytes()) != hipSuccess || hipMalloc(&ctx->tileCounts, sizeof(nv::ClusterCounts)) != hipSuccess ||
 	    hipMemset(ctx->tileCounts, 0, sizeof(nv::ClusterCounts)) != hipSuccess ||
@@ -410,7 +412,9 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 	a.results = ctx->drawResults;
 	a.tileCounts = ctx->drawTileCounts;
 	a.scatterTiles = scatter_grid(ctx);
+#ifdef NV_EXPERIMENTS
 	a.debugMode = ctx->debugMode;
+#endif
 	a.fusedReset = ctx->fusedReset;
 	a.fusedSubmit = ctx->fusedSubmit;
 	a.meshCount = ctx->meshesFrom == d_meshes ? ctx->meshCount : 0u;
@@ -462,6 +466,19 @@ static int fill_cluster_args(nv_context* ctx, nv::ClusterArgs& a, const NvCullDa
 	a.scatterTiles = scatter_grid(ctx);
 	a.generations = ctx->ccBlocksPerCU;
 	a.dealScale = ctx->dealScale;
+	// Margin scale of the conservative filter / certified test (clustercull.hip make_filter): 4 K u S with K = 48,
+	// u = 2^-24 and S = max(1, |f0| + |f1|, |f2| + |f3|) — the error analysis is written for unit-length plane
+	// coefficients (|f| <= 1); other finite coefficients scale the margins, non-finite or absurd ones (or near / far
+	// planes that are not finite) switch both off and every command runs the reference arithmetic.
+	{
+		const float* f = cull->frustum;
+		const float s01 = fabsf(f[0]) + fabsf(f[1]), s23 = fabsf(f[2]) + fabsf(f[3]);
+		float S = 1.0f;
+		S = s01 > S ? s01 : S;
+		S = s23 > S ? s23 : S;
+		const bool finite = s01 <= 1e3f && s23 <= 1e3f && fabsf(cull->znear) <= 1e30f && fabsf(cull->zfar) <= 1e30f; // false on NaN
+		a.filterK = finite ? 4.0f * 48.0f * 5.9604644775390625e-8f * 1.001f * S : 0.0f;
+	}
 	a.hostHint = ctx->hintDevice;
 	return NV_OK;
 }
@@ -480,16 +497,18 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	DeviceGuard guard(ctx->device);
 	a.clusterIndices = d_clusterIndices;
 	a.clusterCount4 = d_clusterCount4;
-	a.debugMode = ctx->debugMode;
 	a.fusedReset = ctx->fusedReset;
 	a.fusedSubmit = ctx->fusedSubmit;
 	a.countsSink = reinterpret_cast<unsigned long long*>(ctx->countsSink);
+#ifdef NV_EXPERIMENTS
+	a.debugMode = ctx->debugMode;
 	if (ctx->debugMode & 8u)
 	{
 		if (!ctx->timing)
 			(void)hipMalloc(&ctx->timing, (size_t)persistent_grid(ctx, ctx->ccBlocksPerCU) * 4 * 8 * sizeof(unsigned long long));
 		a.probeOut = ctx->timing;
 	}
+#endif
 	// two pure maps: the cull kernel also accumulates survivors per scatter tile, so no workgroup waits on another
 	hipStream_t s = (hipStream_t)stream;
 	hipEvent_t e0 = prof_mark(ctx, s);
@@ -581,7 +600,8 @@ int nv_depthreduce(nv_context* ctx, void* stream, const float* d_depth, uint32_t
 	return rc;
 }
 
-// development aid (not part of the public header): copies the NV_DEBUG_MODE bit-3 wave stamps to the host
+#ifdef NV_EXPERIMENTS
+// experiments build only (not part of the public header): copies the NV_DEBUG_MODE bit-3 wave stamps to the host
 int nv_debug_read_timing(nv_context* ctx, unsigned long long* out, uint32_t maxWaves)
 {
 	if (!ctx || !ctx->timing || !out)
@@ -591,6 +611,7 @@ int nv_debug_read_timing(nv_context* ctx, unsigned long long* out, uint32_t maxW
 		waves = maxWaves;
 	return (int)hipMemcpy(out, ctx->timing, (size_t)waves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
 }
+#endif
 
 int nv_set_counts_sink(nv_context* ctx, uint64_t* d_out3)
 {

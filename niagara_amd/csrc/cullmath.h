@@ -1,4 +1,4 @@
-// cullmath.cuh — device-side cull arithmetic for gfx950, one IEEE fp32 operation per source operation.
+// cullmath.h — device-side cull arithmetic for gfx950, one IEEE fp32 operation per source operation.
 //
 // Build with -ffp-contract=off: a visibility decision must be the same bit pattern the CPU reference of the
 // same math produces, so no FMA contraction, IEEE sqrt/divide (hipcc default), and the operation order of the
@@ -277,10 +277,13 @@ NV_DEV HizProbe hiz_prepare(const NvCullData& cd, const NvPyramidDesc& pyr, f3 c
 		footprint(u * (float)w - 0.5f, w, x0, x1, ux0, ux1);
 		footprint(v * (float)h - 0.5f, h, y0, y1, uy0, uy1);
 		const uint32_t base = mipOffsets[l];
-		p.o00 = base + (uint32_t)y0 * w + (uint32_t)x0;
-		p.o10 = base + (uint32_t)y0 * w + (uint32_t)x1;
-		p.o01 = base + (uint32_t)y1 * w + (uint32_t)x0;
-		p.o11 = base + (uint32_t)y1 * w + (uint32_t)x1;
+		// rows and widths are below 2^24 (a mip chain addressed with 32-bit texel offsets): the 24-bit multiply-add is exact,
+		// and unlike the 64-bit form hipcc otherwise picks it reads no register pair (tools/check_asm_hazards.py, check 2)
+		const uint32_t row0 = __umul24((uint32_t)y0, w) + base, row1 = __umul24((uint32_t)y1, w) + base;
+		p.o00 = row0 + (uint32_t)x0;
+		p.o10 = row0 + (uint32_t)x1;
+		p.o01 = row1 + (uint32_t)x0;
+		p.o11 = row1 + (uint32_t)x1;
 		p.use = (ux0 && uy0 ? 1u : 0u) | (ux1 && uy0 ? 2u : 0u) | (ux0 && uy1 ? 4u : 0u) | (ux1 && uy1 ? 8u : 0u) | 16u;
 		p.depthSphere = cd.znear / (c.z - r);
 	}

@@ -11,7 +11,7 @@
 // launches that read every source texel once: 4*W*H + (4/3)*4*pw*ph bytes instead of re-reading each mip.
 // Level 0 from a depth target that is not exactly 2x the pyramid (e.g. 1024x768 -> 512x512) goes through the
 // generic sampler kernel first.
-#include "cullmath.cuh"
+#include "cullmath.h"
 
 namespace nv
 {

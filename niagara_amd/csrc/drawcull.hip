@@ -16,9 +16,8 @@
 //                           TASK mode expands a draw's commands wave-cooperatively: the owning lane's (draw, LOD range,
 //                           dci) is broadcast with readlane and all 64 lanes write consecutive 20-B MeshTaskCommands,
 //                           instead of one lane looping over up to hundreds of commands (drawcull.comp.glsl:131-138).
-#include "cullmath.cuh"
-#include "ordered.cuh"
-#include "args.cuh"
+#include "cullmath.h"
+#include "args.h"
 
 namespace nv
 {
@@ -89,7 +88,7 @@ NV_DEV DrawResult decide_draw(const DrawArgs& a, const char* meshBase, uint32_t 
 	if (visible && (!LATE || cd.clusterOcclusionEnabled == 1 || oldVis == 0 || cd.postPass != 0))
 	{
 		uint32_t lodIndex = 0;
-		if (cd.lodEnabled == 1 && !(a.debugMode & 2u))
+		if (cd.lodEnabled == 1 && !NV_DBG(a, 2u))
 		{
 			float distance = gl_max(length3(c) - radius, 0.0f);
 			float threshold = distance * cd.lodTarget / d0.w;
@@ -294,7 +293,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 		if (c < n)
 		{
 			DrawResult res = { 0, 0, 0 };
-			if (a.debugMode & 1u) // experiments: loads only
+			if (NV_DBG(a, 1u)) // experiments: loads only
 				res.lodWord = __float_as_uint(ld[j].d0.x + ld[j].d1.x) + ld[j].d2.x + ld[j].oldVis == 12345u ? 0x100u : 0u;
 			else
 				res = decide_draw<LATE, TASK, MESH_LDS>(a, meshBase, first + c, ld[j].d0, ld[j].d1, ld[j].d2, ld[j].oldVis);
@@ -308,8 +307,8 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 	__syncthreads();
 	// One thread adds the workgroup's counts to the scatter tiles they fall in (tiles are whole multiples of 64 draws, so
 	// a wave-batch never straddles; a workgroup's 1024 draws usually span one or two tiles): ~1.3 atomics per
-	// workgroup instead of one per wave-batch — atomics into one line serialise in its L2 channel (args.cuh).
-	if (tid == 0 && !(a.debugMode & 4u))
+	// workgroup instead of one per wave-batch — atomics into one line serialise in its L2 channel (args.h).
+	if (tid == 0 && !NV_DBG(a, 4u))
 	{
 		uint32_t runTile = first / T2, runSum = 0;
 #pragma unroll

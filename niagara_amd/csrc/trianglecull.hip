@@ -14,8 +14,8 @@
 // 348 us for 131 k clusters).  Bound: HBM (gather-heavy); algorithmic bytes per slot =
 // 4 + 20 + 48 + 24 + refs (2 or 4 B x vertexCount) + 3 B x triangleCount + 8 B x vertexCount (position half of the 16-B
 // vertex) + 16 B out.
-#include "cullmath.cuh"
-#include "args.cuh"
+#include "cullmath.h"
+#include "args.h"
 
 namespace nv
 {

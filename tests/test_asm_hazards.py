@@ -1,6 +1,8 @@
 """The hazard recognizer of hipcc does not look inside inline asm (clustercull.hip, rules above SlotA): every asm statement
 that reads an SGPR a VALU instruction produced just before it must bring its own s_nop.  tools/check_asm_hazards.py
-compiles the file to gfx950 ISA and checks that; this test runs it and also feeds the scanner a violation."""
+compiles the file to gfx950 ISA and checks that, and (check 2) that no instruction touches a ring register between the
+asm statement that issues its load and the asm statement that waits for it; this test runs both on the real file and
+feeds each scanner a violation."""
 import importlib.util
 import os
 import shutil
@@ -17,12 +19,30 @@ def test_scanner_flags_an_unguarded_block():
     bad = "\tv_readlane_b32 s6, v80, 21\n\tv_readlane_b32 s7, v80, 22\n\t;;#ASMSTART\n\tglobal_load_dword v22, v20, s[6:7]\n\t;;#ASMEND\n"
     good = bad.replace("\tglobal_load_dword", "\ts_nop 4\n\tglobal_load_dword")
     weak = bad.replace("\tglobal_load_dword", "\ts_nop 1\n\tglobal_load_dword")  # enough for a VALU consumer, not for VMEM
-    assert len(chk.scan(bad)[2]) == 1
-    assert chk.scan(good)[1:] == (1, [])
-    assert len(chk.scan(weak)[2]) == 1
+    assert len(chk.scan_nops(bad)[2]) == 1
+    assert chk.scan_nops(good)[1:] == (1, [])
+    assert len(chk.scan_nops(weak)[2]) == 1
     valu = "\tv_readlane_b32 s10, v39, s14\n\t;;#ASMSTART\n\ts_nop 1\n\tv_mov_b32 v65, s10\n\t;;#ASMEND\n"
-    assert chk.scan(valu)[1:] == (1, [])
-    assert len(chk.scan(valu.replace("\ts_nop 1\n", ""))[2]) == 1
+    assert chk.scan_nops(valu)[1:] == (1, [])
+    assert len(chk.scan_nops(valu.replace("\ts_nop 1\n", ""))[2]) == 1
+
+
+def test_scanner_flags_a_touched_in_flight_register():
+    """the hazard found in round 2: a computation scheduled between a ring's last (unused) loads and the drain, in the
+    registers of those loads"""
+    kernel = ["\t;;#ASMSTART", "\ts_nop 4", "\tglobal_load_dwordx2 v[0:1], v20, s[28:29]", "\t;;#ASMEND",
+              "\tv_add_f32_e32 v5, v6, v7",
+              "\tv_rcp_f32_e32 v1, v9",                       # writes v1 while its load is in flight
+              "\t;;#ASMSTART", "\ts_waitcnt vmcnt(0) ; nv_ready all", "\t;;#ASMEND",
+              "\tv_mul_f32_e32 v0, v0, v1", "\ts_endpgm"]
+    found = chk.scan_inflight("k", kernel)
+    assert len(found) == 1 and found[0][2] == [1]
+    ok = [l for l in kernel if "v_rcp" not in l]
+    assert chk.scan_inflight("k", ok) == []
+    # across a branch: the register is still in flight on the taken path
+    branchy = kernel[:4] + ["\ts_cbranch_scc1 .LBB0_2", "\t;;#ASMSTART", "\ts_waitcnt vmcnt(0) ; nv_ready v[0:1]", "\t;;#ASMEND",
+                            ".LBB0_2:", "\tv_mov_b32_e32 v3, v0", "\ts_endpgm"]
+    assert len(chk.scan_inflight("k", branchy)) >= 1
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")

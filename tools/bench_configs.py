@@ -16,6 +16,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
+import oracle  # noqa: E402  (the checker: every config's output is compared with the CPU oracle before its time is reported)
 from niagara_amd import host, synth  # noqa: E402
 from niagara_amd import layouts as L  # noqa: E402
 from niagara_amd import pipeline as P  # noqa: E402
@@ -201,28 +202,50 @@ def config_n4(ctx, iters, n_draws=2048, cpd=1):
                 algorithmic_bytes=algo, achieved_GBs=algo / us / 1e3, frac=algo / us / 1e3 / HBM, triangles_per_s=int(t[1]) / (us * 1e-6))
 
 
-def roofline_size(ctx, iters, n_draws=156250, cpd=10, aos=False):
-    """config 3A x 10 (100 M meshlets, 1.2 GB of cull bytes): HBM, not launch latency or the Infinity Cache, is the bound"""
+def cluster_config(ctx, iters, label, n_draws=156250, cpd=10, aos=False, scene_radius=300.0, backface=1, copies=1):
+    """clustercull<0> over a pre-built command list (config 3A's shape): the roofline size (x10), the AoS-in-place read,
+    and the dense-visibility variants (camera inside the cloud: most commands reach pass B)"""
     dev = ctx.device
-    draws, meshlets, commands, n = synth.cluster_scene(n_draws, cpd)
-    cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, clusterBackfaceEnabled=1)
-    db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+    draws, meshlets, commands, n = synth.cluster_scene(n_draws, cpd, scene_radius=scene_radius)
+    cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, clusterBackfaceEnabled=backface)
+    m = n * 64
+    db, dcb = P.to_device(draws, dev), P.to_device(commands, dev)
+    mlbs = [P.to_device(meshlets, dev) for _ in range(copies)]  # rotated: cache-cold passes when one copy fits the Infinity Cache
+    mlb = torch.cat(mlbs) if copies > 1 else mlbs[0]
+    del mlbs
+    dcbs = [P.to_device(synth.make_task_commands(n_draws, cpd, meshlet_base=c * m), dev) for c in range(copies)]
     if not aos:
-        ctx.upload_meshlets(mlb, len(meshlets))
+        ctx.upload_meshlets(mlb, copies * m)
     dccb = torch.from_numpy(synth.count4_for(n).view(np.int32).copy()).to(dev)
-    cib = torch.zeros(min(n * 64, L.CLUSTER_LIMIT) + 256, dtype=torch.int32, device=dev)
+    cib = torch.zeros(min(m, L.CLUSTER_LIMIT) + 256, dtype=torch.int32, device=dev)
     ccb = torch.zeros(4, dtype=torch.int32, device=dev)
 
     def step(i):
         ctx.reset_count(ccb)
-        ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
+        ctx.clustercull(cd, 0, dcbs[i % copies], dccb, db, mlb, None, None, cib, ccb)
 
     wall, k_us, prof = timed(ctx, step, iters, "cluster_cull")
-    m = n * 64
+    total = int(ccb[0].item())
+    # parity: the whole visible list of the last timed pass against the multithreaded oracle
+    cib_o, cc4_o = np.zeros(m, np.uint32), np.zeros(4, np.uint32)
+    oracle.clustercull(cd, 0, commands, synth.count4_for(n), draws, meshlets, None, None, cib_o, cc4_o, threads=oracle.max_threads())
+    ids = cib[:min(total, L.CLUSTER_LIMIT)].cpu().numpy().view(np.uint32)
+    same = total == int(cc4_o[0]) and (ids == cib_o[:min(total, L.CLUSTER_LIMIT)]).all()
+    # commands that reach pass B = commands with a meshlet the frustum test keeps or the filter cannot exclude; reported as
+    # the share of commands with at least one visible-or-cone-culled meshlet is not observable from outside, so: share of
+    # commands with a survivor (lower bound of the candidates)
+    with_survivor = len(np.unique(cib_o[:int(cc4_o[0])] & 0xffffff)) / n
     algo = m * (24 if aos else 12) + n * 76
-    return dict(config="3A x10 (%s)" % ("AoS in place" if aos else "SoA mirror"), meshlets=m, visible=int(ccb[0].item()), cull_us=k_us,
-                scatter_us=prof["cluster_scatter"][0] / max(1, prof["cluster_scatter"][1]) * 1e3, step_us=wall, algorithmic_bytes=algo,
-                achieved_GBs=algo / k_us / 1e3, frac=algo / k_us / 1e3 / HBM, meshlets_per_s=m / (wall * 1e-6))
+    scat = prof["cluster_scatter"][0] / max(1, prof["cluster_scatter"][1]) * 1e3
+    return dict(config=label, meshlets=m, visible=total, commands_with_survivors=round(with_survivor, 4), cull_us=k_us, scatter_us=scat, step_us=wall,
+                algorithmic_bytes=algo, achieved_GBs=algo / k_us / 1e3, frac=algo / k_us / 1e3 / HBM, pass_frac=(algo - n * 8 + total * 4) / (k_us + scat) / 1e3 / HBM,
+                meshlets_per_s=m / (wall * 1e-6), parity=verdict(same))
+
+
+def verdict(same):
+    if not same:
+        raise SystemExit("parity FAILURE against the CPU oracle")
+    return "bit-identical"
 
 
 if __name__ == "__main__":
@@ -233,7 +256,13 @@ if __name__ == "__main__":
     ctx = P.Context(0)
     runs = {"2": lambda: config2(ctx, a.iters), "2l": lambda: config2_late(ctx, a.iters), "3b": lambda: config3b(ctx, a.iters), "3b_fused": lambda: config3b(P.Context(0), a.iters, fused=True), "4": lambda: config4(ctx, a.iters),
             "4b": lambda: config4(ctx, a.iters, size=1024), "n4": lambda: config_n4(ctx, a.iters),
-            "big": lambda: roofline_size(ctx, max(5, a.iters // 3)), "big_aos": lambda: roofline_size(P.Context(0), max(5, a.iters // 3), aos=True)}
+            "big": lambda: cluster_config(ctx, max(5, a.iters // 3), "3A x10 (SoA mirror)"),
+            "big_aos": lambda: cluster_config(P.Context(0), max(5, a.iters // 3), "3A x10 (AoS in place)", aos=True),
+            # dense visibility: the camera sits inside the cloud, with and without the cone test
+            # (the reference ships clusterBackfaceEnabled = 0 on this path, src/niagara.cpp:1595-1596)
+            "3a_dense": lambda: cluster_config(ctx, a.iters, "3A dense: 10 M meshlets, scene radius 40", 15625, 10, scene_radius=40.0, copies=4),
+            "3a_dense_nocone": lambda: cluster_config(ctx, a.iters, "3A dense, cone off", 15625, 10, scene_radius=40.0, backface=0, copies=4),
+            "3a": lambda: cluster_config(ctx, a.iters, "3A: 10 M meshlets, scene radius 300 (bench.py's workload)", 15625, 10, copies=4)}
     for k, fn in runs.items():
         if a.only and k not in a.only.split(","):
             continue

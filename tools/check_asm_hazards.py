@@ -1,14 +1,22 @@
 #!/usr/bin/env python3
-"""check_asm_hazards.py — guards the one hazard class hipcc cannot see (clustercull.hip, rules above SlotA).
+"""check_asm_hazards.py — ISA scan of clustercull.hip's inline-asm load rings; part of the build (niagara_amd/csrc/Makefile).
 
-The hazard recognizer of the compiler does not look inside inline asm.  On gfx950 an SGPR written by a VALU instruction
-(v_readlane_b32 / v_readfirstlane_b32 — also the reload of a spilled kernel-argument pointer) needs 2 wait states before
-a VALU instruction reads it and 5 before a VMEM instruction uses it as an address base.  Every inline-asm statement that
-reads SGPRs therefore starts with its own s_nop.  This script compiles the file to ISA and checks exactly that: for
-every ;;#ASMSTART block that reads an SGPR produced by a VALU instruction within the preceding few instructions, the
-block must begin with an s_nop that covers the consumer (>= 1 for VALU, >= 4 for VMEM).
+The rings issue global loads from inline asm ("=&v" destinations) and wait for them later with hand-counted
+`s_waitcnt vmcnt(N)` statements that name the slot's registers ("+v").  hipcc is told the destination already holds the
+value at the issue statement, so nothing but its register allocation keeps it from copying, spilling or reading a slot
+before the wait, and its hazard recognizer does not look inside inline asm.  Two checks over the compiled ISA of every
+kernel in the file:
 
-    python tools/check_asm_hazards.py            # exit code 1 and a listing if a block is unguarded
+  1. s_nop guard.  On gfx950 an SGPR written by a VALU instruction (v_readlane_b32 / v_readfirstlane_b32 — also the
+     reload of a spilled kernel-argument pointer) needs 2 wait states before a VALU instruction reads it and 5 before a
+     VMEM instruction uses it as an address base: every asm block fed by such an SGPR within the preceding few
+     instructions must begin with a sufficient s_nop.
+  2. in-flight registers.  Forward dataflow over the kernel's control-flow graph: a VGPR written by an asm load is
+     "in flight" until an asm wait names it (the wait statements print their registers as `; nv_ready v[..] ..`, a drain
+     as `; nv_ready all`).  Any other instruction that reads or writes an in-flight VGPR (a v_mov the allocator inserted
+     to split a live range, a spill, a compiler-scheduled use) is reported, and so is an in-flight register at s_endpgm.
+
+    python tools/check_asm_hazards.py [-D MACRO ...]     # exit code 1 and a listing if anything is found
 """
 import os
 import re
@@ -32,7 +40,16 @@ def sgprs(text):
     return regs
 
 
-def scan(isa):
+def vgprs(text):
+    regs = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", text):
+        regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", text):
+        regs.add(int(m.group(1)))
+    return regs
+
+
+def scan_nops(isa):
     lines = isa.split("\n")
     problems, blocks, guarded = [], 0, 0
     i = 0
@@ -50,9 +67,8 @@ def scan(isa):
         blocks += 1
         reads = set()
         for ins in body:
-            ops = ins.split(None, 1)
+            ops = ins.split(";")[0].split(None, 1)
             if len(ops) == 2 and not ins.startswith("s_nop") and not ins.startswith("s_waitcnt"):
-                # destination operands of loads are VGPRs; every sN / s[a:b] in the operand list is a read (s_mov m0 excepted: still a read)
                 reads |= sgprs(ops[1])
         if not reads:
             continue
@@ -70,15 +86,137 @@ def scan(isa):
     return blocks, guarded, problems
 
 
+def kernels(isa):
+    """(name, [lines]) per function of the .s file"""
+    out, cur, name = [], None, None
+    for ln in isa.split("\n"):
+        m = re.match(r"^(_Z\w+):\s*(;.*)?$", ln)
+        if m:
+            name, cur = m.group(1), []
+            continue
+        if cur is not None:
+            cur.append(ln)
+            if ln.strip().startswith("s_endpgm"):
+                out.append((name, cur))
+                cur = None
+    return out
+
+
+def scan_inflight(name, lines):
+    """forward dataflow: blocks = label-delimited; returns a list of (line number in kernel, instruction, registers)"""
+    # ---- split into basic blocks
+    blocks, order, cur = {}, [], "entry"
+    blocks[cur] = []
+    in_asm = False
+    for no, raw in enumerate(lines):
+        t = raw.strip()
+        m = re.match(r"^(\.LBB\d+_\d+):", t)
+        if m:
+            nxt = m.group(1)
+            blocks.setdefault(cur, [])
+            blocks[cur].append((no, "__fall__ " + nxt, "ctl"))
+            cur = nxt
+            blocks[cur] = []
+            continue
+        if ";;#ASMSTART" in t:
+            in_asm = True
+            continue
+        if ";;#ASMEND" in t:
+            in_asm = False
+            continue
+        if not t or t.startswith((";", ".")):
+            continue
+        blocks[cur].append((no, t, "asm" if in_asm else "ins"))
+        if not in_asm and re.match(r"s_(branch|cbranch_\w+|endpgm|setpc)", t):
+            # a branch ends the block; what follows falls into an anonymous block
+            nxt = "%s.after%d" % (cur, no)
+            if not t.startswith(("s_branch", "s_endpgm", "s_setpc")):
+                blocks[cur].append((no, "__fall__ " + nxt, "ctl"))
+            cur = nxt
+            blocks[cur] = []
+    succ = {}
+    for b, ins in blocks.items():
+        s = []
+        for _, t, kind in ins:
+            if kind == "ctl":
+                s.append(t.split()[1])
+            elif kind == "ins":
+                m = re.match(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", t)
+                if m:
+                    s.append(m.group(1))
+        succ[b] = [x for x in s if x in blocks]
+    # ---- iterate
+    state_in = {b: set() for b in blocks}
+    problems = {}
+    work = list(blocks)
+    seen_once = set()
+    while work:
+        b = work.pop(0)
+        st = set(state_in[b])
+        for no, t, kind in blocks[b]:
+            if kind == "ctl":
+                continue
+            body = t.split(";")[0]
+            if kind == "asm":
+                if body.startswith(("global_load", "buffer_load", "flat_load")):
+                    ops = body.split(None, 1)[1].split(",")
+                    st |= vgprs(ops[0])
+                    touched = vgprs(",".join(ops[1:])) & st
+                    if touched:
+                        problems[(no, t)] = touched
+                elif "nv_ready" in t:
+                    ready = t.split("nv_ready", 1)[1]
+                    if "all" in ready:
+                        st.clear()
+                    else:
+                        st -= vgprs(ready)
+                else:
+                    touched = vgprs(body) & st
+                    if touched:
+                        problems[(no, t)] = touched
+                continue
+            if body.startswith("s_endpgm") and st:
+                problems[(no, t)] = set(st)
+            touched = vgprs(body) & st
+            if touched:
+                problems[(no, t)] = touched
+        for s in succ[b]:
+            if not st <= state_in[s] or s not in seen_once:
+                seen_once.add(s)
+                if not st <= state_in[s]:
+                    state_in[s] |= st
+                    if s not in work:
+                        work.append(s)
+                elif s not in work and s not in seen_once:
+                    work.append(s)
+    return [(no, t, sorted(r)) for (no, t), r in sorted(problems.items())]
+
+
 def main():
+    defines = []
+    args = sys.argv[1:]
+    while args and args[0] == "-D":
+        defines.append("-D" + args[1])
+        args = args[2:]
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "cc.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + [SRC, "-o", out], cwd=os.path.dirname(SRC), stderr=subprocess.DEVNULL)
-        blocks, guarded, problems = scan(open(out).read())
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + defines + [SRC, "-o", out], cwd=os.path.dirname(SRC), stderr=subprocess.DEVNULL)
+        isa = open(out).read()
+    blocks, guarded, problems = scan_nops(isa)
     print("inline-asm blocks: %d, of which fed by a VALU-written SGPR and guarded by s_nop: %d, unguarded: %d" % (blocks, guarded, len(problems)))
     for line, body, producer in problems:
         print("  ISA line %d: %s   <=   %s" % (line, " | ".join(body), producer))
-    return 1 if problems else 0
+    bad = len(problems)
+    for name, lines in kernels(isa):
+        found = scan_inflight(name, lines)
+        if found:
+            print("%s: %d instruction(s) touch a ring register whose load is still in flight" % (name, len(found)))
+            for no, t, regs in found[:12]:
+                print("   +%d  %s    [%s]" % (no, t, ", ".join("v%d" % r for r in regs)))
+        bad += len(found)
+    if not bad:
+        print("in-flight scan: no instruction touches a ring register between its issue and its wait (%d kernels)" % len(kernels(isa)))
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":
