@@ -620,3 +620,152 @@ def test_cluster_expand_decodes_the_lists_like_the_mesh_stage(ctx):
                        torch.from_numpy(cc4.view(np.int32).copy()).to(dev), d_rec, slots, d_tot)
     assert P.from_device(d_rec, L.CLUSTERRECORD).tobytes() == rec_o.tobytes()
     assert (d_tot.cpu().numpy().view(np.uint64) == tot_o).all()
+
+
+def test_cone_test_is_exact_on_the_threshold(ctx):
+    """adversarial input for the certified cone test of pass B: for every draw the position is solved (fp64 bisection
+    along the view-space cone axis) so that meshlet 0 sits ON the threshold  dot(c, axis) = cutoff |c| + r  to fp32
+    precision; the draw's other 63 meshlets share centre, axis and cutoff and step the fp16 radius through the
+    neighbouring values, so they straddle the threshold far inside the margin.  Undecided lanes must fall back to the
+    reference arithmetic and the list must be the oracle's — early pass and late pass (HiZ, visibility bits)."""
+    rng = np.random.default_rng(321)
+    n_draws, cpd = 600, 1
+    draws = host.synth_draws(n_draws, 1, 30.0)
+    cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, clusterBackfaceEnabled=1, draw_distance=120.0)
+    commands = synth.make_task_commands(n_draws, cpd)
+    n = n_draws * cpd
+    meshlets = synth.make_meshlets(n * 64, seed=19)
+    V = cd["view"][0].astype(np.float64).reshape(4, 4).T[:3, :]  # rows of the 3x4 view matrix (column-major storage)
+
+    def rot(q, v):
+        qv, w = q[:3], q[3]
+        return v + 2.0 * np.cross(qv, np.cross(qv, v) + w * v)
+
+    for i in range(n_draws):
+        k = rng.integers(-127, 128, 3).astype(np.int8)
+        if not k.any():
+            k[0] = 127
+        kc = np.int8(rng.integers(-100, 101))
+        v = rng.uniform(-1, 1, 3).astype(np.float16)
+        r0 = np.float16(rng.uniform(0.02, 0.1))
+        q = draws["orientation"][i].astype(np.float64)
+        s = float(draws["scale"][i])
+        axis = V[:, :3] @ rot(q, k.astype(np.float64) / 127.0)
+        cutoff, rr = float(kc) / 127.0, float(r0) * s
+
+        def D(t, base):
+            p = base + t * dirw
+            c = V[:, :3] @ (rot(q, v.astype(np.float64)) * s + p) + V[:, 3]
+            return c @ axis - (cutoff * np.linalg.norm(c) + rr)
+
+        base = np.array([rng.uniform(-10, 10), rng.uniform(-10, 10), -rng.uniform(15, 60)])  # in front of the camera
+        dirw = V[:, :3].T @ (axis / max(np.linalg.norm(axis), 1e-9))  # world direction that moves c along the axis
+        lo, hi = -200.0, 200.0
+        if D(lo, base) * D(hi, base) < 0:  # a root exists on this line: bisect (else keep the random position)
+            for _ in range(200):
+                mid = 0.5 * (lo + hi)
+                if D(lo, base) * D(mid, base) <= 0:
+                    hi = mid
+                else:
+                    lo = mid
+            draws["position"][i] = (base + 0.5 * (lo + hi) * dirw).astype(np.float32)
+        sl = slice(i * 64, i * 64 + 64)
+        meshlets["center"][sl] = v.view(np.uint16)
+        meshlets["cone_axis"][sl] = k
+        meshlets["cone_cutoff"][sl] = kc
+        meshlets["radius"][sl] = (np.array(r0).view(np.uint16).astype(np.int32) + np.arange(-32, 32)).astype(np.uint16)
+    total = _compare_cluster_pass(ctx, draws, meshlets, commands, n, cd, 0, None, None, None)
+    assert 0.05 * n * 64 < total < 0.95 * n * 64
+    # late pass with HiZ and visibility bits over the same geometry
+    mvb0 = rng.integers(0, 2 ** 32, n * 2 + 3, dtype=np.uint64).astype(np.uint32)
+    commands["lateDrawVisibility"][:n] = rng.integers(0, 2, n)
+    pyr = oracle.Pyramid(256, 192)
+    depth = make_scene(seed=3)["depth"]
+    oracle.depthreduce(depth, pyr)
+    gp = P.DepthPyramid(ctx.device, 256, 192)
+    ctx.depthreduce(torch.from_numpy(depth).to(ctx.device), 256, 192, gp.desc)
+    c2 = cd.copy()
+    c2["pyramidWidth"], c2["pyramidHeight"], c2["clusterOcclusionEnabled"] = pyr.width, pyr.height, 1
+    _compare_cluster_pass(ctx, draws, meshlets, commands, n, c2, 1, mvb0, pyr, gp)
+    _compare_cluster_pass(ctx, draws, meshlets, commands, n, c2, 0, mvb0, pyr, gp)
+
+
+@pytest.mark.parametrize("scale", [1.0, 37.5, 1e-3, 5e3, float("inf"), float("nan")])
+def test_frustum_coefficients_outside_the_unit_range(ctx, scale):
+    """the filter's margins are proven for unit-length plane coefficients.  A caller may pass anything in
+    CullData.frustum: scaled coefficients scale the margins, non-finite or absurd ones switch filter and certified test
+    off — the list is the oracle's either way (the reference compares whatever it is given)."""
+    draws, meshlets, commands, n, cd = _cluster_inputs(700, 5, seed=12)
+    draws["position"] *= np.float32(0.15)
+    c = cd.copy()
+    f = c["frustum"][0].copy()
+    f[:2] *= np.float32(scale)
+    if scale == 37.5:
+        f[2:] *= np.float32(0.01)
+    c["frustum"][0] = f
+    _compare_cluster_pass(ctx, draws, meshlets, commands, n, c, 0, None, None, None)
+    c["znear"] = np.float32(scale) if scale != 1.0 else c["znear"]
+    _compare_cluster_pass(ctx, draws, meshlets, commands, n, c, 0, None, None, None)
+
+
+def test_three_million_draws_then_clustercull(ctx):
+    """ADVICE r1 (high) / VERDICT r1 item 4a: a drawcull above the initial result-scratch capacity (2 097 088 draws) grows
+    the scratch; the cluster pass behind it must still find its mapped hint word (it was freed with the old scratch)."""
+    n_draws = 3_000_000
+    meshes, total = synth.make_meshes(2, 2, 70)
+    meshlets = synth.make_meshlets(total)
+    draws = host.synth_draws(n_draws, 2, 300.0)
+    slots, _ = host.assign_visibility_offsets(draws, meshes)
+    cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, lodEnabled=1, clusterBackfaceEnabled=1)
+    T = oracle.max_threads()
+    cap = 1 << 19
+    co, c4o = np.zeros(cap, dtype=L.TASKCMD), np.zeros(4, np.uint32)
+    oracle.drawcull(cd, 0, 1, draws, meshes, co, c4o, np.ones(n_draws, np.uint32), None, threads=T)
+    oracle.tasksubmit(c4o, co)
+    ncmd = int(c4o[1]) * 64
+    assert 1000 < ncmd < cap
+    cib_o, cc4_o = np.zeros(ncmd * 64 + 256, np.uint32), np.zeros(4, np.uint32)
+    oracle.clustercull(cd, 0, co, c4o, draws, meshlets, None, None, cib_o, cc4_o, threads=T)
+    c = P.Context()  # a fresh context: its scratch starts at the initial capacity
+    try:
+        dev = c.device
+        db, mb, mlb = P.to_device(draws, dev), P.to_device(meshes, dev), P.to_device(meshlets, dev)
+        c.upload_meshlets(mlb, len(meshlets))
+        dcb = torch.zeros(cap * 20, dtype=torch.uint8, device=dev)
+        dccb, ccb = torch.zeros(4, dtype=torch.int32, device=dev), torch.zeros(4, dtype=torch.int32, device=dev)
+        dvb = torch.ones(n_draws, dtype=torch.int32, device=dev)
+        cib = torch.zeros(ncmd * 64 + 256, dtype=torch.int32, device=dev)
+        for _ in range(2):
+            dccb.zero_()
+            ccb.zero_()
+            c.drawcull(cd, 0, 1, db, mb, dcb, dccb, dvb, None)
+            c.tasksubmit(dccb, dcb)
+            c.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
+            c.status()
+            assert (G.host_u32(dccb) == c4o).all()
+            assert P.from_device(dcb, L.TASKCMD)[:ncmd].tobytes() == co[:ncmd].tobytes()
+            total = int(cc4_o[0])
+            assert int(ccb[0].item()) == total and (G.host_u32(cib)[:total] == cib_o[:total]).all()
+    finally:
+        c.close()
+
+
+def test_environment_cannot_change_results(monkeypatch):
+    """the product library reads no environment variable.  NV_DEBUG_MODE used to switch off LOD
+    selection, the scatter or the exact pass in the shipped .so; with every bit set a new context still produces the
+    oracle's buffers."""
+    monkeypatch.setenv("NV_DEBUG_MODE", str(0x7fffffff & ~8))
+    monkeypatch.setenv("NV_CC_BLOCKS_PER_CU", "3")
+    monkeypatch.setenv("NV_DEAL_SCALE", "0")
+    scene = make_scene(seed=31, n_draws=2500)
+    c = P.Context()
+    try:
+        got = G.run_frames(c, scene, (1, 1, 1, 1, 1), frames=2)
+    finally:
+        c.close()
+    want = passes.run_frames(oracle, scene, (1, 1, 1, 1, 1), frames=2)
+    for g, w in zip(got, want):
+        for phase in ("early", "late"):
+            for key in ("count4", "cc4", "cib", "dvb", "mvb"):
+                assert (g[phase][key] == w[phase][key]).all(), (phase, key)
+            assert g[phase]["commands"].tobytes() == w[phase]["commands"].tobytes()

@@ -62,9 +62,14 @@ def config2(ctx, iters, n_draws=1_000_000, copies=6):
 
     wall, k_us, _ = timed(ctx, step, iters, "drawcull")
     v = int(dccb[0].item())
+    # parity: commands, count and (untouched by the early pass) drawVisibility against the oracle
+    co, c4o, dvo = np.zeros(n_draws + 1, dtype=L.DRAWCMD), np.zeros(4, np.uint32), np.ones(n_draws, np.uint32)
+    oracle.drawcull(cd, 0, 0, draws, meshes, co, c4o, dvo, None, threads=oracle.max_threads())
+    same = (v == int(c4o[0]) and dcb[:v * 24].cpu().numpy().tobytes() == co[:v].tobytes()
+            and (dvbs[(iters - 1) % copies].cpu().numpy().view(np.uint32) == dvo).all())
     algo = n_draws * 52 + v * 24 + 208 + 4
     return dict(config="2: 1M draws, drawcull<0,0>", draws=n_draws, visible=v, kernel_us=k_us, step_us=wall, draws_per_s=n_draws / (k_us * 1e-6),
-                algorithmic_bytes=algo, achieved_GBs=algo / k_us / 1e3, frac=algo / k_us / 1e3 / HBM)
+                algorithmic_bytes=algo, achieved_GBs=algo / k_us / 1e3, frac=algo / k_us / 1e3 / HBM, parity=verdict(same))
 
 
 def config2_late(ctx, iters, n_draws=1_000_000, copies=6, size=2048):
@@ -94,8 +99,16 @@ def config2_late(ctx, iters, n_draws=1_000_000, copies=6, size=2048):
         ctx.drawcull(cd, 1, 0, dbs[i % copies], mb, dcb, dccb, dvbs[i % copies], pyr.desc)
 
     wall, k_us, _ = timed(ctx, step, iters, "drawcull")
-    return dict(config="2L: 1M draws, drawcull<1,0> with HiZ", draws=n_draws, visible=int(dccb[0].item()), kernel_us=k_us, step_us=wall,
-                draws_per_s=n_draws / (k_us * 1e-6))
+    v = int(dccb[0].item())
+    # parity: pyramid, commands, count and the rewritten drawVisibility against the oracle
+    po = oracle.Pyramid(size, size)
+    oracle.depthreduce(depth.cpu().numpy(), po)
+    co, c4o, dvo = np.zeros(n_draws + 1, dtype=L.DRAWCMD), np.zeros(4, np.uint32), dvb0.cpu().numpy().view(np.uint32).copy()
+    oracle.drawcull(cd, 1, 0, draws, meshes, co, c4o, dvo, po, threads=oracle.max_threads())
+    same = ((pyr.data.cpu().numpy() == po.data).all() and v == int(c4o[0]) and dcb[:v * 24].cpu().numpy().tobytes() == co[:v].tobytes()
+            and (dvbs[(iters - 1) % copies].cpu().numpy().view(np.uint32) == dvo).all())
+    return dict(config="2L: 1M draws, drawcull<1,0> with HiZ", draws=n_draws, visible=v, kernel_us=k_us, step_us=wall,
+                draws_per_s=n_draws / (k_us * 1e-6), parity=verdict(same))
 
 
 def config3b(ctx, iters, n_draws=15625 * 4, fused=False):
@@ -117,9 +130,24 @@ def config3b(ctx, iters, n_draws=15625 * 4, fused=False):
     wall, k_us, prof = timed(ctx, step, iters, "cluster_cull")
     cmds = int(pipe.dccb[0].item())
     tested = int((P.from_device(pipe.dcb, L.TASKCMD)[:cmds]["taskCount"]).sum())
+    # parity: every buffer of the chain against the oracle (the pipeline rewrote the draws' visibility offsets: use its copy)
+    T = oracle.max_threads()
+    pdc = cd.copy()
+    pdc["clusterBackfaceEnabled"] = 1  # what VisibilityPipeline.cull passes for postPass 0 (src/niagara.cpp:1549)
+    co, c4o = np.zeros(n_draws * 10 + 128, dtype=L.TASKCMD), np.zeros(4, np.uint32)
+    oracle.drawcull(pdc, 0, 1, pipe.draws_host, meshes, co, c4o, np.ones(n_draws, np.uint32), None, threads=T)
+    oracle.tasksubmit(c4o, co)
+    ncmd = int(c4o[1]) * 64
+    cib_o, cc4_o = np.zeros(ncmd * 64 + 256, np.uint32), np.zeros(4, np.uint32)
+    oracle.clustercull(cd, 0, co, c4o, pipe.draws_host, meshlets, None, None, cib_o, cc4_o, threads=T)
+    oracle.clustersubmit(cc4_o, cib_o)
+    nv = (int(cc4_o[0]) + 255) // 256 * 256
+    same = ((pipe.dccb.cpu().numpy().view(np.uint32) == c4o).all() and P.from_device(pipe.dcb, L.TASKCMD)[:ncmd].tobytes() == co[:ncmd].tobytes()
+            and (pipe.ccb.cpu().numpy().view(np.uint32) == cc4_o).all() and (pipe.cib[:nv].cpu().numpy().view(np.uint32) == cib_o[:nv]).all()
+            and bool((pipe.dvb == 1).all().item()))
     return dict(config="3B: drawcull<0,1> -> tasksubmit -> clustercull<0> -> clustersubmit" + (" (NV_OPT_FUSED_SUBMIT + FUSED_COUNT_RESET: 4 launches)" if fused else " (8 launches)"), draws=n_draws, task_commands=cmds, meshlets_tested=tested,
                 visible=int(pipe.ccb[0].item()), step_us=wall, cluster_cull_us=k_us, cluster_scatter_us=prof["cluster_scatter"][0] / max(1, prof["cluster_scatter"][1]) * 1e3,
-                drawcull_us=prof["drawcull"][0] / max(1, prof["drawcull"][1]) * 1e3, meshlets_per_s=tested / (wall * 1e-6))
+                drawcull_us=prof["drawcull"][0] / max(1, prof["drawcull"][1]) * 1e3, meshlets_per_s=tested / (wall * 1e-6), parity=verdict(same))
 
 
 def config4(ctx, iters, size=4096, n_draws=15625, cpd=10):
@@ -154,7 +182,16 @@ def config4(ctx, iters, size=4096, n_draws=15625, cpd=10):
     wall_c, k_c, prof = timed(ctx, late, iters, "cluster_cull")
     m = n * 64
     algo = m * 12 + n * 68 + n * 8 + m // 4
-    return dict(config="4: 4096^2 depth pyramid + 10M-meshlet late clustercull with HiZ", pyramid_us=k_p, pyramid_bytes=pyr_bytes,
+    # parity: the pyramid, the visible IDs and the rewritten visibility words against the oracle
+    po = oracle.Pyramid(size, size)
+    oracle.depthreduce(depth.cpu().numpy(), po)
+    mvo = mvb0.cpu().numpy().view(np.uint32).copy()
+    cib_o, cc4_o = np.zeros(m, np.uint32), np.zeros(4, np.uint32)
+    oracle.clustercull(cd, 1, commands, synth.count4_for(n), draws, meshlets, mvo, po, cib_o, cc4_o, threads=oracle.max_threads())
+    total = int(ccb[0].item())
+    same = ((pyr.data.cpu().numpy() == po.data).all() and total == int(cc4_o[0]) and (cib[:total].cpu().numpy().view(np.uint32) == cib_o[:total]).all()
+            and (mvb.cpu().numpy().view(np.uint32) == mvo).all())
+    return dict(config="4: 4096^2 depth pyramid + 10M-meshlet late clustercull with HiZ", parity=verdict(same), pyramid_us=k_p, pyramid_bytes=pyr_bytes,
                 pyramid_GBs=pyr_bytes / k_p / 1e3, pyramid_frac=pyr_bytes / k_p / 1e3 / HBM, texels_per_s=size * size / (k_p * 1e-6),
                 late_cull_us=k_c, late_scatter_us=prof["cluster_scatter"][0] / max(1, prof["cluster_scatter"][1]) * 1e3, late_visible=int(ccb[0].item()),
                 late_algorithmic_bytes=algo, late_frac=algo / k_c / 1e3 / HBM, meshlets_per_s=m / ((k_c + prof["cluster_scatter"][0] / max(1, prof["cluster_scatter"][1]) * 1e3) * 1e-6))
@@ -198,16 +235,21 @@ def config_n4(ctx, iters, n_draws=2048, cpd=1):
     refs = np.where(meshlets["shortRefs"] == 1, 2, 4) * vc
     algo = int((4 + 20 + 48 + 24 + 16) * m + refs.sum() + 3 * tc.sum() + 8 * vc.sum())
     t = totals.cpu().numpy() // iters
+    # parity: every slot's keep mask and the totals against the oracle
+    mo, to = np.zeros(slots, dtype=L.TRIMASK), np.zeros(3, np.uint64)
+    cib_h = cib.cpu().numpy().view(np.uint32)
+    oracle.trianglecull(g, commands, draws, meshlets, data, vertices, cib_h, ccb.cpu().numpy().view(np.uint32), mo, to)
+    same = masks.cpu().numpy().tobytes() == mo.tobytes() and [int(x) for x in t] == [int(x) for x in to]
     return dict(config="N4: mesh-stage triangle cull, %d clusters" % m, clusters=int(t[0]), triangles=int(t[1]), kept=int(t[2]), call_us=us,
-                algorithmic_bytes=algo, achieved_GBs=algo / us / 1e3, frac=algo / us / 1e3 / HBM, triangles_per_s=int(t[1]) / (us * 1e-6))
+                algorithmic_bytes=algo, achieved_GBs=algo / us / 1e3, frac=algo / us / 1e3 / HBM, triangles_per_s=int(t[1]) / (us * 1e-6), parity=verdict(same))
 
 
-def cluster_config(ctx, iters, label, n_draws=156250, cpd=10, aos=False, scene_radius=300.0, backface=1, copies=1):
+def cluster_config(ctx, iters, label, n_draws=156250, cpd=10, aos=False, scene_radius=300.0, backface=1, copies=1, cam_pos=(0, 0, 0)):
     """clustercull<0> over a pre-built command list (config 3A's shape): the roofline size (x10), the AoS-in-place read,
     and the dense-visibility variants (camera inside the cloud: most commands reach pass B)"""
     dev = ctx.device
     draws, meshlets, commands, n = synth.cluster_scene(n_draws, cpd, scene_radius=scene_radius)
-    cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, clusterBackfaceEnabled=backface)
+    cd = host.build_cull_data(cam_pos=cam_pos, draw_count=n_draws, cullingEnabled=1, clusterBackfaceEnabled=backface)
     m = n * 64
     db, dcb = P.to_device(draws, dev), P.to_device(commands, dev)
     mlbs = [P.to_device(meshlets, dev) for _ in range(copies)]  # rotated: cache-cold passes when one copy fits the Infinity Cache
@@ -258,10 +300,12 @@ if __name__ == "__main__":
             "4b": lambda: config4(ctx, a.iters, size=1024), "n4": lambda: config_n4(ctx, a.iters),
             "big": lambda: cluster_config(ctx, max(5, a.iters // 3), "3A x10 (SoA mirror)"),
             "big_aos": lambda: cluster_config(P.Context(0), max(5, a.iters // 3), "3A x10 (AoS in place)", aos=True),
-            # dense visibility: the camera sits inside the cloud, with and without the cone test
-            # (the reference ships clusterBackfaceEnabled = 0 on this path, src/niagara.cpp:1595-1596)
-            "3a_dense": lambda: cluster_config(ctx, a.iters, "3A dense: 10 M meshlets, scene radius 40", 15625, 10, scene_radius=40.0, copies=4),
-            "3a_dense_nocone": lambda: cluster_config(ctx, a.iters, "3A dense, cone off", 15625, 10, scene_radius=40.0, backface=0, copies=4),
+            # dense visibility: the same 10 M meshlets in a cloud of radius 40 seen from z = +60 (87 % of the
+            # commands have survivors) or +30 (53 %), with and without the cone test (the reference ships
+            # clusterBackfaceEnabled = 0 on this path, src/niagara.cpp:1595-1596)
+            "3a_dense": lambda: cluster_config(ctx, a.iters, "3A dense: 10 M meshlets, radius 40, camera z=60", 15625, 10, scene_radius=40.0, copies=4, cam_pos=(0, 0, 60)),
+            "3a_dense_nocone": lambda: cluster_config(ctx, a.iters, "3A dense, cone off", 15625, 10, scene_radius=40.0, backface=0, copies=4, cam_pos=(0, 0, 60)),
+            "3a_half": lambda: cluster_config(ctx, a.iters, "3A half dense: radius 40, camera z=30", 15625, 10, scene_radius=40.0, copies=4, cam_pos=(0, 0, 30)),
             "3a": lambda: cluster_config(ctx, a.iters, "3A: 10 M meshlets, scene radius 300 (bench.py's workload)", 15625, 10, copies=4)}
     for k, fn in runs.items():
         if a.only and k not in a.only.split(","):
