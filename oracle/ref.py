@@ -99,3 +99,36 @@ def occlusion_mip(aabb, pw, ph):
 
 def cone_cull(c, r, axis, cutoff):
     return bool(lib().ref_cone_cull(_p(np.asarray(c, np.float32)), C.c_float(r), _p(np.asarray(axis, np.float32)), C.c_float(cutoff)))
+
+
+# ---- the reference's scene-cache code (src/scenecache.cpp compiled in place, oracle/ref_scenecache.cpp) ----
+def scene_sizeof(what):
+    lib().ref_scene_sizeof.restype = C.c_uint32
+    return int(lib().ref_scene_sizeof(int(what)))
+
+
+def save_scene_cache(path, meshes, meshlets, draws, *, vertex_count=100, index_count=300, meshletdata_count=500, meshletvtx0_count=64,
+                     material_count=3, light_count=2, animation_count=1, keyframe_count=4, texture_paths=2,
+                     camera=((1.0, 2.0, 3.0), (0.0, 0.0, 0.0, 1.0), 1.2, 0.5), sun=(0.0, -1.0, 0.0), hash_meta=0x1122334455667788, clrt_mode=False,
+                     omm_states=0):
+    """saveSceneCache (src/scenecache.cpp:120-260) itself, uncompressed (the codecs are meshoptimizer's: not vendored)"""
+    cam = np.array(list(camera[0]) + list(camera[1]) + [camera[2], camera[3]], np.float32)
+    s3 = np.array(sun, np.float32)
+    rc = lib().ref_save_scene_cache(os.fsencode(str(path)), _p(np.ascontiguousarray(meshes)), C.c_uint32(len(meshes)), _p(np.ascontiguousarray(meshlets)),
+                                    C.c_uint32(len(meshlets)), _p(np.ascontiguousarray(draws)), C.c_uint32(len(draws)), C.c_uint32(vertex_count),
+                                    C.c_uint32(index_count), C.c_uint32(meshletdata_count), C.c_uint32(meshletvtx0_count), C.c_uint32(material_count),
+                                    C.c_uint32(light_count), C.c_uint32(animation_count), C.c_uint32(keyframe_count), C.c_uint32(texture_paths), _p(cam), _p(s3),
+                                    C.c_uint64(hash_meta), int(bool(clrt_mode)), C.c_uint32(omm_states))
+    if rc:
+        raise RuntimeError("saveSceneCache failed")
+
+
+def load_scene_cache(path, mesh_dtype, meshlet_dtype, draw_dtype, hash_meta=0x1122334455667788, clrt_mode=False, omm_states=0):
+    """loadSceneCache (src/scenecache.cpp:273-370) itself -> (meshes, meshlets, draws, camera9, sun3), or None if it rejects the file"""
+    counts, cam, sun = np.zeros(3, np.uint32), np.zeros(9, np.float32), np.zeros(3, np.float32)
+    rc = lib().ref_load_scene_cache(os.fsencode(str(path)), C.c_uint64(hash_meta), int(bool(clrt_mode)), int(omm_states), _p(counts), _p(cam), _p(sun))
+    if rc:
+        return None
+    meshes, meshlets, draws = np.zeros(counts[0], mesh_dtype), np.zeros(counts[1], meshlet_dtype), np.zeros(counts[2], draw_dtype)
+    lib().ref_loaded_arrays(_p(meshes), _p(meshlets), _p(draws))
+    return meshes, meshlets, draws, cam, sun

@@ -3,9 +3,11 @@
 (nv_scenecache_info / nv_scenecache_read).
 
 The meshopt-coded streams of a compressed file are opaque to the reader (it steps over them by the sizes in the
-header), so `compressed=True` writes arbitrary bytes of the stated sizes there.  Parity note: no `.cache` file and no
-meshoptimizer sources exist in the reference tree, so this writer — not a file produced by niagara — is what the reader
-is checked against ("parity unpinned" for SURVEY.md §8f N3).
+header), so `compressed=True` writes arbitrary bytes of the stated sizes there.  Parity: the reader is pinned against the
+reference's own saveSceneCache / loadSceneCache (src/scenecache.cpp compiled in place, oracle/ref_scenecache.cpp) for the
+raw layout, and this writer is itself held to the reference's loader (tests/test_scenecache.py).  What stays unpinned is
+the `compressed` layout only — the codecs are meshoptimizer's, which the reference does not vendor, so niagara's code
+cannot produce such a file here; for it this writer restates :163-182 (same sections, sizes from the header).
 """
 import struct
 
