@@ -46,13 +46,28 @@ def parse():
     return ap.parse_args()
 
 
+def make_inputs(n_draws, cpd, rank, world):
+    """the rank's shard of the synthetic pool: (draws, meshlets, CullData, dccb words).  The pool's commands are
+    [0, world * n_draws * cpd); shard.command_range gives the rank its contiguous range, whose draws are the matching
+    slice of niagara's draw generator (src/niagara.cpp:978-997) and whose meshlets come from a per-rank seed."""
+    from niagara_amd import host, shard, synth
+    n_cmd = n_draws * cpd
+    b, e = shard.command_range(n_cmd * world, rank, world)
+    assert (b, e) == (rank * n_cmd, (rank + 1) * n_cmd)
+    draws = host.synth_draws(n_draws * world, 1, 300.0)[b // cpd:e // cpd].copy()
+    draws["meshletVisibilityOffset"] = np.arange(n_draws, dtype=np.uint32) * (cpd * 64)
+    meshlets = synth.make_meshlets(n_cmd * 64, seed=2 + rank)
+    cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, clusterBackfaceEnabled=1)
+    return draws, meshlets, cd, synth.count4_for(n_cmd)
+
+
 def main():
     args = parse()
     import torch
     import torch.distributed as dist
 
     import niagara_amd  # raises if libniagara_vis.so is missing: there is no fallback
-    from niagara_amd import host, synth
+    from niagara_amd import shard, synth
     from niagara_amd import layouts as L
     from niagara_amd import pipeline as P
 
@@ -74,16 +89,13 @@ def main():
         dist.all_reduce(torch.zeros(1, dtype=torch.int64, device=dev))
         torch.cuda.synchronize()
 
-    # ---- inputs: rank r owns commands [r*C, (r+1)*C) of a world*C command pool; weak scaling
+    # ---- inputs: the pool of world x C commands shards by contiguous command ranges (niagara_amd/shard.py);
+    # rank r owns [r C, (r+1) C) and the 10 M meshlets they reference (weak scaling); draws follow their commands
     n_draws, cpd = args.draws, args.commands_per_draw
     n_cmd = n_draws * cpd
     n_meshlets = n_cmd * 64
     copies = max(1, args.copies)
-    draws = host.synth_draws(n_draws * world, 1, 300.0)[rank * n_draws:(rank + 1) * n_draws].copy()
-    draws["meshletVisibilityOffset"] = np.arange(n_draws, dtype=np.uint32) * (cpd * 64)
-    meshlets = synth.make_meshlets(n_meshlets, seed=2 + rank)
-    cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, clusterBackfaceEnabled=1)
-    count4 = synth.count4_for(n_cmd)
+    draws, meshlets, cd, count4 = make_inputs(n_draws, cpd, rank, world)
 
     ctx = P.Context(local_rank)
     if not args.explicit_reset:
@@ -97,14 +109,9 @@ def main():
     dccb = torch.from_numpy(count4.view(np.int32).copy()).to(dev)
     cib = torch.zeros(min(n_meshlets, L.CLUSTER_LIMIT) + 256, dtype=torch.int32, device=dev)
     ccb = torch.zeros(4, dtype=torch.int32, device=dev)
-    # N > 1: the passes' counts are summed over the ranks.  Nothing on the data path waits for them, so
-    # they are (a) written by the scatter launch itself (nv_set_counts_sink: no extra launch per pass) into row i % B of a
-    # [B, 3] int64 block and (b) reduced B passes at a time — one asynchronous all-reduce of the block on the
-    # collective's own stream, waited for only when its block comes round again (two blocks alternate).  Every pass's
-    # counts are reduced inside the timed region; per pass that is 1/B of a latency-bound collective instead of one.
+    # N > 1: the passes' counts are summed over the ranks; batched, asynchronous, written by the scatter launch (shard.CountsReducer)
     B = max(1, args.counts_batch)
-    blocks = [torch.zeros((B, 3), dtype=torch.int64, device=dev) for _ in range(2)]
-    pending = [None, None]
+    red = shard.CountsReducer(ctx, dev, B)
     if not args.aos:
         ctx.upload_meshlets(mlb, copies * n_meshlets)
     torch.cuda.synchronize()
@@ -112,26 +119,11 @@ def main():
     def step(i):
         if args.explicit_reset:
             ctx.reset_count(ccb)  # the caller's vkCmdFillBuffer(ccb, 0, 4, 0) as its own launch
-        if world > 1:
-            blk, row = (i // B) % 2, i % B
-            if row == 0 and pending[blk] is not None:
-                pending[blk].wait()  # the block's previous reduction (issued 2 B passes ago)
-                pending[blk] = None
-            ctx.set_counts_sink(blocks[blk][row])
+        red.before_pass(i)
         ctx.clustercull(cd, 0, dcbs[i % copies], dccb, db, mlb, None, None, cib, ccb)
-        if world > 1 and i % B == B - 1:
-            pending[(i // B) % 2] = dist.all_reduce(blocks[(i // B) % 2], async_op=True)
+        red.after_pass(i)
 
-    def drain(n_steps):
-        """reduces the rows of a batch the loop left unfinished, then waits for everything in flight"""
-        if world > 1:
-            if n_steps % B:
-                blk = (n_steps // B) % 2
-                pending[blk] = dist.all_reduce(blocks[blk], async_op=True)
-            for k in range(2):
-                if pending[k] is not None:
-                    pending[k].wait()
-                    pending[k] = None
+    drain = red.drain
 
     for i in range(args.warmup):
         step(i)
@@ -151,7 +143,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    last_counts = blocks[((args.steps - 1) // B) % 2][(args.steps - 1) % B].clone() if world > 1 else None
+    last_counts = red.last(args.steps) if world > 1 else None
 
     # ---- roofline leg: the same `steps` passes again with the library's HIP events bracketing each kernel on the
     # launch stream (nv_profile_*).  It is a separate loop because an event record is itself a barrier packet: three

@@ -26,10 +26,64 @@ def to_global_ids(local_ids, command_base):
     """clusterIndices entries are commandId (24 bits) | lane << 24 (clustercull.comp.glsl:138); rebase the rank-local
     command id by the first command the rank owns"""
     local_ids = np.asarray(local_ids, dtype=np.uint32)
-    cmd = (local_ids & np.uint32(0xffffff)) + np.uint32(command_base)
-    if cmd.size and int(cmd.max()) >= 1 << 24:
+    pad = local_ids == np.uint32(0xffffffff)  # clustersubmit's padding entries (clustersubmit.comp.glsl:41-44) stay ~0
+    cmd = (local_ids & np.uint32(0xffffff)).astype(np.uint64) + np.uint64(command_base)
+    if cmd.size and int(cmd[~pad].max(initial=0)) >= 1 << 24:
         raise ValueError("global command id does not fit the 24-bit field of a cluster index")
-    return cmd | (local_ids & np.uint32(0xff000000))
+    out = cmd.astype(np.uint32) | (local_ids & np.uint32(0xff000000))
+    out[pad] = np.uint32(0xffffffff)
+    return out
+
+
+class CountsReducer:
+    """The passes' counts {0, task commands, visible meshlets} summed over the ranks — the one collective of the sharded
+    path.  Nothing on the data path waits for it, so it is kept off the critical path twice over:
+    the scatter launch writes the payload itself (nv_set_counts_sink: no extra launch per pass) into row i % B of a
+    [B, 3] int64 block, and the block is reduced B passes at a time with ONE asynchronous all-reduce on the collective's
+    own stream, waited for only when the block comes round again (two blocks alternate).  B = 1: one collective per pass.
+
+        red = CountsReducer(ctx, device, batch)
+        for i in range(steps): red.before_pass(i); ctx.clustercull(...); red.after_pass(i)
+        red.drain(steps); total = red.last(steps)          # int64[3], summed over the ranks
+    """
+
+    def __init__(self, ctx, device, batch=8):
+        import torch
+        import torch.distributed as dist
+        self.ctx, self.dist, self.B = ctx, dist, max(1, int(batch))
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.blocks = [torch.zeros((self.B, 3), dtype=torch.int64, device=device) for _ in range(2)]
+        self.pending = [None, None]
+
+    def before_pass(self, i):
+        if self.world == 1:
+            return
+        blk, row = (i // self.B) % 2, i % self.B
+        if row == 0 and self.pending[blk] is not None:
+            self.pending[blk].wait()  # the block's previous reduction (issued 2 B passes ago)
+            self.pending[blk] = None
+        self.ctx.set_counts_sink(self.blocks[blk][row])
+
+    def after_pass(self, i):
+        if self.world > 1 and i % self.B == self.B - 1:
+            blk = (i // self.B) % 2
+            self.pending[blk] = self.dist.all_reduce(self.blocks[blk], async_op=True)
+
+    def drain(self, n_steps):
+        """reduces the rows of a batch the loop left unfinished, then waits for everything in flight"""
+        if self.world == 1:
+            return
+        if n_steps % self.B:
+            blk = (n_steps // self.B) % 2
+            self.pending[blk] = self.dist.all_reduce(self.blocks[blk], async_op=True)
+        for k in range(2):
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+                self.pending[k] = None
+
+    def last(self, n_steps):
+        """the summed counts of pass n_steps - 1 (after drain)"""
+        return self.blocks[((n_steps - 1) // self.B) % 2][(n_steps - 1) % self.B].clone()
 
 
 def allreduce_counts(counts):

@@ -71,3 +71,12 @@ def test_shard_ranges_cover_without_overlap():
 def test_global_id_field_overflow_is_refused():
     with pytest.raises(ValueError):
         shard.to_global_ids(np.array([5], np.uint32), (1 << 24) - 2)
+
+
+def test_padding_entries_are_not_rebased():
+    """clustersubmit pads the list with ~0 up to a multiple of 256 (clustersubmit.comp.glsl:41-44); rebasing must
+    leave those entries alone instead of overflowing the 24-bit command field"""
+    ids = np.array([3 | (5 << 24), 0xffffffff, 70 | (63 << 24), 0xffffffff], np.uint32)
+    out = shard.to_global_ids(ids, 1000)
+    assert out.tolist() == [1003 | (5 << 24), 0xffffffff, 1070 | (63 << 24), 0xffffffff]
+    assert shard.to_global_ids(np.zeros(0, np.uint32), 5).size == 0

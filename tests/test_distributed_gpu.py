@@ -1,0 +1,114 @@
+"""The N > 1 path executed with the HIP kernels.  A gpurun box has ONE GPU, so both ranks share
+cuda:0 and the process group is gloo; what runs is exactly bench.py's N > 1 code and niagara_amd/shard.py — command
+ranges, nv_set_counts_sink rows written by the scatter launch, the batched asynchronous all-reduce, ID rebasing — only
+the transport differs from the 8-GPU run (RCCL over xGMI), which is the driver's to launch."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("batch", [8, 1, 3])
+def test_bench_two_ranks_on_one_device(batch):
+    """python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --backend gloo --shared-device: rc 0, one JSON
+    line, and the all-reduced visible count of the last pass = the sum of what the oracle sees in the two shards"""
+    import oracle
+    sys.path.insert(0, ROOT)
+    import bench
+    from niagara_amd import synth
+    draws_per_rank, cpd, steps = 3000, 10, 16
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--shared-device", "--steps", str(steps), "--warmup", "3",
+           "--counts-batch", str(batch), "--draws", str(draws_per_rank), "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == steps and rec["scaling"] == "weak"
+    want = []
+    for rank in range(2):
+        draws, meshlets, cd, c4 = bench.make_inputs(draws_per_rank, cpd, rank, 2)
+        commands = synth.make_task_commands(draws_per_rank, cpd)
+        cib, cc4 = np.zeros(len(commands) * 64, np.uint32), np.zeros(4, np.uint32)
+        oracle.clustercull(cd, 0, commands, c4, draws, meshlets, None, None, cib, cc4, threads=oracle.max_threads())
+        want.append(int(cc4[0]))
+    assert rec["config"]["visible_per_gpu"] == want[0]
+    assert rec["config"]["visible_total"] == want[0] + want[1] and want[1] > 0
+
+
+def _worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    from niagara_amd import host, shard, synth
+    from niagara_amd import pipeline as P
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    ctx = P.Context(0)
+    dev = ctx.device
+    draws, meshlets, commands, n = synth.cluster_scene(2500, 7, seed=5)
+    cd = host.build_cull_data(draw_count=len(draws), cullingEnabled=1, clusterBackfaceEnabled=1)
+    b, e = shard.command_range(n, rank, world)
+    local, ln = shard.local_commands(commands, b, e)
+    db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(local, dev)
+    ctx.upload_meshlets(mlb, len(meshlets))
+    dccb = torch.from_numpy(synth.count4_for(ln).view(np.int32).copy()).to(dev)
+    cib = torch.zeros(len(local) * 64 + 256, dtype=torch.int32, device=dev)
+    ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+    red = shard.CountsReducer(ctx, dev, batch=2)
+    for i in range(5):
+        ccb.zero_()
+        red.before_pass(i)
+        ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
+        ctx.clustersubmit(ccb, cib)
+        red.after_pass(i)
+    red.drain(5)
+    ctx.status()
+    total = int(ccb[0].item())
+    padded = (total + 255) // 256 * 256
+    ids = shard.to_global_ids(cib[:padded].cpu().numpy().view(np.uint32), b)
+    np.save(os.path.join(out_dir, "ids_%d.npy" % rank), ids[:total])
+    np.save(os.path.join(out_dir, "pad_%d.npy" % rank), ids[total:])
+    np.save(os.path.join(out_dir, "counts_%d.npy" % rank), red.last(5).cpu().numpy())
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_run_the_hip_pass_on_their_shards(tmp_path):
+    """each rank culls ITS command range with nv_clustercull (not the oracle), rebases its IDs; concatenated they are the
+    unsharded oracle list, the padding entries stay ~0, and every rank holds the global sums"""
+    import torch.multiprocessing as mp
+    import oracle
+    from niagara_amd import host, synth
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    draws, meshlets, commands, n = synth.cluster_scene(2500, 7, seed=5)
+    cd = host.build_cull_data(draw_count=len(draws), cullingEnabled=1, clusterBackfaceEnabled=1)
+    cib, cc4 = np.zeros(len(commands) * 64 + 256, np.uint32), np.zeros(4, np.uint32)
+    oracle.clustercull(cd, 0, commands, synth.count4_for(n), draws, meshlets, None, None, cib, cc4)
+    ids = np.concatenate([np.load(tmp_path / ("ids_%d.npy" % r)) for r in range(world)])
+    assert cc4[0] > 1000 and (ids == cib[:cc4[0]]).all()
+    for r in range(world):
+        assert (np.load(tmp_path / ("pad_%d.npy" % r)) == 0xffffffff).all()
+        c = np.load(tmp_path / ("counts_%d.npy" % r))
+        assert c[1] == n and c[2] == cc4[0]
