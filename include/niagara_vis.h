@@ -217,6 +217,17 @@ int nv_upload_meshlets(nv_context* ctx, void* stream, const NvMeshlet* d_meshlet
  * unregistered or larger tables are gathered from global memory.  The table is only read at pass time. */
 int nv_upload_meshes(nv_context* ctx, void* stream, const NvMesh* d_meshes, uint32_t meshCount);
 
+/* Upload hook next to uploadBuffer(db) (src/niagara.cpp:1052): builds the library-owned SoA mirror of what a draw
+ * decision reads of a MeshDraw — {position, scale} and {orientation} as two 16-B streams, {meshIndex, postPass} as an
+ * 8-B stream — so that the decide kernel of nv_drawcull reads three perfectly coalesced streams (40 B per draw) instead
+ * of 48-B-stride records.  Used when nv_drawcull's d_draws is the pointer registered here or a record inside that
+ * buffer with drawCount records behind it (a pass over a shard of the draws); the 48-B AoS records are read in place
+ * otherwise (same results).  Same registration contract as nv_upload_meshlets ((NULL, 0) drops it).
+ * nv_update_draws re-transposes [first, first + count) after the caller rewrote those records — the animation path,
+ * src/niagara.cpp:1385-1391, which memcpy()s single MeshDraws into the mapped draw buffer every frame. */
+int nv_upload_draws(nv_context* ctx, void* stream, const NvMeshDraw* d_draws, uint32_t drawCount);
+int nv_update_draws(nv_context* ctx, void* stream, const NvMeshDraw* d_draws, uint32_t first, uint32_t count);
+
 /* ---- the passes ---- */
 
 /* drawcull.comp.glsl:54-156; dispatch at src/niagara.cpp:1548-1556.

@@ -25,6 +25,7 @@ int launch_taskcull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_
 int launch_probe(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
 int launch_soa_split(hipStream_t, const NvMeshlet*, uint32_t count, uint32_t padded, uint2* bounds, uint32_t* cones);
 int launch_drawcull(hipStream_t, const DrawArgs&, int late, int task);
+int launch_draw_split(hipStream_t, const NvMeshDraw*, uint32_t first, uint32_t count, float4* posScale, float4* orient, uint2* meshPost);
 size_t drawcull_result_bytes(uint32_t drawCount);
 int launch_tasksubmit(hipStream_t, uint32_t* count4, NvMeshTaskCommand* commands);
 int launch_reset_count(hipStream_t, uint32_t* a, uint32_t* b);
@@ -60,6 +61,13 @@ struct nv_context
 	uint2* soaBounds;
 	uint32_t* soaCones;
 	uint32_t soaCapacity;
+	// SoA mirror of the MeshDraw fields a draw decision reads (nv_upload_draws)
+	const NvMeshDraw* drawsFrom;
+	uint32_t drawsCount;
+	float4* soaPosScale;
+	float4* soaOrient;
+	uint2* soaMeshPost;
+	uint32_t drawsCapacity;
 	// Mesh table registered by nv_upload_meshes (pointer identity + count): lets drawcull stage it in LDS
 	const NvMesh* meshesFrom;
 	uint32_t meshCount;
@@ -253,6 +261,12 @@ void nv_destroy(nv_context* ctx)
 		(void)hipFree(ctx->soaBounds);
 	if (ctx->soaCones)
 		(void)hipFree(ctx->soaCones);
+	if (ctx->soaPosScale)
+		(void)hipFree(ctx->soaPosScale);
+	if (ctx->soaOrient)
+		(void)hipFree(ctx->soaOrient);
+	if (ctx->soaMeshPost)
+		(void)hipFree(ctx->soaMeshPost);
 	if (ctx->timing)
 		(void)hipFree(ctx->timing);
 	delete ctx->prof;
@@ -387,6 +401,59 @@ int nv_upload_meshes(nv_context* ctx, void* stream, const NvMesh* d_meshes, uint
 	return NV_OK;
 }
 
+int nv_upload_draws(nv_context* ctx, void* stream, const NvMeshDraw* d_draws, uint32_t drawCount)
+{
+	if (!ctx || (!d_draws && drawCount))
+		return NV_EINVAL;
+	DeviceGuard guard(ctx->device);
+	if (!d_draws)
+	{
+		ctx->drawsFrom = nullptr;
+		ctx->drawsCount = 0;
+		return NV_OK;
+	}
+	if (drawCount > ctx->drawsCapacity)
+	{
+		hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+		if (e != hipSuccess)
+			return (int)e;
+		if (ctx->soaPosScale)
+			(void)hipFree(ctx->soaPosScale);
+		if (ctx->soaOrient)
+			(void)hipFree(ctx->soaOrient);
+		if (ctx->soaMeshPost)
+			(void)hipFree(ctx->soaMeshPost);
+		ctx->soaPosScale = ctx->soaOrient = nullptr;
+		ctx->soaMeshPost = nullptr;
+		ctx->drawsCapacity = 0;
+		ctx->drawsFrom = nullptr;
+		const size_t cap = (size_t)drawCount + 64;
+		if (hipMalloc(&ctx->soaPosScale, cap * sizeof(float4)) != hipSuccess || hipMalloc(&ctx->soaOrient, cap * sizeof(float4)) != hipSuccess ||
+		    hipMalloc(&ctx->soaMeshPost, cap * sizeof(uint2)) != hipSuccess)
+			return NV_ENOMEM;
+		ctx->drawsCapacity = drawCount;
+	}
+	int rc = nv::launch_draw_split((hipStream_t)stream, d_draws, 0, drawCount, ctx->soaPosScale, ctx->soaOrient, ctx->soaMeshPost);
+	if (rc)
+		return rc;
+	ctx->drawsFrom = d_draws;
+	ctx->drawsCount = drawCount;
+	return NV_OK;
+}
+
+int nv_update_draws(nv_context* ctx, void* stream, const NvMeshDraw* d_draws, uint32_t first, uint32_t count)
+{
+	if (!ctx || !d_draws)
+		return NV_EINVAL;
+	if (!ctx->drawsFrom || d_draws < ctx->drawsFrom || d_draws >= ctx->drawsFrom + ctx->drawsCount || ctx->drawsFrom + (d_draws - ctx->drawsFrom) != d_draws)
+		return NV_OK; // nothing registered for this buffer: the passes read it in place anyway
+	const size_t base = (size_t)(d_draws - ctx->drawsFrom) + first;
+	if (base > ctx->drawsCount || count > ctx->drawsCount - base)
+		return NV_EINVAL;
+	DeviceGuard guard(ctx->device);
+	return nv::launch_draw_split((hipStream_t)stream, ctx->drawsFrom, (uint32_t)base, count, ctx->soaPosScale, ctx->soaOrient, ctx->soaMeshPost);
+}
+
 int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late, int task, const NvMeshDraw* d_draws,
                 const NvMesh* d_meshes, void* d_commands, uint32_t* d_count4, uint32_t* d_drawVisibility,
                 const NvPyramidDesc* pyramid)
@@ -405,6 +472,13 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 	a.cd = *cull;
 	a.pyr = pyramid ? *pyramid : null_pyramid();
 	a.draws = d_draws;
+	// the mirror serves the registered buffer and any sub-range of it that starts on a record (a pass over a shard of the draws)
+	const size_t drawOffset = ctx->drawsFrom && d_draws >= ctx->drawsFrom ? (size_t)(d_draws - ctx->drawsFrom) : ~size_t(0);
+	const bool mirrored = ctx->soaPosScale && drawOffset != ~size_t(0) && ctx->drawsFrom + drawOffset == d_draws &&
+	                      drawOffset + cull->drawCount <= ctx->drawsCount;
+	a.soaPosScale = mirrored ? ctx->soaPosScale + drawOffset : nullptr;
+	a.soaOrient = mirrored ? ctx->soaOrient + drawOffset : nullptr;
+	a.soaMeshPost = mirrored ? ctx->soaMeshPost + drawOffset : nullptr;
 	a.meshes = d_meshes;
 	a.commands = d_commands;
 	a.count4 = d_count4;

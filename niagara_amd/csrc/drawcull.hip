@@ -138,13 +138,26 @@ struct DrawLoad
 	uint32_t oldVis;
 };
 
+// SOA: the three streams of the mirror (a wave reads 1 KiB + 1 KiB + 512 B contiguous); otherwise the 48-B record in
+// place (three 16-B loads at a 48-B stride: every load instruction touches 48 cache lines for 16 of their 64 bytes)
+template <bool SOA>
 NV_DEV DrawLoad load_draw_record(const DrawArgs& a, uint32_t di)
 {
 	DrawLoad l;
-	const float4* p = reinterpret_cast<const float4*>(a.draws + di);
-	l.d0 = p[0];
-	l.d1 = p[1];
-	l.d2 = *reinterpret_cast<const uint4*>(p + 2);
+	if (SOA)
+	{
+		l.d0 = a.soaPosScale[di];
+		l.d1 = a.soaOrient[di];
+		const uint2 mp = a.soaMeshPost[di];
+		l.d2 = make_uint4(mp.x, 0u, mp.y, 0u); // the decision reads meshIndex and postPass only
+	}
+	else
+	{
+		const float4* p = reinterpret_cast<const float4*>(a.draws + di);
+		l.d0 = p[0];
+		l.d1 = p[1];
+		l.d2 = *reinterpret_cast<const uint4*>(p + 2);
+	}
 	l.oldVis = a.dvb[di];
 	return l;
 }
@@ -246,7 +259,7 @@ NV_DEV const char* stage_lod_commit(const DrawArgs& a, const LodStage& st, uint3
 }
 
 // K1
-template <bool LATE, bool TASK, bool MESH_LDS>
+template <bool LATE, bool TASK, bool MESH_LDS, bool SOA>
 __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 {
 	// the Mesh table (center/radius, LOD errors, LOD ranges) is read by every draw: staged once per workgroup when
@@ -279,7 +292,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 	for (int j = 0; j < DC_BATCH; ++j)
 	{
 		const uint32_t c = j * DC_THREADS + tid;
-		ld[j] = load_draw_record(a, first + (c < n ? c : n - 1));
+		ld[j] = load_draw_record<SOA>(a, first + (c < n ? c : n - 1));
 	}
 	const char* meshBase = stage_lod_commit<MESH_LDS>(a, st, s_lodTable);
 
@@ -590,24 +603,34 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 	}
 }
 
-template <bool MESH_LDS>
-static void launch_dc(hipStream_t stream, const DrawArgs& a, int late, int task, uint32_t decideBlocks)
+template <bool MESH_LDS, bool SOA>
+static void launch_decide(hipStream_t stream, const DrawArgs& a, int late, int task, uint32_t decideBlocks)
 {
 	dim3 grid(decideBlocks), block(DC_THREADS);
 	if (late)
 	{
 		if (task)
-			hipLaunchKernelGGL((draw_decide_kernel<true, true, MESH_LDS>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((draw_decide_kernel<true, true, MESH_LDS, SOA>), grid, block, 0, stream, a);
 		else
-			hipLaunchKernelGGL((draw_decide_kernel<true, false, MESH_LDS>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((draw_decide_kernel<true, false, MESH_LDS, SOA>), grid, block, 0, stream, a);
 	}
 	else
 	{
 		if (task)
-			hipLaunchKernelGGL((draw_decide_kernel<false, true, MESH_LDS>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((draw_decide_kernel<false, true, MESH_LDS, SOA>), grid, block, 0, stream, a);
 		else
-			hipLaunchKernelGGL((draw_decide_kernel<false, false, MESH_LDS>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((draw_decide_kernel<false, false, MESH_LDS, SOA>), grid, block, 0, stream, a);
 	}
+}
+
+template <bool MESH_LDS>
+static void launch_dc(hipStream_t stream, const DrawArgs& a, int late, int task, uint32_t decideBlocks)
+{
+	dim3 block(DC_THREADS);
+	if (a.soaPosScale)
+		launch_decide<MESH_LDS, true>(stream, a, late, task, decideBlocks);
+	else
+		launch_decide<MESH_LDS, false>(stream, a, late, task, decideBlocks);
 	const uint32_t t = (a.cd.drawCount + a.scatterTiles - 1) / a.scatterTiles; // scatter_tile_draws, before rounding
 	const dim3 sgrid(a.scatterTiles);
 	if (task)
@@ -637,6 +660,27 @@ int launch_drawcull(hipStream_t stream, const DrawArgs& a, int late, int task)
 		launch_dc<true>(stream, a, late, task, decideBlocks ? decideBlocks : 1u);
 	else
 		launch_dc<false>(stream, a, late, task, decideBlocks ? decideBlocks : 1u);
+	return (int)hipGetLastError();
+}
+
+// SoA mirror of the decision's inputs (nv_upload_draws / nv_update_draws): draws [first, first + count)
+__global__ __launch_bounds__(256) void draw_split_kernel(const NvMeshDraw* __restrict__ draws, uint32_t first, uint32_t count, float4* __restrict__ posScale,
+                                                        float4* __restrict__ orient, uint2* __restrict__ meshPost)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= count)
+		return;
+	const float4* p = reinterpret_cast<const float4*>(draws + first + i);
+	const uint4 ids = *reinterpret_cast<const uint4*>(p + 2);
+	posScale[first + i] = p[0];
+	orient[first + i] = p[1];
+	meshPost[first + i] = make_uint2(ids.x, ids.z);
+}
+
+int launch_draw_split(hipStream_t stream, const NvMeshDraw* draws, uint32_t first, uint32_t count, float4* posScale, float4* orient, uint2* meshPost)
+{
+	if (count)
+		hipLaunchKernelGGL(draw_split_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, draws, first, count, posScale, orient, meshPost);
 	return (int)hipGetLastError();
 }
 

@@ -84,6 +84,14 @@ class Context:
     def upload_meshes(self, mb, count):
         check(lib.nv_upload_meshes(self.h, _stream(), _ptr(mb), count), "nv_upload_meshes")
 
+    def upload_draws(self, db, count):
+        """SoA mirror of the MeshDraw fields a draw decision reads (None, 0 drops the registration)"""
+        check(lib.nv_upload_draws(self.h, _stream(), _ptr(db), count), "nv_upload_draws")
+
+    def update_draws(self, db, first, count):
+        """re-transposes draws [first, first + count) after the caller rewrote them (animation, src/niagara.cpp:1385-1391)"""
+        check(lib.nv_update_draws(self.h, _stream(), _ptr(db), first, count), "nv_update_draws")
+
     def drawcull(self, cull, late, task, db, mb, dcb, dccb, dvb, pyramid=None):
         check(lib.nv_drawcull(self.h, _stream(), C.c_void_p(cull.ctypes.data), int(late), int(task), _ptr(db), _ptr(mb), _ptr(dcb),
                               _ptr(dccb), _ptr(dvb), None if pyramid is None else C.byref(pyramid)), "nv_drawcull")
@@ -175,6 +183,8 @@ class VisibilityPipeline:
         self.pyramid = DepthPyramid(dev, *depth_size)
         if use_soa and self.meshlet_count:
             self.ctx.upload_meshlets(self.mlb, self.meshlet_count)
+        if use_soa and self.draw_count:
+            self.ctx.upload_draws(self.db, self.draw_count)
         self.ctx.upload_meshes(self.mb, self.mesh_count)
 
     # src/niagara.cpp:1530-1574

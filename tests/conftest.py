@@ -36,4 +36,5 @@ def _drop_scene_registrations(request):
         c = request.getfixturevalue("ctx")
         c.upload_meshlets(None, 0)
         c.upload_meshes(None, 0)
+        c.upload_draws(None, 0)
     yield

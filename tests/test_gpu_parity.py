@@ -769,3 +769,62 @@ def test_environment_cannot_change_results(monkeypatch):
             for key in ("count4", "cc4", "cib", "dvb", "mvb"):
                 assert (g[phase][key] == w[phase][key]).all(), (phase, key)
             assert g[phase]["commands"].tobytes() == w[phase]["commands"].tobytes()
+
+
+def test_draw_mirror_update_and_sub_ranges(ctx):
+    """nv_upload_draws / nv_update_draws: the SoA mirror follows rewritten records (animation path,
+    src/niagara.cpp:1385-1391), serves passes over a sub-range of the registered buffer, and an unregistered buffer is read
+    in place — commands, count and drawVisibility are the oracle's in every case"""
+    rng = np.random.default_rng(77)
+    scene = make_scene(seed=61, n_draws=5000, n_meshes=3, lods=4, meshlets_lod0=100)
+    dev = ctx.device
+    draws = scene["draws"].copy()
+    meshes = scene["meshes"]
+    db = P.to_device(draws, dev)
+    mb = P.to_device(meshes, dev)
+    ctx.upload_meshes(mb, len(meshes))
+    ctx.upload_draws(db, len(draws))
+
+    def check(first, count, task, late):
+        cd = scene["cull"].copy()
+        cd["drawCount"] = count
+        sub = draws[first:first + count]
+        cap = task_capacity(dict(scene, draws=sub)) if task else count + 1
+        dt = L.TASKCMD if task else L.DRAWCMD
+        co, c4o = np.zeros(cap, dtype=dt), np.zeros(4, np.uint32)
+        dvo = rng.integers(0, 2, count).astype(np.uint32)
+        dv0 = dvo.copy()
+        pyr = oracle.Pyramid(*scene["viewport"])
+        oracle.depthreduce(scene["depth"], pyr)
+        oracle.drawcull(cd, late, task, sub, meshes, co, c4o, dvo, pyr)
+        gp = P.DepthPyramid(dev, *scene["viewport"])
+        ctx.depthreduce(torch.from_numpy(scene["depth"]).to(dev), scene["viewport"][0], scene["viewport"][1], gp.desc)
+        dcb = torch.zeros(cap * dt.itemsize, dtype=torch.uint8, device=dev)
+        dccb = torch.zeros(4, dtype=torch.int32, device=dev)
+        dvb = torch.from_numpy(dv0.view(np.int32).copy()).to(dev)
+        ctx.drawcull(cd, late, task, db[first * 48:], mb, dcb, dccb, dvb, gp.desc)
+        ctx.status()
+        n = int(c4o[0])
+        assert int(dccb[0].item()) == n and n > 0
+        assert dcb[:n * dt.itemsize].cpu().numpy().tobytes() == co[:n].tobytes()
+        assert (G.host_u32(dvb) == dvo).all()
+
+    for task in (0, 1):
+        for late in (0, 1):
+            check(0, len(draws), task, late)
+            check(1234, 3000, task, late)
+    # animate: rewrite scattered records on the device, re-transpose only those
+    for first, count in ((17, 1), (4000, 250), (4999, 1)):
+        draws["position"][first:first + count] = rng.uniform(-5, 5, (count, 3)).astype(np.float32)
+        draws["scale"][first:first + count] = rng.uniform(0.5, 3, count).astype(np.float32)
+        q = rng.normal(size=(count, 4)).astype(np.float32)
+        draws["orientation"][first:first + count] = q / np.linalg.norm(q, axis=1, keepdims=True)
+        db[first * 48:(first + count) * 48].copy_(P.to_device(draws[first:first + count], dev))
+        ctx.update_draws(db, first, count)
+    check(0, len(draws), 0, 0)
+    check(3990, 1010, 1, 1)
+    # a stale mirror would show: rewrite without updating, then drop the registration (records read in place)
+    draws["position"][100:200] += np.float32(3.0)
+    db[100 * 48:200 * 48].copy_(P.to_device(draws[100:200], dev))
+    ctx.upload_draws(None, 0)
+    check(0, len(draws), 0, 1)

@@ -40,7 +40,7 @@ def timed(ctx, fn, iters, slot):
     return wall * 1e6, ms / max(1, n) * 1e3, prof
 
 
-def config2(ctx, iters, n_draws=1_000_000, copies=6):
+def config2(ctx, iters, n_draws=1_000_000, copies=6, soa=True):
     """1 M MeshDraw spheres, frustum cull + LOD + ordered compaction: drawcull<LATE=0,TASK=0>"""
     dev = ctx.device
     meshes, _ = synth.make_meshes(1, 8, 1 << 12)
@@ -51,7 +51,11 @@ def config2(ctx, iters, n_draws=1_000_000, copies=6):
     cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, lodEnabled=1)
     mb = P.to_device(meshes, dev)
     ctx.upload_meshes(mb, len(meshes))
-    dbs = [P.to_device(draws, dev) for _ in range(copies)]
+    one = P.to_device(draws, dev)
+    db_all = torch.cat([one] * copies)  # `copies` shards of one buffer, rotated: every pass streams from HBM
+    dbs = [db_all[c * one.numel():(c + 1) * one.numel()] for c in range(copies)]
+    if soa:
+        ctx.upload_draws(db_all, copies * n_draws)
     dvbs = [torch.ones(n_draws, dtype=torch.int32, device=dev) for _ in range(copies)]
     dcb = torch.zeros(n_draws * 24 + 64, dtype=torch.uint8, device=dev)
     dccb = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -68,7 +72,7 @@ def config2(ctx, iters, n_draws=1_000_000, copies=6):
     same = (v == int(c4o[0]) and dcb[:v * 24].cpu().numpy().tobytes() == co[:v].tobytes()
             and (dvbs[(iters - 1) % copies].cpu().numpy().view(np.uint32) == dvo).all())
     algo = n_draws * 52 + v * 24 + 208 + 4
-    return dict(config="2: 1M draws, drawcull<0,0>", draws=n_draws, visible=v, kernel_us=k_us, step_us=wall, draws_per_s=n_draws / (k_us * 1e-6),
+    return dict(config="2: 1M draws, drawcull<0,0>" + ("" if soa else " (AoS records in place)"), draws=n_draws, visible=v, kernel_us=k_us, step_us=wall, draws_per_s=n_draws / (k_us * 1e-6),
                 algorithmic_bytes=algo, achieved_GBs=algo / k_us / 1e3, frac=algo / k_us / 1e3 / HBM, parity=verdict(same))
 
 
@@ -86,7 +90,10 @@ def config2_late(ctx, iters, n_draws=1_000_000, copies=6, size=2048):
     cd = host.build_cull_data(draw_count=n_draws, viewport=(size, size), pyramid=(pyr.width, pyr.height), cullingEnabled=1, lodEnabled=1, occlusionEnabled=1)
     mb = P.to_device(meshes, dev)
     ctx.upload_meshes(mb, len(meshes))
-    dbs = [P.to_device(draws, dev) for _ in range(copies)]
+    one = P.to_device(draws, dev)
+    db_all = torch.cat([one] * copies)
+    dbs = [db_all[c * one.numel():(c + 1) * one.numel()] for c in range(copies)]
+    ctx.upload_draws(db_all, copies * n_draws)
     rng = np.random.default_rng(3)
     dvb0 = torch.from_numpy(rng.integers(0, 2, n_draws).astype(np.int32)).to(dev)
     dvbs = [dvb0.clone() for _ in range(copies)]
@@ -296,7 +303,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     ctx = P.Context(0)
-    runs = {"2": lambda: config2(ctx, a.iters), "2l": lambda: config2_late(ctx, a.iters), "3b": lambda: config3b(ctx, a.iters), "3b_fused": lambda: config3b(P.Context(0), a.iters, fused=True), "4": lambda: config4(ctx, a.iters),
+    runs = {"2": lambda: config2(ctx, a.iters), "2_aos": lambda: config2(P.Context(0), a.iters, soa=False), "2l": lambda: config2_late(ctx, a.iters), "3b": lambda: config3b(ctx, a.iters), "3b_fused": lambda: config3b(P.Context(0), a.iters, fused=True), "4": lambda: config4(ctx, a.iters),
             "4b": lambda: config4(ctx, a.iters, size=1024), "n4": lambda: config_n4(ctx, a.iters),
             "big": lambda: cluster_config(ctx, max(5, a.iters // 3), "3A x10 (SoA mirror)"),
             "big_aos": lambda: cluster_config(P.Context(0), max(5, a.iters // 3), "3A x10 (AoS in place)", aos=True),
