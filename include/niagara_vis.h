@@ -217,15 +217,19 @@ int nv_upload_meshlets(nv_context* ctx, void* stream, const NvMeshlet* d_meshlet
  * unregistered or larger tables are gathered from global memory.  The table is only read at pass time. */
 int nv_upload_meshes(nv_context* ctx, void* stream, const NvMesh* d_meshes, uint32_t meshCount);
 
-/* Upload hook next to uploadBuffer(db) (src/niagara.cpp:1052): builds the library-owned SoA mirror of what a draw
- * decision reads of a MeshDraw — {position, scale} and {orientation} as two 16-B streams, {meshIndex, postPass} as an
- * 8-B stream — so that the decide kernel of nv_drawcull reads three perfectly coalesced streams (40 B per draw) instead
- * of 48-B-stride records.  Used when nv_drawcull's d_draws is the pointer registered here or a record inside that
- * buffer with drawCount records behind it (a pass over a shard of the draws); the 48-B AoS records are read in place
- * otherwise (same results).  Same registration contract as nv_upload_meshlets ((NULL, 0) drops it).
- * nv_update_draws re-transposes [first, first + count) after the caller rewrote those records — the animation path,
+/* Upload hook next to uploadBuffer(db) (src/niagara.cpp:1052): builds the library-owned mirror of what a draw decision
+ * reads.  Everything drawcull.comp.glsl:73-75 computes BEFORE the view transform is view-independent — the world-space
+ * sphere {rotateQuat(mesh.center, orientation) * scale + position, mesh.radius * scale} — so it is evaluated once here, in
+ * the reference's operation order (the intermediates are bit-identical), and stored as a 16-B stream next to
+ * {scale, meshIndex} (8 B) and postPass (4 B).  The decide kernel of nv_drawcull then reads three coalesced streams
+ * (28 B per draw instead of 48-B-stride records plus a Mesh gather) and is left with the view transform and the tests.
+ * Used when nv_drawcull's d_draws is the pointer registered here or a record inside that buffer with drawCount records
+ * behind it (a pass over a shard of the draws) AND its d_meshes is the table given here; the 48-B AoS records are read
+ * in place otherwise (same results).  Same registration contract as nv_upload_meshlets ((NULL, 0, NULL) drops it); call
+ * again when the Mesh table's bounds change.
+ * nv_update_draws re-evaluates [first, first + count) after the caller rewrote those records — the animation path,
  * src/niagara.cpp:1385-1391, which memcpy()s single MeshDraws into the mapped draw buffer every frame. */
-int nv_upload_draws(nv_context* ctx, void* stream, const NvMeshDraw* d_draws, uint32_t drawCount);
+int nv_upload_draws(nv_context* ctx, void* stream, const NvMeshDraw* d_draws, uint32_t drawCount, const NvMesh* d_meshes);
 int nv_update_draws(nv_context* ctx, void* stream, const NvMeshDraw* d_draws, uint32_t first, uint32_t count);
 
 /* ---- the passes ---- */

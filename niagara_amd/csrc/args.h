@@ -112,10 +112,10 @@ struct DrawArgs
 	NvCullData cd;
 	NvPyramidDesc pyr;
 	const NvMeshDraw* draws;
-	// SoA mirror of the decision's inputs (nv_upload_draws; nullptr: read the AoS records)
-	const float4* __restrict__ soaPosScale; // position.xyz, scale
-	const float4* __restrict__ soaOrient;   // orientation.xyzw
-	const uint2* __restrict__ soaMeshPost;  // meshIndex, postPass
+	// mirror of the decision's inputs (nv_upload_draws; nullptr: read the AoS records)
+	const float4* __restrict__ soaWorld;      // world-space sphere: rotateQuat(center, q) * scale + position, radius * scale
+	const uint2* __restrict__ soaScaleMesh;   // scale (fp32 bits), meshIndex
+	const uint32_t* __restrict__ soaPostPass; // postPass
 	const NvMesh* meshes;
 	void* commands;
 	uint32_t* count4;

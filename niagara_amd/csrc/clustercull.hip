@@ -1438,13 +1438,17 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 
 // K2: contiguous ranges, ordered scatter.  Tile t's append base = count word + survivors of tiles < t, which the cull
 // kernel has already accumulated per tile: no workgroup waits on another, the kernel is a handful of parallel loads,
-// one scan and the stores.  Each lane owns 4 consecutive commands (32 B of ballots, two 16-B loads).
-template <int DUMMY>
-__global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs a)
+// one scan and the stores.  A step covers 1024 commands: 16 waves with one command per lane (the usual shape: the stores
+// are emitted one owning command at a time per wave, so with one wave per SIMD — 4 waves x 4 commands per lane — a
+// workgroup spent 3.7 of its 8 us walking ~25 owners per wave at single-wave issue latency), or 4 waves with four.
+template <int SC_WAVES>
+__global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterArgs a)
 {
-	__shared__ uint32_t s_part[CC_WAVES];
-	__shared__ uint32_t s_sum[CC_WAVES];
-	constexpr uint32_t PER_LANE = 4, STEP = CC_THREADS * PER_LANE;
+	constexpr uint32_t SC_THREADS = SC_WAVES * 64;
+	__shared__ uint32_t s_part[SC_WAVES];
+	__shared__ uint32_t s_sum[SC_WAVES];
+	constexpr uint32_t STEP = 1024, PER_LANE = STEP / SC_THREADS;
+	constexpr int TILE_LOADS = (int)((CC_MAX_SCATTER_TILES + SC_THREADS - 1) / SC_THREADS); // tile counters per thread and bank
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
@@ -1460,11 +1464,11 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs
 	// Both banks of tile counts are read speculatively so that no load waits for the parity word.
 	const uint32_t k2parity = load_uniform_u32(&a.tileCounts->k2parity);
 	const uint32_t base0 = load_uniform_u32(&a.tileCounts->base);
-	uint32_t cnt0[2] = { 0, 0 }, cnt1[2] = { 0, 0 }; // this thread's tiles tid and tid + 256, per bank
+	uint32_t cnt0[TILE_LOADS] = {}, cnt1[TILE_LOADS] = {}; // this thread's tiles tid, tid + SC_THREADS, ..., per bank
 #pragma unroll
-	for (int j = 0; j < 2; ++j)
+	for (int j = 0; j < TILE_LOADS; ++j)
 	{
-		const uint32_t i = j * CC_THREADS + tid;
+		const uint32_t i = j * SC_THREADS + tid;
 		if (i < numTiles)
 		{
 			cnt0[j] = a.tileCounts->counts[0][i * CC_COUNT_STRIDE];
@@ -1476,6 +1480,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs
 	// first step's ballots (the only step for the usual T <= 1024); the ballot array is padded, so the 16-B loads of
 	// a partially valid quad stay in range and are masked afterwards
 	uint64_t m4[PER_LANE];
+	if (PER_LANE == 4)
 	{
 		const uint32_t c = tid * PER_LANE;
 		const ulonglong2* src = reinterpret_cast<const ulonglong2*>(a.masks + first + c);
@@ -1486,15 +1491,21 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs
 			hi = src[1];
 		}
 		m4[0] = c + 0 < n ? lo.x : 0ull;
-		m4[1] = c + 1 < n ? lo.y : 0ull;
-		m4[2] = c + 2 < n ? hi.x : 0ull;
-		m4[3] = c + 3 < n ? hi.y : 0ull;
+		m4[PER_LANE > 1 ? 1 : 0] = c + 1 < n ? lo.y : 0ull;
+		m4[PER_LANE > 2 ? 2 : 0] = c + 2 < n ? hi.x : 0ull;
+		m4[PER_LANE > 3 ? 3 : 0] = c + 3 < n ? hi.y : 0ull;
+	}
+	else
+	{
+#pragma unroll
+		for (uint32_t j = 0; j < PER_LANE; ++j)
+			m4[j] = tid * PER_LANE + j < n ? a.masks[first + tid * PER_LANE + j] : 0ull;
 	}
 
 	const uint32_t bank = k2parity & 1u;
 	// every workgroup clears its entries of the other bank for the next pass; one thread flips the parity the next
 	// cull kernel will read (this pass reads k2parity only)
-	for (uint32_t i = tile * CC_THREADS + tid; i < CC_MAX_SCATTER_TILES; i += gridDim.x * CC_THREADS)
+	for (uint32_t i = tile * SC_THREADS + tid; i < CC_MAX_SCATTER_TILES; i += gridDim.x * SC_THREADS)
 		a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE] = 0;
 	if (tile == 0 && tid == 0)
 	{
@@ -1527,9 +1538,9 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs
 
 	uint32_t before = 0, all = 0;
 #pragma unroll
-	for (int j = 0; j < 2; ++j)
+	for (int j = 0; j < TILE_LOADS; ++j)
 	{
-		const uint32_t i = j * CC_THREADS + tid;
+		const uint32_t i = j * SC_THREADS + tid;
 		const uint32_t v = bank ? cnt1[j] : cnt0[j];
 		all += v;
 		before += i < tile ? v : 0u;
@@ -1543,7 +1554,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs
 	__syncthreads();
 	uint32_t running = base0, total = base0;
 #pragma unroll
-	for (int w = 0; w < CC_WAVES; ++w)
+	for (int w = 0; w < SC_WAVES; ++w)
 	{
 		running += s_part[w];
 		total += s_sum[w];
@@ -1607,7 +1618,7 @@ __global__ __launch_bounds__(CC_THREADS) void cluster_scatter_kernel(ClusterArgs
 		__syncthreads();
 		uint32_t excl = running + incl - mine;
 #pragma unroll
-		for (int w = 0; w < CC_WAVES; ++w)
+		for (int w = 0; w < SC_WAVES; ++w)
 		{
 			uint32_t p = s_part[w];
 			excl += w < (int)wave ? p : 0u;
@@ -1786,7 +1797,7 @@ bool clustercull_prefers_shallow(uint32_t previousCommandCount) { return previou
 // one workgroup per scatter tile (context.hip: one per CU, at most CC_MAX_SCATTER_TILES); no workgroup waits on another
 int launch_cluster_scatter(hipStream_t stream, const ClusterArgs& a, uint32_t scatterBlocks)
 {
-	hipLaunchKernelGGL((cluster_scatter_kernel<0>), dim3(scatterBlocks), dim3(CC_THREADS), 0, stream, a);
+	hipLaunchKernelGGL((cluster_scatter_kernel<16>), dim3(scatterBlocks), dim3(16 * 64), 0, stream, a);
 	return (int)hipGetLastError();
 }
 

@@ -25,7 +25,7 @@ int launch_taskcull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_
 int launch_probe(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
 int launch_soa_split(hipStream_t, const NvMeshlet*, uint32_t count, uint32_t padded, uint2* bounds, uint32_t* cones);
 int launch_drawcull(hipStream_t, const DrawArgs&, int late, int task);
-int launch_draw_split(hipStream_t, const NvMeshDraw*, uint32_t first, uint32_t count, float4* posScale, float4* orient, uint2* meshPost);
+int launch_draw_split(hipStream_t, const NvMeshDraw*, const NvMesh*, uint32_t first, uint32_t count, float4* world, uint2* scaleMesh, uint32_t* postPass);
 size_t drawcull_result_bytes(uint32_t drawCount);
 int launch_tasksubmit(hipStream_t, uint32_t* count4, NvMeshTaskCommand* commands);
 int launch_reset_count(hipStream_t, uint32_t* a, uint32_t* b);
@@ -63,10 +63,11 @@ struct nv_context
 	uint32_t soaCapacity;
 	// SoA mirror of the MeshDraw fields a draw decision reads (nv_upload_draws)
 	const NvMeshDraw* drawsFrom;
+	const NvMesh* drawsMeshes; // the Mesh table whose centres / radii are folded into the mirror
 	uint32_t drawsCount;
-	float4* soaPosScale;
-	float4* soaOrient;
-	uint2* soaMeshPost;
+	float4* soaWorld;
+	uint2* soaScaleMesh;
+	uint32_t* soaPostPass;
 	uint32_t drawsCapacity;
 	// Mesh table registered by nv_upload_meshes (pointer identity + count): lets drawcull stage it in LDS
 	const NvMesh* meshesFrom;
@@ -261,12 +262,12 @@ void nv_destroy(nv_context* ctx)
 		(void)hipFree(ctx->soaBounds);
 	if (ctx->soaCones)
 		(void)hipFree(ctx->soaCones);
-	if (ctx->soaPosScale)
-		(void)hipFree(ctx->soaPosScale);
-	if (ctx->soaOrient)
-		(void)hipFree(ctx->soaOrient);
-	if (ctx->soaMeshPost)
-		(void)hipFree(ctx->soaMeshPost);
+	if (ctx->soaWorld)
+		(void)hipFree(ctx->soaWorld);
+	if (ctx->soaScaleMesh)
+		(void)hipFree(ctx->soaScaleMesh);
+	if (ctx->soaPostPass)
+		(void)hipFree(ctx->soaPostPass);
 	if (ctx->timing)
 		(void)hipFree(ctx->timing);
 	delete ctx->prof;
@@ -401,14 +402,15 @@ int nv_upload_meshes(nv_context* ctx, void* stream, const NvMesh* d_meshes, uint
 	return NV_OK;
 }
 
-int nv_upload_draws(nv_context* ctx, void* stream, const NvMeshDraw* d_draws, uint32_t drawCount)
+int nv_upload_draws(nv_context* ctx, void* stream, const NvMeshDraw* d_draws, uint32_t drawCount, const NvMesh* d_meshes)
 {
-	if (!ctx || (!d_draws && drawCount))
+	if (!ctx || (!d_draws && drawCount) || (d_draws && !d_meshes))
 		return NV_EINVAL;
 	DeviceGuard guard(ctx->device);
 	if (!d_draws)
 	{
 		ctx->drawsFrom = nullptr;
+		ctx->drawsMeshes = nullptr;
 		ctx->drawsCount = 0;
 		return NV_OK;
 	}
@@ -417,26 +419,28 @@ int nv_upload_draws(nv_context* ctx, void* stream, const NvMeshDraw* d_draws, ui
 		hipError_t e = hipStreamSynchronize((hipStream_t)stream);
 		if (e != hipSuccess)
 			return (int)e;
-		if (ctx->soaPosScale)
-			(void)hipFree(ctx->soaPosScale);
-		if (ctx->soaOrient)
-			(void)hipFree(ctx->soaOrient);
-		if (ctx->soaMeshPost)
-			(void)hipFree(ctx->soaMeshPost);
-		ctx->soaPosScale = ctx->soaOrient = nullptr;
-		ctx->soaMeshPost = nullptr;
+		if (ctx->soaWorld)
+			(void)hipFree(ctx->soaWorld);
+		if (ctx->soaScaleMesh)
+			(void)hipFree(ctx->soaScaleMesh);
+		if (ctx->soaPostPass)
+			(void)hipFree(ctx->soaPostPass);
+		ctx->soaWorld = nullptr;
+		ctx->soaScaleMesh = nullptr;
+		ctx->soaPostPass = nullptr;
 		ctx->drawsCapacity = 0;
 		ctx->drawsFrom = nullptr;
 		const size_t cap = (size_t)drawCount + 64;
-		if (hipMalloc(&ctx->soaPosScale, cap * sizeof(float4)) != hipSuccess || hipMalloc(&ctx->soaOrient, cap * sizeof(float4)) != hipSuccess ||
-		    hipMalloc(&ctx->soaMeshPost, cap * sizeof(uint2)) != hipSuccess)
+		if (hipMalloc(&ctx->soaWorld, cap * sizeof(float4)) != hipSuccess || hipMalloc(&ctx->soaScaleMesh, cap * sizeof(uint2)) != hipSuccess ||
+		    hipMalloc(&ctx->soaPostPass, cap * sizeof(uint32_t)) != hipSuccess)
 			return NV_ENOMEM;
 		ctx->drawsCapacity = drawCount;
 	}
-	int rc = nv::launch_draw_split((hipStream_t)stream, d_draws, 0, drawCount, ctx->soaPosScale, ctx->soaOrient, ctx->soaMeshPost);
+	int rc = nv::launch_draw_split((hipStream_t)stream, d_draws, d_meshes, 0, drawCount, ctx->soaWorld, ctx->soaScaleMesh, ctx->soaPostPass);
 	if (rc)
 		return rc;
 	ctx->drawsFrom = d_draws;
+	ctx->drawsMeshes = d_meshes;
 	ctx->drawsCount = drawCount;
 	return NV_OK;
 }
@@ -451,7 +455,7 @@ int nv_update_draws(nv_context* ctx, void* stream, const NvMeshDraw* d_draws, ui
 	if (base > ctx->drawsCount || count > ctx->drawsCount - base)
 		return NV_EINVAL;
 	DeviceGuard guard(ctx->device);
-	return nv::launch_draw_split((hipStream_t)stream, ctx->drawsFrom, (uint32_t)base, count, ctx->soaPosScale, ctx->soaOrient, ctx->soaMeshPost);
+	return nv::launch_draw_split((hipStream_t)stream, ctx->drawsFrom, ctx->drawsMeshes, (uint32_t)base, count, ctx->soaWorld, ctx->soaScaleMesh, ctx->soaPostPass);
 }
 
 int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late, int task, const NvMeshDraw* d_draws,
@@ -474,11 +478,11 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 	a.draws = d_draws;
 	// the mirror serves the registered buffer and any sub-range of it that starts on a record (a pass over a shard of the draws)
 	const size_t drawOffset = ctx->drawsFrom && d_draws >= ctx->drawsFrom ? (size_t)(d_draws - ctx->drawsFrom) : ~size_t(0);
-	const bool mirrored = ctx->soaPosScale && drawOffset != ~size_t(0) && ctx->drawsFrom + drawOffset == d_draws &&
-	                      drawOffset + cull->drawCount <= ctx->drawsCount;
-	a.soaPosScale = mirrored ? ctx->soaPosScale + drawOffset : nullptr;
-	a.soaOrient = mirrored ? ctx->soaOrient + drawOffset : nullptr;
-	a.soaMeshPost = mirrored ? ctx->soaMeshPost + drawOffset : nullptr;
+	const bool mirrored = ctx->soaWorld && drawOffset != ~size_t(0) && ctx->drawsFrom + drawOffset == d_draws &&
+	                      drawOffset + cull->drawCount <= ctx->drawsCount && ctx->drawsMeshes == d_meshes; // (the mirror folds THAT table's bounds in)
+	a.soaWorld = mirrored ? ctx->soaWorld + drawOffset : nullptr;
+	a.soaScaleMesh = mirrored ? ctx->soaScaleMesh + drawOffset : nullptr;
+	a.soaPostPass = mirrored ? ctx->soaPostPass + drawOffset : nullptr;
 	a.meshes = d_meshes;
 	a.commands = d_commands;
 	a.count4 = d_count4;

@@ -24,7 +24,7 @@ namespace nv
 
 constexpr int DC_WAVES = 4;
 constexpr int DC_THREADS = DC_WAVES * 64;
-constexpr int DC_BATCH = 4;                          // draws per lane of the decide kernel
+constexpr int DC_BATCH = 2;                          // draws per lane of the decide kernel
 constexpr uint32_t DC_TILE = DC_THREADS * DC_BATCH;   // draws per workgroup of the decide kernel
 constexpr uint32_t DC_MESH_LDS = 64;  // meshes staged in LDS (13 KiB) when the table is registered and small enough
 
@@ -59,7 +59,10 @@ NV_DEV uint32_t lod_table_source(uint32_t k)
 }
 
 // drawcull.comp.glsl:56-118 + :154-155 for one draw.  COMPACT: meshBase is the LDS table above, else the NvMesh array.
-template <bool LATE, bool TASK, bool COMPACT>
+// WORLD: the draw comes from the mirror of nv_upload_draws — d0 = the world-space sphere {rotateQuat(center, q) * scale +
+// position, radius * scale}, i.e. the view-independent prefix of drawcull.comp.glsl:73-75 evaluated once at upload in the
+// reference's own operation order (bit-identical intermediates), d1.x = scale; only the view transform is left per pass.
+template <bool LATE, bool TASK, bool COMPACT, bool WORLD>
 NV_DEV DrawResult decide_draw(const DrawArgs& a, const char* meshBase, uint32_t di, const float4& d0, const float4& d1, const uint4& d2, uint32_t oldVis)
 {
 	const NvCullData& cd = a.cd;
@@ -72,11 +75,22 @@ NV_DEV DrawResult decide_draw(const DrawArgs& a, const char* meshBase, uint32_t 
 
 	const uint32_t meshIndex = d2.x;
 	const char* mesh = meshBase + (size_t)meshIndex * (COMPACT ? DC_LOD_WORDS * 4u : sizeof(NvMesh));
-	const float4 cr = *reinterpret_cast<const float4*>(mesh); // center.xyz, radius
-
-	f3 q = { d1.x, d1.y, d1.z };
-	f3 c = sphere_center(cd, f3{ cr.x, cr.y, cr.z }, q, d1.w, d0.w, f3{ d0.x, d0.y, d0.z });
-	float radius = cr.w * d0.w;
+	f3 c;
+	float radius, scale;
+	if (WORLD)
+	{
+		c = view_point(cd.view, f3{ d0.x, d0.y, d0.z });
+		radius = d0.w;
+		scale = d1.x;
+	}
+	else
+	{
+		const float4 cr = *reinterpret_cast<const float4*>(mesh); // center.xyz, radius
+		f3 q = { d1.x, d1.y, d1.z };
+		c = sphere_center(cd, f3{ cr.x, cr.y, cr.z }, q, d1.w, d0.w, f3{ d0.x, d0.y, d0.z });
+		radius = cr.w * d0.w;
+		scale = d0.w;
+	}
 
 	bool visible = frustum_test(cd, c, radius);
 	visible = visible || cd.cullingEnabled == 0;
@@ -91,7 +105,7 @@ NV_DEV DrawResult decide_draw(const DrawArgs& a, const char* meshBase, uint32_t 
 		if (cd.lodEnabled == 1 && !NV_DBG(a, 2u))
 		{
 			float distance = gl_max(length3(c) - radius, 0.0f);
-			float threshold = distance * cd.lodTarget / d0.w;
+			float threshold = distance * cd.lodTarget / scale;
 			// drawcull.comp.glsl:108-110: the last LOD below the threshold.  All eight slots exist in the struct, so the
 			// errors are fetched together and the loop bound becomes part of the condition.
 			uint32_t lodCount;
@@ -138,18 +152,18 @@ struct DrawLoad
 	uint32_t oldVis;
 };
 
-// SOA: the three streams of the mirror (a wave reads 1 KiB + 1 KiB + 512 B contiguous); otherwise the 48-B record in
-// place (three 16-B loads at a 48-B stride: every load instruction touches 48 cache lines for 16 of their 64 bytes)
+// SOA: the streams of the mirror (a wave reads 1 KiB + 512 B + 256 B contiguous); otherwise the 48-B record in place
+// (three 16-B loads at a 48-B stride)
 template <bool SOA>
 NV_DEV DrawLoad load_draw_record(const DrawArgs& a, uint32_t di)
 {
 	DrawLoad l;
 	if (SOA)
 	{
-		l.d0 = a.soaPosScale[di];
-		l.d1 = a.soaOrient[di];
-		const uint2 mp = a.soaMeshPost[di];
-		l.d2 = make_uint4(mp.x, 0u, mp.y, 0u); // the decision reads meshIndex and postPass only
+		l.d0 = a.soaWorld[di];
+		const uint2 sm = a.soaScaleMesh[di];
+		l.d1 = make_float4(__uint_as_float(sm.x), 0.0f, 0.0f, 0.0f);
+		l.d2 = make_uint4(sm.y, 0u, a.soaPostPass[di], 0u); // the decision reads meshIndex and postPass only
 	}
 	else
 	{
@@ -309,7 +323,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 			if (NV_DBG(a, 1u)) // experiments: loads only
 				res.lodWord = __float_as_uint(ld[j].d0.x + ld[j].d1.x) + ld[j].d2.x + ld[j].oldVis == 12345u ? 0x100u : 0u;
 			else
-				res = decide_draw<LATE, TASK, MESH_LDS>(a, meshBase, first + c, ld[j].d0, ld[j].d1, ld[j].d2, ld[j].oldVis);
+				res = decide_draw<LATE, TASK, MESH_LDS, SOA>(a, meshBase, first + c, ld[j].d0, ld[j].d1, ld[j].d2, ld[j].oldVis);
 			a.results[first + c] = (uint8_t)((res.lodWord & 7u) | ((res.lodWord >> 8 & 1u) << 3) | ((ld[j].oldVis != 0 ? 1u : 0u) << 4));
 			count = res.count;
 		}
@@ -627,7 +641,7 @@ template <bool MESH_LDS>
 static void launch_dc(hipStream_t stream, const DrawArgs& a, int late, int task, uint32_t decideBlocks)
 {
 	dim3 block(DC_THREADS);
-	if (a.soaPosScale)
+	if (a.soaWorld)
 		launch_decide<MESH_LDS, true>(stream, a, late, task, decideBlocks);
 	else
 		launch_decide<MESH_LDS, false>(stream, a, late, task, decideBlocks);
@@ -663,24 +677,31 @@ int launch_drawcull(hipStream_t stream, const DrawArgs& a, int late, int task)
 	return (int)hipGetLastError();
 }
 
-// SoA mirror of the decision's inputs (nv_upload_draws / nv_update_draws): draws [first, first + count)
-__global__ __launch_bounds__(256) void draw_split_kernel(const NvMeshDraw* __restrict__ draws, uint32_t first, uint32_t count, float4* __restrict__ posScale,
-                                                        float4* __restrict__ orient, uint2* __restrict__ meshPost)
+// Mirror of the decision's inputs (nv_upload_draws / nv_update_draws), draws [first, first + count): the world-space
+// sphere — drawcull.comp.glsl:73-75 up to the view transform, in the reference's operation order — plus {scale, meshIndex}
+// and postPass as their own streams.
+__global__ __launch_bounds__(256) void draw_split_kernel(const NvMeshDraw* __restrict__ draws, const NvMesh* __restrict__ meshes, uint32_t first, uint32_t count,
+                                                        float4* __restrict__ world, uint2* __restrict__ scaleMesh, uint32_t* __restrict__ postPass)
 {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= count)
 		return;
 	const float4* p = reinterpret_cast<const float4*>(draws + first + i);
+	const float4 d0 = p[0], d1 = p[1];
 	const uint4 ids = *reinterpret_cast<const uint4*>(p + 2);
-	posScale[first + i] = p[0];
-	orient[first + i] = p[1];
-	meshPost[first + i] = make_uint2(ids.x, ids.z);
+	const float4 cr = *reinterpret_cast<const float4*>(meshes + ids.x); // center.xyz, radius
+	const f3 r = rotate_quat(f3{ cr.x, cr.y, cr.z }, f3{ d1.x, d1.y, d1.z }, d1.w);
+	// the same three statements as sphere_center() (cullmath.h) before view_point()
+	world[first + i] = make_float4(r.x * d0.w + d0.x, r.y * d0.w + d0.y, r.z * d0.w + d0.z, cr.w * d0.w);
+	scaleMesh[first + i] = make_uint2(__float_as_uint(d0.w), ids.x);
+	postPass[first + i] = ids.z;
 }
 
-int launch_draw_split(hipStream_t stream, const NvMeshDraw* draws, uint32_t first, uint32_t count, float4* posScale, float4* orient, uint2* meshPost)
+int launch_draw_split(hipStream_t stream, const NvMeshDraw* draws, const NvMesh* meshes, uint32_t first, uint32_t count, float4* world, uint2* scaleMesh,
+                      uint32_t* postPass)
 {
 	if (count)
-		hipLaunchKernelGGL(draw_split_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, draws, first, count, posScale, orient, meshPost);
+		hipLaunchKernelGGL(draw_split_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, draws, meshes, first, count, world, scaleMesh, postPass);
 	return (int)hipGetLastError();
 }
 

@@ -84,9 +84,10 @@ class Context:
     def upload_meshes(self, mb, count):
         check(lib.nv_upload_meshes(self.h, _stream(), _ptr(mb), count), "nv_upload_meshes")
 
-    def upload_draws(self, db, count):
-        """SoA mirror of the MeshDraw fields a draw decision reads (None, 0 drops the registration)"""
-        check(lib.nv_upload_draws(self.h, _stream(), _ptr(db), count), "nv_upload_draws")
+    def upload_draws(self, db, count, mb=None):
+        """mirror of what a draw decision reads: world-space spheres (mesh bounds of table `mb` folded in), scale, meshIndex,
+        postPass (None, 0 drops the registration)"""
+        check(lib.nv_upload_draws(self.h, _stream(), _ptr(db), count, _ptr(mb)), "nv_upload_draws")
 
     def update_draws(self, db, first, count):
         """re-transposes draws [first, first + count) after the caller rewrote them (animation, src/niagara.cpp:1385-1391)"""
@@ -184,7 +185,7 @@ class VisibilityPipeline:
         if use_soa and self.meshlet_count:
             self.ctx.upload_meshlets(self.mlb, self.meshlet_count)
         if use_soa and self.draw_count:
-            self.ctx.upload_draws(self.db, self.draw_count)
+            self.ctx.upload_draws(self.db, self.draw_count, self.mb)
         self.ctx.upload_meshes(self.mb, self.mesh_count)
 
     # src/niagara.cpp:1530-1574

@@ -25,7 +25,7 @@ class GpuScene:
         if use_soa:
             ctx.upload_meshlets(self.mlb, len(scene["meshlets"]))
             ctx.upload_meshes(self.mb, len(scene["meshes"]))  # Mesh table staged in LDS; the other variant gathers it
-            ctx.upload_draws(self.db, len(scene["draws"]))    # decision inputs from the SoA mirror; the other variant reads the records
+            ctx.upload_draws(self.db, len(scene["draws"]), self.mb)    # decision inputs from the SoA mirror; the other variant reads the records
         else:
             # the registrations are by device pointer: a context shared between scenes must drop the previous scene's, or a
             # reused allocation would be taken for the buffer the mirror was built from

@@ -783,7 +783,7 @@ def test_draw_mirror_update_and_sub_ranges(ctx):
     db = P.to_device(draws, dev)
     mb = P.to_device(meshes, dev)
     ctx.upload_meshes(mb, len(meshes))
-    ctx.upload_draws(db, len(draws))
+    ctx.upload_draws(db, len(draws), mb)
 
     def check(first, count, task, late):
         cd = scene["cull"].copy()

@@ -55,7 +55,7 @@ def config2(ctx, iters, n_draws=1_000_000, copies=6, soa=True):
     db_all = torch.cat([one] * copies)  # `copies` shards of one buffer, rotated: every pass streams from HBM
     dbs = [db_all[c * one.numel():(c + 1) * one.numel()] for c in range(copies)]
     if soa:
-        ctx.upload_draws(db_all, copies * n_draws)
+        ctx.upload_draws(db_all, copies * n_draws, mb)
     dvbs = [torch.ones(n_draws, dtype=torch.int32, device=dev) for _ in range(copies)]
     dcb = torch.zeros(n_draws * 24 + 64, dtype=torch.uint8, device=dev)
     dccb = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -93,7 +93,7 @@ def config2_late(ctx, iters, n_draws=1_000_000, copies=6, size=2048):
     one = P.to_device(draws, dev)
     db_all = torch.cat([one] * copies)
     dbs = [db_all[c * one.numel():(c + 1) * one.numel()] for c in range(copies)]
-    ctx.upload_draws(db_all, copies * n_draws)
+    ctx.upload_draws(db_all, copies * n_draws, mb)
     rng = np.random.default_rng(3)
     dvb0 = torch.from_numpy(rng.integers(0, 2, n_draws).astype(np.int32)).to(dev)
     dvbs = [dvb0.clone() for _ in range(copies)]
