@@ -315,6 +315,18 @@ typedef struct NvTriangleMask
 	uint32_t keep[3]; /* MESH_MAXTRI = 96 (src/config.h:15) */
 	uint32_t counts;
 } NvTriangleMask;
+/* SURVEY.md §8(f) N2 — meshlet bounds (src/scene.cpp:69-85: meshopt_computeMeshletBounds, meshopt_quantizeHalf,
+ * cone_axis_s8 / cone_cutoff_s8).  For every Meshlet of d_meshlets[0, meshletCount) — dataOffset, baseVertex, vertexCount,
+ * triangleCount and shortRefs filled in by the caller, the payload in d_meshletData as src/scene.cpp:24-47 packs it, the
+ * fp16 positions in d_vertices — computes the bounding sphere and the normal cone of its triangles and writes center[3],
+ * radius (fp16) and cone_axis[3], cone_cutoff (s8) into the record (bytes 0-11; the rest is left alone).  d_bounds8
+ * (optional) receives the unquantised {center.xyz, radius, axis.xyz, cutoff} per meshlet.  Call nv_upload_meshlets
+ * afterwards (a mirror built from these records before is dropped).
+ * PARITY UNPINNED: the arithmetic is meshoptimizer's, which the reference does not vendor; the library's published
+ * algorithm is restated with defined fp32 semantics here and in the CPU oracle (orc_meshlet_bounds), and the two agree bit for bit. */
+int nv_meshlet_bounds(nv_context* ctx, void* stream, const NvVertex* d_vertices, const uint32_t* d_meshletData, NvMeshlet* d_meshlets,
+                      uint32_t meshletCount, float* d_bounds8);
+
 int nv_trianglecull(nv_context* ctx, void* stream, const NvGlobals* globals, const NvMeshTaskCommand* d_commands,
                     const NvMeshDraw* d_draws, const NvMeshlet* d_meshlets, const uint32_t* d_meshletData,
                     const NvVertex* d_vertices, const uint32_t* d_clusterIndices, const uint32_t* d_clusterCount4,

@@ -57,6 +57,7 @@ _SIGS = {
     "nv_upload_meshlets": (_i, [_vp, _vp, _vp, _u32]),
     "nv_upload_meshes": (_i, [_vp, _vp, _vp, _u32]),
     "nv_upload_draws": (_i, [_vp, _vp, _vp, _u32, _vp]),
+    "nv_meshlet_bounds": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "nv_update_draws": (_i, [_vp, _vp, _vp, _u32, _u32]),
     "nv_drawcull": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(PyramidDesc)]),
     "nv_reset_count": (_i, [_vp, _vp, _vp, _vp]),

@@ -35,6 +35,7 @@ int launch_clustersubmit(hipStream_t, uint32_t* cc4, uint32_t* clusterIndices);
 int launch_pack_counts(hipStream_t, const uint32_t*, const uint32_t*, const uint32_t*, uint64_t*);
 int launch_depthreduce(hipStream_t, const float* depth, uint32_t w, uint32_t h, const NvPyramidDesc& pyr);
 int launch_trianglecull(hipStream_t, const TriangleArgs& a, uint32_t gridBlocks);
+int launch_meshlet_bounds(hipStream_t, const NvVertex* vertices, const uint32_t* data, NvMeshlet* meshlets, uint32_t count, float* out8, uint32_t gridBlocks);
 
 } // namespace nv
 
@@ -664,6 +665,21 @@ int nv_trianglecull(nv_context* ctx, void* stream, const NvGlobals* globals, con
 		return NV_ENOMEM;
 	a.partials = ctx->totalsPartials;
 	return nv::launch_trianglecull((hipStream_t)stream, a, grid);
+}
+
+int nv_meshlet_bounds(nv_context* ctx, void* stream, const NvVertex* d_vertices, const uint32_t* d_meshletData, NvMeshlet* d_meshlets, uint32_t meshletCount,
+                      float* d_bounds8)
+{
+	if (!ctx || (meshletCount && (!d_vertices || !d_meshletData || !d_meshlets)))
+		return NV_EINVAL;
+	DeviceGuard guard(ctx->device);
+	const uint32_t blocks = (meshletCount + 3) / 4;
+	const uint32_t cap = persistent_grid(ctx, 16);
+	int rc = nv::launch_meshlet_bounds((hipStream_t)stream, d_vertices, d_meshletData, d_meshlets, meshletCount, d_bounds8, blocks < cap ? blocks : cap);
+	// a mirror built from these records is stale now (its registration is by pointer, its contents a snapshot)
+	if (rc == 0 && ctx->mirroredFrom == d_meshlets)
+		ctx->mirroredFrom = nullptr;
+	return rc;
 }
 
 int nv_depthreduce(nv_context* ctx, void* stream, const float* d_depth, uint32_t width, uint32_t height,

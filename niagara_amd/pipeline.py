@@ -84,6 +84,10 @@ class Context:
     def upload_meshes(self, mb, count):
         check(lib.nv_upload_meshes(self.h, _stream(), _ptr(mb), count), "nv_upload_meshes")
 
+    def meshlet_bounds(self, vertices, meshlet_data, mlb, count, bounds8=None):
+        """src/scene.cpp:69-85 on the GPU: fills center / radius / cone of the Meshlet records in `mlb` (parity unpinned: header)"""
+        check(lib.nv_meshlet_bounds(self.h, _stream(), _ptr(vertices), _ptr(meshlet_data), _ptr(mlb), count, _ptr(bounds8)), "nv_meshlet_bounds")
+
     def upload_draws(self, db, count, mb=None):
         """mirror of what a draw decision reads: world-space spheres (mesh bounds of table `mb` folded in), scale, meshIndex,
         postPass (None, 0 drops the registration)"""

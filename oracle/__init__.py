@@ -178,5 +178,13 @@ def trianglecull(globals_, commands, draws, meshlets, meshlet_data, vertices, ci
                            C.c_uint32(len(masks)), _p(totals3))
 
 
+def meshlet_bounds(vertices, meshlet_data, meshlets, want_float=False):
+    """fills center / radius / cone_axis / cone_cutoff of `meshlets` in place (src/scene.cpp:69-85; parity unpinned: oracle.c);
+    optionally returns the unquantised {center, radius, axis, cutoff} rows"""
+    out = np.zeros((len(meshlets), 8), np.float32) if want_float else None
+    lib().orc_meshlet_bounds(_p(vertices), _p(meshlet_data), _p(meshlets), C.c_uint32(len(meshlets)), _p(out))
+    return out
+
+
 def max_threads():
     return int(lib().orc_max_threads())

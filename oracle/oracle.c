@@ -962,3 +962,185 @@ void orc_drawcull_mt(const OrcCullData* cd, int late, int task, const OrcMeshDra
 	free(dec);
 	free(oldWord);
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * SURVEY.md §8(f) N2 — meshlet bounds: bounding sphere, normal cone and their fp16 / s8 quantisation, as niagara stores
+ * them in a Meshlet (src/scene.cpp:69-85: meshopt_computeMeshletBounds, meshopt_quantizeHalf, cone_axis_s8 /
+ * cone_cutoff_s8).
+ *
+ * PARITY UNPINNED.  The arithmetic is meshoptimizer's (https://github.com/zeux/meshoptimizer, .gitmodules:7-9, an
+ * un-vendored submodule with no pinned commit): nothing under /root/reference computes or stores a meshlet bound, so
+ * there is no golden vector to hold this against.  What follows restates the library's PUBLISHED algorithm
+ * (clusterizer.cpp: meshopt_computeClusterBounds + computeBoundingSphere in its three-axis form; meshoptimizer.h:
+ * meshopt_quantizeHalf, meshopt_quantizeSnorm) with DEFINED semantics — fp32, one IEEE operation per C operation, no
+ * contraction, sums left to right, points visited in triangle order — and the tests pin what can be pinned without the
+ * library: the HIP kernel equals this function bit for bit, every vertex lies inside the sphere and every triangle normal
+ * inside the cone (up to the fp16 / s8 rounding that niagara's own call sites accept), and culling real geometry with the
+ * generated bounds never removes a meshlet whose triangles a per-triangle test keeps (tests/test_meshlet_bounds.py).
+ * Input positions are the fp16 vertex positions, dequantised, exactly like src/scene.cpp:193-198 feeds the library. */
+static uint16_t orc_quantize_half(float v)
+{
+	/* meshopt_quantizeHalf: round to nearest (ties away in the mantissa sum), flush below 2^-14, saturate to inf */
+	union { float f; uint32_t ui; } u = { v };
+	uint32_t ui = u.ui;
+	int s = (int)((ui >> 16) & 0x8000);
+	int em = (int)(ui & 0x7fffffff);
+	int h = (em - (112 << 23) + (1 << 12)) >> 13;
+	h = (em < (113 << 23)) ? 0 : h;
+	h = (em >= (143 << 23)) ? 0x7c00 : h;
+	h = (em > (255 << 23)) ? 0x7e00 : h;
+	return (uint16_t)(s | h);
+}
+
+static int orc_quantize_snorm8(float v)
+{
+	/* meshopt_quantizeSnorm(v, 8) */
+	const float scale = 127.0f;
+	float round = (v >= 0 ? 0.5f : -0.5f);
+	v = (v >= -1) ? v : -1;
+	v = (v <= +1) ? v : +1;
+	return (int)(v * scale + round);
+}
+
+/* computeBoundingSphere (three-axis Ritter): extreme points per axis, the longest of the three segments as the first
+ * diameter, then one pass that grows the sphere over every point outside it */
+static void bounding_sphere(float result[4], const float (*points)[3], uint32_t count)
+{
+	uint32_t pmin[3] = { 0, 0, 0 }, pmax[3] = { 0, 0, 0 };
+	for (uint32_t i = 0; i < count; ++i)
+		for (int axis = 0; axis < 3; ++axis)
+		{
+			pmin[axis] = (points[i][axis] < points[pmin[axis]][axis]) ? i : pmin[axis];
+			pmax[axis] = (points[i][axis] > points[pmax[axis]][axis]) ? i : pmax[axis];
+		}
+	float paxisd2 = 0;
+	int paxis = 0;
+	for (int axis = 0; axis < 3; ++axis)
+	{
+		const float* p1 = points[pmin[axis]];
+		const float* p2 = points[pmax[axis]];
+		float dx = p2[0] - p1[0], dy = p2[1] - p1[1], dz = p2[2] - p1[2];
+		float d2 = (dx * dx + dy * dy) + dz * dz;
+		if (d2 > paxisd2)
+		{
+			paxisd2 = d2;
+			paxis = axis;
+		}
+	}
+	const float* p1 = points[pmin[paxis]];
+	const float* p2 = points[pmax[paxis]];
+	float center[3] = { (p1[0] + p2[0]) / 2, (p1[1] + p2[1]) / 2, (p1[2] + p2[2]) / 2 };
+	float radius = sqrtf(paxisd2) / 2;
+	for (uint32_t i = 0; i < count; ++i)
+	{
+		const float* p = points[i];
+		float dx = p[0] - center[0], dy = p[1] - center[1], dz = p[2] - center[2];
+		float d2 = (dx * dx + dy * dy) + dz * dz;
+		if (d2 > radius * radius)
+		{
+			float d = sqrtf(d2);
+			float k = 0.5f + (radius / d) / 2;
+			center[0] = center[0] * k + p[0] * (1 - k);
+			center[1] = center[1] * k + p[1] * (1 - k);
+			center[2] = center[2] * k + p[2] * (1 - k);
+			radius = (radius + d) / 2;
+		}
+	}
+	result[0] = center[0], result[1] = center[1], result[2] = center[2], result[3] = radius;
+}
+
+/* fills center / radius / cone_axis / cone_cutoff of meshlets[0..count); out8 (optional) receives the unquantised
+ * {center.xyz, radius, axis.xyz, cutoff} per meshlet for the tests */
+void orc_meshlet_bounds(const OrcVertex* vertices, const uint32_t* meshletData, OrcMeshlet* meshlets, uint32_t count, float* out8)
+{
+	const uint16_t* data16 = (const uint16_t*)meshletData;
+	const uint8_t* data8 = (const uint8_t*)meshletData;
+	for (uint32_t mi = 0; mi < count; ++mi)
+	{
+		OrcMeshlet* m = &meshlets[mi];
+		uint32_t vertexCount = m->vertexCount < 64 ? m->vertexCount : 64, triangleCount = m->triangleCount < 96 ? m->triangleCount : 96;
+		int shortRefs = m->shortRefs == 1;
+		uint32_t indexOffset = m->dataOffset + (shortRefs ? (vertexCount + 1) / 2 : vertexCount);
+		float pos[64][3];
+		memset(pos, 0, sizeof(pos));
+		for (uint32_t i = 0; i < vertexCount; ++i)
+		{
+			uint32_t vi = (shortRefs ? (uint32_t)data16[m->dataOffset * 2 + i] : meshletData[m->dataOffset + i]) + m->baseVertex;
+			pos[i][0] = orc_half_to_float(vertices[vi].vx);
+			pos[i][1] = orc_half_to_float(vertices[vi].vy);
+			pos[i][2] = orc_half_to_float(vertices[vi].vz);
+		}
+		/* triangle normals and corners, degenerate triangles dropped (meshopt_computeClusterBounds) */
+		static _Thread_local float normals[96][3];
+		static _Thread_local float corners[96 * 3][3];
+		uint32_t triangles = 0;
+		for (uint32_t i = 0; i < triangleCount; ++i)
+		{
+			uint32_t a = data8[indexOffset * 4 + i * 3 + 0] & 63, b = data8[indexOffset * 4 + i * 3 + 1] & 63, c = data8[indexOffset * 4 + i * 3 + 2] & 63;
+			const float *p0 = pos[a], *p1 = pos[b], *p2 = pos[c];
+			float p10[3] = { p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2] };
+			float p20[3] = { p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2] };
+			float nx = p10[1] * p20[2] - p10[2] * p20[1];
+			float ny = p10[2] * p20[0] - p10[0] * p20[2];
+			float nz = p10[0] * p20[1] - p10[1] * p20[0];
+			float area = sqrtf((nx * nx + ny * ny) + nz * nz);
+			if (area == 0.0f)
+				continue;
+			normals[triangles][0] = nx / area, normals[triangles][1] = ny / area, normals[triangles][2] = nz / area;
+			memcpy(corners[triangles * 3 + 0], p0, 12);
+			memcpy(corners[triangles * 3 + 1], p1, 12);
+			memcpy(corners[triangles * 3 + 2], p2, 12);
+			triangles++;
+		}
+		float center[3] = { 0, 0, 0 }, radius = 0, axis[3] = { 0, 0, 0 }, cutoff = 0;
+		int axis_s8[3] = { 0, 0, 0 }, cutoff_s8 = 0;
+		if (triangles)
+		{
+			float psphere[4], nsphere[4];
+			bounding_sphere(psphere, corners, triangles * 3);
+			bounding_sphere(nsphere, normals, triangles);
+			center[0] = psphere[0], center[1] = psphere[1], center[2] = psphere[2], radius = psphere[3];
+			axis[0] = nsphere[0], axis[1] = nsphere[1], axis[2] = nsphere[2];
+			float axislength = sqrtf((axis[0] * axis[0] + axis[1] * axis[1]) + axis[2] * axis[2]);
+			float invaxislength = axislength == 0.0f ? 0.0f : 1.0f / axislength;
+			axis[0] *= invaxislength, axis[1] *= invaxislength, axis[2] *= invaxislength;
+			float mindp = 1.0f;
+			for (uint32_t i = 0; i < triangles; ++i)
+			{
+				float dp = (normals[i][0] * axis[0] + normals[i][1] * axis[1]) + normals[i][2] * axis[2];
+				mindp = (dp < mindp) ? dp : mindp;
+			}
+			if (mindp <= 0.1f)
+			{
+				/* normal cone wider than a hemisphere: no cone (cutoff 1 never culls) */
+				axis[0] = axis[1] = axis[2] = 0;
+				cutoff = 1;
+				cutoff_s8 = 127;
+			}
+			else
+			{
+				cutoff = sqrtf(1 - mindp * mindp);
+				float e = 0;
+				for (int k = 0; k < 3; ++k)
+				{
+					axis_s8[k] = orc_quantize_snorm8(axis[k]);
+					e += fabsf((float)axis_s8[k] / 127.0f - axis[k]);
+				}
+				/* rounded up so that the 8-bit test stays conservative */
+				int c8 = (int)(127 * (cutoff + e) + 1);
+				cutoff_s8 = c8 > 127 ? 127 : c8;
+			}
+		}
+		m->center[0] = orc_quantize_half(center[0]);
+		m->center[1] = orc_quantize_half(center[1]);
+		m->center[2] = orc_quantize_half(center[2]);
+		m->radius = orc_quantize_half(radius);
+		m->cone_axis[0] = (int8_t)axis_s8[0], m->cone_axis[1] = (int8_t)axis_s8[1], m->cone_axis[2] = (int8_t)axis_s8[2];
+		m->cone_cutoff = (int8_t)cutoff_s8;
+		if (out8)
+		{
+			float* o = out8 + (size_t)mi * 8;
+			o[0] = center[0], o[1] = center[1], o[2] = center[2], o[3] = radius, o[4] = axis[0], o[5] = axis[1], o[6] = axis[2], o[7] = cutoff;
+		}
+	}
+}

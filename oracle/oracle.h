@@ -163,6 +163,11 @@ void orc_trianglecull(const OrcGlobals* globals, const OrcMeshTaskCommand* comma
 void orc_probe_cluster_scalars(const OrcCullData* cull, const OrcMeshTaskCommand* commands, uint32_t commandCount,
                                const OrcMeshDraw* draws, const OrcMeshlet* meshlets, const OrcPyramid* pyr, float* out16);
 
+/* meshlet bounding sphere + normal cone + fp16 / s8 quantisation (src/scene.cpp:69-85).  PARITY
+ * UNPINNED: meshoptimizer's published algorithm restated (see oracle.c); the vertex array is the reference's Vertex
+ * (fp16 positions), the data array its packed vertex references + index bytes */
+void orc_meshlet_bounds(const OrcVertex* vertices, const uint32_t* meshletData, OrcMeshlet* meshlets, uint32_t count, float* out8);
+
 /* multi-threaded (OpenMP) forms used only as the CPU baseline; identical output */
 int orc_max_threads(void);
 void orc_clustercull_mt(const OrcCullData* cull, int late, const OrcMeshTaskCommand* commands, const uint32_t* count4,
