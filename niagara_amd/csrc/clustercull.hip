@@ -375,7 +375,15 @@ NV_DEV uint32_t indirect_command_count(const ClusterArgs& a)
 //                             clustersubmit's words and the all-reduce payload).
 //
 // The ballots cost 8 B per 64 meshlets of extra traffic (1 %), the extra launch boundary ~4 us.
-constexpr uint32_t CC_CHUNK = 4; // consecutive commands per dealt chunk
+constexpr uint32_t CC_CHUNK = 4; // consecutive commands per dealt chunk (early pass)
+// Late pass: a candidate command costs ~3 k cycles there (certified test + the reference's sphere + the HiZ probe), so the
+// launch ends with the waves that drew the most candidates.  Dealing smaller chunks spreads a draw's commands over more
+// waves, but measured slower: 42.0 us with 4, 45.3 with 2, 49.7 with 1 (config 4) — every command then starts a new draw
+// in pass A (16 v_readlane + 4 moves per command) and the command loads stop coalescing.
+#ifndef NV_CC_CHUNK_LATE
+#define NV_CC_CHUNK_LATE 4
+#endif
+constexpr uint32_t CC_CHUNK_LATE = NV_CC_CHUNK_LATE;
 // CC_DA (template parameter of the cull kernel) = ring slots of the filter pass: CC_DA - 1 commands' bounds in flight behind
 // the one being filtered.  8 keep HBM saturated through the segment boundaries of a long stream (100 M meshlets: 198 us
 // vs 208 us with 4) and suit the late pass; for a pass of a few hundred thousand commands — one segment per wave — 4
@@ -953,11 +961,12 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 	const uint32_t numCmds = indirect_command_count(a);
 	if (a.hostHint && blockIdx.x == 0 && threadIdx.x == 0)
 		__hip_atomic_store(a.hostHint, numCmds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-	const uint32_t numChunks = (numCmds + CC_CHUNK - 1) / CC_CHUNK;
+	constexpr uint32_t CH = LATE ? CC_CHUNK_LATE : CC_CHUNK;
+	const uint32_t numChunks = (numCmds + CH - 1) / CH;
 	uint32_t chunkOf;
 	bool dealtWeighted;
 	const uint32_t myChunks = make_dealing(numChunks, wave, lane, a.generations, gen, !LATE && !NV_DBG(a, 32768u), a.dealScale, &chunkOf, &dealtWeighted); // (late pass: even — the weights are calibrated on the early pass, and the extra state costs the late variants two resident workgroups per CU) // bit 15 (experiments): even dealing
-	const uint32_t myCmds = myChunks * CC_CHUNK; // the last chunk of the pass may run past numCmds: guarded below
+	const uint32_t myCmds = myChunks * CH; // the last chunk of the pass may run past numCmds: guarded below
 	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles);
 	const uint32_t bank = load_uniform_u32(&a.tileCounts->parity) & 1u;
 	if (w == 0 && lane == 0)
@@ -979,9 +988,9 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 		const uint32_t cnt = myCmds - seg < 64u ? myCmds - seg : 64u;
 
 		// lane l holds the wave's (seg + l)-th command and (below) the MeshDraw it points at
-		const uint32_t cidx = (seg + lane) / CC_CHUNK;
+		const uint32_t cidx = (seg + lane) / CH;
 		const uint32_t chunk = dealtWeighted ? (uint32_t)__shfl(chunkOf, cidx & 63u, 64) : cidx * (gridDim.x * CC_WAVES) + w;
-		const uint32_t myIdx = chunk * CC_CHUNK + (seg + lane) % CC_CHUNK;
+		const uint32_t myIdx = chunk * CH + (seg + lane) % CH;
 		SegmentRegs r = {};
 		if (lane < cnt && myIdx < numCmds)
 		{
@@ -1128,7 +1137,10 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 			}
 			NV_STAMP(3);
 
-			// ---- pass B: exact tests (reference arithmetic) for the commands that can have survivors, bounds + cone
+			// ---- pass B: the commands that can have survivors, bounds + cone.  (Measured and dropped: raising a wave to the
+			// top priority for pass B, because it is on the launch's critical path — late pass 44.8 -> 48.8 us, early pass
+			// unchanged: the boosted wave takes issue slots from the streaming waves that keep HBM busy; likewise
+			// keeping level 3 out of the streaming waves' rotation: early pass +1.5 us.)
 			if (LATE && candMask && a.cd.clusterOcclusionEnabled == 1 && !NV_DBG(a, 1024u | 524288u)) // bit 19 (experiments): texels fetched per command
 			{
 				// Late pass with HiZ: the same ring for bounds + cone, and behind it the texel fetches of CC_PT commands in
@@ -1775,6 +1787,7 @@ int launch_cluster_mask(hipStream_t stream, const ClusterArgs& a, int late, bool
 {
 	if (late)
 	{
+		// (the 4-deep ring measured slower for the late pass: 46.7 vs 42.9 us, config 4)
 		if (soa)
 			launch_cc<true, true, 8>(stream, a, maskBlocks);
 		else
