@@ -78,6 +78,7 @@ struct nv_context
 	uint32_t debugMode;
 	uint32_t ccBlocksPerCU;
 	uint32_t dealScale;
+	uint32_t scatterTilesPerCU;
 	// command count of the previous clustercull launch, written by its kernel into mapped host memory (tuning hint)
 	volatile uint32_t* hintHost;
 	uint32_t* hintDevice;
@@ -159,7 +160,7 @@ int ensure_draw_results(nv_context* ctx, uint32_t drawCount)
 // one scatter workgroup per CU, capped by the per-tile count table
 uint32_t scatter_grid(const nv_context* ctx)
 {
-	uint32_t g = (uint32_t)ctx->numCUs;
+	uint32_t g = (uint32_t)ctx->numCUs * ctx->scatterTilesPerCU;
 	return g > nv::CC_MAX_SCATTER_TILES ? nv::CC_MAX_SCATTER_TILES : g;
 }
 
@@ -203,7 +204,10 @@ int nv_create(nv_context** out_ctx, int device)
 	ctx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	ctx->ccBlocksPerCU = 6;
 	ctx->dealScale = 100;
+	ctx->scatterTilesPerCU = 1;
 #ifdef NV_EXPERIMENTS
+	if (const char* v = getenv("NV_SCATTER_TILES_PER_CU"))
+		ctx->scatterTilesPerCU = (uint32_t)atoi(v) ? (uint32_t)atoi(v) : 1;
 	// the experiments build only (tools/): the product library reads no environment variable
 	if (const char* v = getenv("NV_DEBUG_MODE"))
 		ctx->debugMode = (uint32_t)atoi(v);

@@ -180,6 +180,18 @@ class VisibilityPipeline:
         self.mvb = torch.zeros(max(1, (self.slots + 31) // 32 + 2), dtype=torch.int32, device=dev)  # (:1459-1468)
         tcap = task_capacity or L.TASK_WGLIMIT
         ccap = cluster_capacity or L.CLUSTER_LIMIT
+        # The kernels clamp at the reference's limits (TASK_WGLIMIT commands, CLUSTER_LIMIT indices: the sizes niagara
+        # allocates, src/niagara.cpp:1070,1088), not at the size of a smaller buffer.  Smaller buffers are accepted only when
+        # no pass over this scene can fill them: every draw emitting its largest LOD (+ the submit kernels' padding).
+        lod_counts = meshes["lods"]["meshletCount"].astype(np.int64)
+        lod_valid = np.arange(lod_counts.shape[1])[None, :] < meshes["lodCount"][:, None]
+        per_mesh = np.where(lod_valid, lod_counts, 0).max(axis=1) if len(meshes) else np.zeros(0, np.int64)
+        mi = np.minimum(draws["meshIndex"].astype(np.int64), max(0, len(meshes) - 1))
+        worst_meshlets = int(per_mesh[mi].sum()) if len(draws) and len(meshes) else 0
+        worst_tasks = int(((per_mesh[mi] + 63) // 64).sum()) if len(draws) and len(meshes) else 0
+        if tcap < min(worst_tasks, L.TASK_WGLIMIT) + 64 or ccap < min(worst_meshlets, L.CLUSTER_LIMIT):
+            raise NvError("task_capacity %d / cluster_capacity %d cannot hold what this scene can emit (%d task commands, %d meshlets): the passes "
+                          "drop output only at the reference's limits, never at a smaller buffer's end" % (tcap, ccap, worst_tasks, worst_meshlets))
         self.dcb = torch.zeros(tcap * L.TASKCMD.itemsize + 64 * L.TASKCMD.itemsize, dtype=torch.uint8, device=dev)
         self.dccb = torch.zeros(4, dtype=torch.int32, device=dev)
         self.cib = torch.zeros(ccap + 256, dtype=torch.int32, device=dev)

@@ -828,3 +828,16 @@ def test_draw_mirror_update_and_sub_ranges(ctx):
     db[100 * 48:200 * 48].copy_(P.to_device(draws[100:200], dev))
     ctx.upload_draws(None, 0)
     check(0, len(draws), 0, 1)
+
+
+def test_pipeline_refuses_buffers_a_scene_could_overflow(ctx):
+    """the kernels clamp at TASK_WGLIMIT / CLUSTER_LIMIT, the sizes niagara allocates — a smaller command or
+    index buffer is accepted by the host layer only if no pass over the scene can fill it"""
+    scene = make_scene(seed=5, n_draws=200, n_meshes=2, lods=2, meshlets_lod0=130)
+    ok = P.VisibilityPipeline(scene["meshes"], scene["meshlets"], scene["draws"], scene["viewport"], ctx=ctx, task_capacity=200 * 3 + 64,
+                              cluster_capacity=200 * 130)
+    assert ok.dcb.numel() >= (200 * 3 + 64) * 20
+    with pytest.raises(P.NvError):
+        P.VisibilityPipeline(scene["meshes"], scene["meshlets"], scene["draws"], scene["viewport"], ctx=ctx, task_capacity=200 * 3 - 1, cluster_capacity=200 * 130)
+    with pytest.raises(P.NvError):
+        P.VisibilityPipeline(scene["meshes"], scene["meshlets"], scene["draws"], scene["viewport"], ctx=ctx, task_capacity=200 * 3 + 64, cluster_capacity=200 * 130 - 1)

@@ -127,7 +127,7 @@ def config3b(ctx, iters, n_draws=15625 * 4, fused=False):
     slots, _ = host.assign_visibility_offsets(draws, meshes)
     cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, lodEnabled=1, clusterBackfaceEnabled=1)
     cd["cullingEnabled"] = 0  # every draw emits commands: the cluster pass sees the whole pool
-    pipe = P.VisibilityPipeline(meshes, meshlets, draws, (1024, 768), ctx=ctx, task_capacity=n_draws * 10 + 64, cluster_capacity=1 << 22, fused=fused)
+    pipe = P.VisibilityPipeline(meshes, meshlets, draws, (1024, 768), ctx=ctx, task_capacity=n_draws * 10 + 64, fused=fused)
     pipe.dvb.fill_(1)
 
     def step(i):
