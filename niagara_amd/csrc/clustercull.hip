@@ -636,7 +636,8 @@ NV_DEV float s8_to_float(uint32_t word, int byte)
 
 // need = the lanes whose decision matters (valid, and for the early pass with visibility bits: bit set).  Returns true
 // when every such lane is decided; *vis = ballot of the lanes that pass frustum and cone (clustercull.comp.glsl:102-108).
-NV_DEV bool certified_visible(const NvCullData& cd, const CertUniform& f, uint32_t b0, uint32_t b1, uint32_t cone, uint64_t need, uint64_t* vis)
+NV_DEV bool certified_visible(const NvCullData& cd, const CertUniform& f, uint32_t b0, uint32_t b1, uint32_t cone, uint64_t need, uint64_t* vis,
+                              bool* filterRejects = nullptr)
 {
 	const float vx = half_bits_to_float(b0 & 0xffffu), vy = half_bits_to_float(b0 >> 16), vz = half_bits_to_float(b1 & 0xffffu);
 	const float rad = half_bits_to_float(b1 >> 16);
@@ -655,6 +656,8 @@ NV_DEV bool certified_visible(const NvCullData& cd, const CertUniform& f, uint32
 	// a finite T implies finite, bounded c~ and (host-checked) finite coefficients: no NaN is dropped by these minima
 	const float g = __builtin_fminf(__builtin_fminf(g1, g2), __builtin_fminf(gn, gf));
 	const uint64_t outM = __ballot(g < -thrHi), inM = __ballot(g > -thrLo);
+	if (filterRejects) // what pass A's filter would have said about this command (the same comparison)
+		*filterRejects = (need & ~outM) == 0;
 	if (need & ~(outM | inM))
 		return false;
 	uint64_t alive = need & inM;
@@ -930,7 +933,12 @@ NV_DEV uint32_t make_dealing(uint32_t numChunks, uint32_t wave, uint32_t lane, u
 	return mine;
 }
 
-template <bool LATE, bool SOA, bool BITS, int CC_DA>
+// DIRECT (SoA mirror only): no pass A — every valid command goes straight to pass B, bounds and cone read once.  The
+// host picks it for a launch when the previous launch found that most commands pass the filter (frame coherence; the
+// kernels count what the filter rejects, or would have rejected, and leave the count in a mapped host word): a pass over
+// the commands of draws that drawcull already found visible — the production case — has nothing for the filter to remove,
+// and streaming its 8 bytes first only to re-read them with the cone costs a third of the launch.
+template <bool LATE, bool SOA, bool BITS, int CC_DA, bool DIRECT = false>
 __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs a)
 {
 	const uint32_t lane = threadIdx.x & 63u;
@@ -983,6 +991,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 	if (dbgTime && lane == 0)
 		stamps[6] = wall_clock64(); // 100 MHz, chip-wide: comparable across CUs (the cycle counter is not)
 
+	uint32_t passedFilter = 0; // commands of this wave the conservative filter does not finish (DIRECT: would not have finished)
 	for (uint32_t seg = 0; seg < myCmds; seg += 64)
 	{
 		const uint32_t cnt = myCmds - seg < 64u ? myCmds - seg : 64u;
@@ -1083,6 +1092,13 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				ringA_issue<BITS_A>(slot, a, off8, offw, order);
 			};
 
+			if (DIRECT)
+			{
+				NV_COUNTED_WAIT("s_waitcnt vmcnt(%2) ; nv_ready %0 %1" : "+v"(g0), "+v"(g1) : "i"(0) : "memory"); // the gather
+				gather_finish();
+				candMask = __ballot(lane < cnt && myIdx < numCmds && r.taskCount != 0); // every valid command
+			}
+			else
 			{
 				SlotA ring[CC_DA];
 #pragma unroll
@@ -1134,6 +1150,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 #pragma unroll
 				for (int k = 0; k < CC_DA; ++k)
 					ring_release(ring[k]);
+				passedFilter += (uint32_t)__builtin_popcountll(candMask);
 			}
 			NV_STAMP(3);
 
@@ -1215,8 +1232,13 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 									certDraw = cmd.drawId;
 									cf = segment_cert(r, c);
 								}
-								decided = certified_visible(a.cd, cf, cur.b0, cur.b1, cur.cone, cmd.taskCount >= 64u ? ~0ull : (1ull << cmd.taskCount) - 1ull, &vis);
+								bool rejects = false;
+								decided = certified_visible(a.cd, cf, cur.b0, cur.b1, cur.cone, cmd.taskCount >= 64u ? ~0ull : (1ull << cmd.taskCount) - 1ull, &vis, &rejects);
+								if (DIRECT && !rejects)
+									++passedFilter;
 							}
+							else if (DIRECT)
+								++passedFilter;
 							if (!decided || vis)
 							{
 								if (cmd.drawId != curDraw)
@@ -1331,9 +1353,14 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 									else if (cmd.lateDrawVisibility == 1)
 										skipM = bitM;
 								}
-								decided = certified_visible(a.cd, cf, cur.b0, cur.b1, cur.cone, need, &vis);
+								bool rejects = false;
+								decided = certified_visible(a.cd, cf, cur.b0, cur.b1, cur.cone, need, &vis, &rejects);
 								m = vis & ~skipM;
+								if (DIRECT && !rejects)
+									++passedFilter;
 							}
+							else if (DIRECT)
+								++passedFilter;
 							if (!decided) // some lane sits inside a margin (or the test is off): the reference arithmetic for the whole wave
 							{
 								if (cmd.drawId != curDraw)
@@ -1442,6 +1469,13 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				atomicAdd(&a.tileCounts->counts[bank][tileOf * CC_COUNT_STRIDE], pc);
 		}
 	}
+	// the launch's filter statistic for the host's choice of the next launch's form: one add per wave, spread over the tile
+	// counters' lines (word 1 of a line; the scatter kernel sums them)
+	if (lane == 0 && passedFilter)
+	{
+		const uint32_t numTiles = (numCmds + T2 - 1) / T2;
+		atomicAdd(&a.tileCounts->counts[bank][(w % (numTiles ? numTiles : 1u)) * CC_COUNT_STRIDE + 1], passedFilter);
+	}
 	NV_STAMP(5);
 	if (dbgTime && lane == 0)
 		stamps[7] = wall_clock64();
@@ -1477,6 +1511,7 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 	const uint32_t k2parity = load_uniform_u32(&a.tileCounts->k2parity);
 	const uint32_t base0 = load_uniform_u32(&a.tileCounts->base);
 	uint32_t cnt0[TILE_LOADS] = {}, cnt1[TILE_LOADS] = {}; // this thread's tiles tid, tid + SC_THREADS, ..., per bank
+	uint32_t pf0[TILE_LOADS] = {}, pf1[TILE_LOADS] = {};   // likewise the cull kernel's filter statistic (word 1 of the line)
 #pragma unroll
 	for (int j = 0; j < TILE_LOADS; ++j)
 	{
@@ -1485,6 +1520,8 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 		{
 			cnt0[j] = a.tileCounts->counts[0][i * CC_COUNT_STRIDE];
 			cnt1[j] = a.tileCounts->counts[1][i * CC_COUNT_STRIDE];
+			pf0[j] = a.tileCounts->counts[0][i * CC_COUNT_STRIDE + 1];
+			pf1[j] = a.tileCounts->counts[1][i * CC_COUNT_STRIDE + 1];
 		}
 	}
 	const uint32_t first = tile * T;
@@ -1518,10 +1555,15 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 	// every workgroup clears its entries of the other bank for the next pass; one thread flips the parity the next
 	// cull kernel will read (this pass reads k2parity only)
 	for (uint32_t i = tile * SC_THREADS + tid; i < CC_MAX_SCATTER_TILES; i += gridDim.x * SC_THREADS)
+	{
 		a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE] = 0;
+		a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE + 1] = 0;
+	}
 	if (tile == 0 && tid == 0)
 	{
 		a.tileCounts->parity = bank ^ 1u;
+		if (numTiles == 0 && a.hostHint)
+			__hip_atomic_store(a.hostHint + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		if (numTiles == 0) // no commands at all: the count word keeps its base, the submit words describe an empty grid
 		{
 			if (a.fusedReset)
@@ -1548,7 +1590,7 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 	if (tile >= numTiles)
 		return;
 
-	uint32_t before = 0, all = 0;
+	uint32_t before = 0, all = 0, passed = 0;
 #pragma unroll
 	for (int j = 0; j < TILE_LOADS; ++j)
 	{
@@ -1556,6 +1598,20 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 		const uint32_t v = bank ? cnt1[j] : cnt0[j];
 		all += v;
 		before += i < tile ? v : 0u;
+		passed += bank ? pf1[j] : pf0[j];
+	}
+	if (tile == numTiles - 1 && a.hostHint) // (one workgroup: the statistic is a tuning hint, its sum need not be fast)
+	{
+		__shared__ uint32_t s_passed;
+		if (tid == 0)
+			s_passed = 0;
+		__syncthreads();
+		const uint32_t wp = wave_sum_u32(passed);
+		if (lane == 0 && wp)
+			atomicAdd(&s_passed, wp);
+		__syncthreads();
+		if (tid == 0)
+			__hip_atomic_store(a.hostHint + 1, s_passed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 	const uint32_t wBefore = wave_sum_u32(before), wAll = wave_sum_u32(all);
 	if (lane == 0)
@@ -1772,20 +1828,28 @@ __global__ __launch_bounds__(256) void soa_split_kernel(const NvMeshlet* __restr
 // ---------------------------------------------------------------------------------------------------------------
 // launchers (called from context.hip)
 
-template <bool LATE, bool SOA, int DEPTH>
+template <bool LATE, bool SOA, int DEPTH, bool DIRECT = false>
 static void launch_cc(hipStream_t stream, const ClusterArgs& a, uint32_t gridBlocks)
 {
 	dim3 grid(gridBlocks), block(CC_THREADS);
 	if (a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0)
-		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, true, DEPTH>), grid, block, 0, stream, a);
+		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, true, DEPTH, DIRECT>), grid, block, 0, stream, a);
 	else
-		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, false, DEPTH>), grid, block, 0, stream, a);
+		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, false, DEPTH, DIRECT>), grid, block, 0, stream, a);
 }
 
-// any grid size (pure map); shallow = use the 4-deep filter ring (early pass over the SoA mirror only)
-int launch_cluster_mask(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t maskBlocks, bool shallow)
+// any grid size (pure map); shallow = use the 4-deep filter ring (early pass over the SoA mirror only); direct = no filter
+// pass (SoA mirror only; the host's guess from the previous launch's statistic — a wrong guess only costs speed)
+int launch_cluster_mask(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t maskBlocks, bool shallow, bool direct)
 {
-	if (late)
+	if (soa && direct && a.filterK > 0.0f)
+	{
+		if (late)
+			launch_cc<true, true, 8, true>(stream, a, maskBlocks);
+		else
+			launch_cc<false, true, 8, true>(stream, a, maskBlocks);
+	}
+	else if (late)
 	{
 		// (the 4-deep ring measured slower for the late pass: 46.7 vs 42.9 us, config 4)
 		if (soa)
@@ -1806,6 +1870,12 @@ int launch_cluster_mask(hipStream_t stream, const ClusterArgs& a, int late, bool
 }
 
 bool clustercull_prefers_shallow(uint32_t previousCommandCount) { return previousCommandCount != 0 && previousCommandCount <= CC_SHALLOW_COMMANDS; }
+
+// the filter pass pays for itself while it finishes more than about half of the commands (measured: DESIGN.md §4.1)
+bool clustercull_prefers_direct(uint32_t previousCommandCount, uint32_t previousPassedFilter, uint32_t percent)
+{
+	return previousCommandCount != 0 && (uint64_t)previousPassedFilter * 100u > (uint64_t)previousCommandCount * percent;
+}
 
 // one workgroup per scatter tile (context.hip: one per CU, at most CC_MAX_SCATTER_TILES); no workgroup waits on another
 int launch_cluster_scatter(hipStream_t stream, const ClusterArgs& a, uint32_t scatterBlocks)

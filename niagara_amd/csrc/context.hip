@@ -17,8 +17,9 @@
 namespace nv
 {
 
-int launch_cluster_mask(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t maskBlocks, bool shallow);
+int launch_cluster_mask(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t maskBlocks, bool shallow, bool direct);
 bool clustercull_prefers_shallow(uint32_t previousCommandCount);
+bool clustercull_prefers_direct(uint32_t previousCommandCount, uint32_t previousPassedFilter, uint32_t percent);
 int launch_cluster_scatter(hipStream_t, const ClusterArgs&, uint32_t scatterBlocks);
 size_t clustercull_mask_bytes();
 int launch_taskcull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t gridBlocks);
@@ -79,6 +80,8 @@ struct nv_context
 	uint32_t ccBlocksPerCU;
 	uint32_t dealScale;
 	uint32_t scatterTilesPerCU;
+	uint32_t directPercent; // share of commands passing the filter above which the next launch skips the filter pass
+	int forceDirect;        // experiments build: -1 = by statistic, 0 / 1 = always filter / always direct
 	// command count of the previous clustercull launch, written by its kernel into mapped host memory (tuning hint)
 	volatile uint32_t* hintHost;
 	uint32_t* hintDevice;
@@ -205,7 +208,13 @@ int nv_create(nv_context** out_ctx, int device)
 	ctx->ccBlocksPerCU = 6;
 	ctx->dealScale = 100;
 	ctx->scatterTilesPerCU = 1;
+	ctx->directPercent = 35; // measured crossover (config 3A geometry at several densities): ~36 % of the commands passing the filter
+	ctx->forceDirect = -1;
 #ifdef NV_EXPERIMENTS
+	if (const char* v = getenv("NV_DIRECT"))
+		ctx->forceDirect = atoi(v);
+	if (const char* v = getenv("NV_DIRECT_PERCENT"))
+		ctx->directPercent = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_SCATTER_TILES_PER_CU"))
 		ctx->scatterTilesPerCU = (uint32_t)atoi(v) ? (uint32_t)atoi(v) : 1;
 	// the experiments build only (tools/): the product library reads no environment variable
@@ -596,7 +605,12 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	hipStream_t s = (hipStream_t)stream;
 	hipEvent_t e0 = prof_mark(ctx, s);
 	const bool shallow = ctx->hintHost && nv::clustercull_prefers_shallow(*ctx->hintHost) && !(ctx->debugMode & 65536u); // bit 16 (experiments): always deep
-	rc = nv::launch_cluster_mask(s, a, late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), shallow);
+	// mapped host words the previous launches left: [0] command count, [1] commands their filter did not (or would not
+	// have) finished — possibly a launch or two behind, which only matters for speed
+	bool direct = ctx->hintHost && nv::clustercull_prefers_direct(ctx->hintHost[0], ctx->hintHost[1], ctx->directPercent);
+	if (ctx->forceDirect >= 0)
+		direct = ctx->forceDirect != 0;
+	rc = nv::launch_cluster_mask(s, a, late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), shallow, direct);
 	hipEvent_t e1 = prof_mark(ctx, s);
 	if (rc == 0 && !(ctx->debugMode & 16u)) // bit 4 (experiments): ballots only
 		rc = nv::launch_cluster_scatter(s, a, a.scatterTiles);

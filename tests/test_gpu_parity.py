@@ -841,3 +841,36 @@ def test_pipeline_refuses_buffers_a_scene_could_overflow(ctx):
         P.VisibilityPipeline(scene["meshes"], scene["meshlets"], scene["draws"], scene["viewport"], ctx=ctx, task_capacity=200 * 3 - 1, cluster_capacity=200 * 130)
     with pytest.raises(P.NvError):
         P.VisibilityPipeline(scene["meshes"], scene["meshlets"], scene["draws"], scene["viewport"], ctx=ctx, task_capacity=200 * 3 + 64, cluster_capacity=200 * 130 - 1)
+
+
+@pytest.mark.parametrize("soa", [True, False])
+def test_dense_passes_switch_to_the_direct_form(ctx, soa):
+    """When most commands pass the conservative filter, the next launch skips the filter pass (the kernels leave the
+    statistic in a mapped host word; frame coherence).  A dense scene, every flag combination, each pass three times in a
+    row — the later launches run the direct form — and a sparse pass in between to switch back: all equal the oracle."""
+    rng = np.random.default_rng(17)
+    draws, meshlets, commands, n, cd = _cluster_inputs(900, 6, seed=4)
+    draws["position"] *= np.float32(0.05)                      # a cloud of radius 15 ...
+    dense = host.build_cull_data(cam_pos=(0, 0, 25), draw_count=len(draws), cullingEnabled=1, clusterBackfaceEnabled=1)  # ... seen from outside
+    commands["lateDrawVisibility"][:n] = rng.integers(0, 2, n)
+    commands["taskCount"][:n:9] = rng.integers(0, 65, len(commands["taskCount"][:n:9]))
+    mvb0 = rng.integers(0, 2 ** 32, n * 2 + 3, dtype=np.uint64).astype(np.uint32)
+    pyr = oracle.Pyramid(256, 192)
+    depth = make_scene(seed=3)["depth"]
+    oracle.depthreduce(depth, pyr)
+    gp = P.DepthPyramid(ctx.device, 256, 192)
+    ctx.depthreduce(torch.from_numpy(depth).to(ctx.device), 256, 192, gp.desc)
+    dense["pyramidWidth"], dense["pyramidHeight"] = pyr.width, pyr.height
+    sparse = dense.copy()
+    sparse["view"][0][14] += np.float32(500.0)                 # the same scene far behind the far plane
+    totals = []
+    for late in (0, 1):
+        for coe in (0, 1):
+            for cbe in (0, 1):
+                for post in (0, 1):
+                    c = dense.copy()
+                    c["clusterOcclusionEnabled"], c["clusterBackfaceEnabled"], c["postPass"] = coe, cbe, post
+                    for _ in range(3):
+                        totals.append(_compare_cluster_pass(ctx, draws, meshlets, commands, n, c, late, mvb0, pyr, gp, soa))
+                    _compare_cluster_pass(ctx, draws, meshlets, commands, n, sparse, late, mvb0, pyr, gp, soa)
+    assert max(totals) > 0.3 * n * 64
