@@ -226,16 +226,18 @@ def main():
 def pmc_traffic(n_meshlets, args):
     """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the process being timed:
     they come from separate `rocprofv3 --pmc` passes over this same command (tools/pmc_traffic.sh), whose per-launch
-    means are committed as profiles/r01_pmc_traffic.json with the guide's gfx950 corrections already applied.  Used only
-    when the committed measurement is for this workload; otherwise null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-        if rec.get("meshlets_per_gpu") == n_meshlets and rec.get("meshlet_layout") == ("AoS24" if args.aos else "SoA12"):
-            return rec["cluster_mask_kernel"]["traffic_bytes"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE x2 per the gfx950 calibration)"
-    except (OSError, KeyError, ValueError):
-        pass
+    means are committed as profiles/rNN_pmc_traffic.json (the newest round's file is used) with the guide's gfx950
+    corrections already applied.  Used only when the committed measurement is for this workload; otherwise null."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+            if rec.get("meshlets_per_gpu") == n_meshlets and rec.get("meshlet_layout") == ("AoS24" if args.aos else "SoA12"):
+                return rec["cluster_mask_kernel"]["traffic_bytes"], "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE x2 per the gfx950 calibration)" % os.path.basename(path)
+        except (OSError, KeyError, ValueError):
+            continue
     return None, None
 
 
