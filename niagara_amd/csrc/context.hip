@@ -80,6 +80,7 @@ struct nv_context
 	uint32_t ccBlocksPerCU;
 	uint32_t dealScale;
 	uint32_t scatterTilesPerCU;
+	uint32_t hizLds; // stage the coarse pyramid levels in LDS for drawcull's late pass (experiments: measured slower)
 	uint32_t directPercent; // share of commands passing the filter above which the next launch skips the filter pass
 	int forceDirect;        // experiments build: -1 = by statistic, 0 / 1 = always filter / always direct
 	// command count of the previous clustercull launch, written by its kernel into mapped host memory (tuning hint)
@@ -211,6 +212,8 @@ int nv_create(nv_context** out_ctx, int device)
 	ctx->directPercent = 35; // measured crossover (config 3A geometry at several densities): ~36 % of the commands passing the filter
 	ctx->forceDirect = -1;
 #ifdef NV_EXPERIMENTS
+	if (const char* v = getenv("NV_HIZ_LDS"))
+		ctx->hizLds = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_DIRECT"))
 		ctx->forceDirect = atoi(v);
 	if (const char* v = getenv("NV_DIRECT_PERCENT"))
@@ -510,6 +513,18 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 	a.fusedReset = ctx->fusedReset;
 	a.fusedSubmit = ctx->fusedSubmit;
 	a.meshCount = ctx->meshesFrom == d_meshes ? ctx->meshCount : 0u;
+	// LDS-staged coarse pyramid levels for the late pass's HiZ probes: measured slower than reading them through L2 (a
+	// workgroup of 512 draws stages 22 KiB to serve the ~20 probes of its visible draws) — off unless asked for
+	a.stagedBase = ~0u;
+#ifdef NV_EXPERIMENTS
+	if (late && ctx->hizLds && pyramid && pyramid->levels)
+		for (uint32_t l = 0; l < pyramid->levels; ++l)
+			if (pyramid->totalTexels - pyramid->mipOffset[l] <= 5632u)
+			{
+				a.stagedBase = pyramid->mipOffset[l];
+				break;
+			}
+#endif
 	hipEvent_t e0 = prof_mark(ctx, (hipStream_t)stream);
 	rc = nv::launch_drawcull((hipStream_t)stream, a, late, task);
 	prof_push(ctx, NV_PROF_DRAWCULL, e0, prof_mark(ctx, (hipStream_t)stream));

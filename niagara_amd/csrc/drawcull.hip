@@ -26,6 +26,15 @@ constexpr int DC_WAVES = 4;
 constexpr int DC_THREADS = DC_WAVES * 64;
 constexpr int DC_BATCH = 2;                          // draws per lane of the decide kernel
 constexpr uint32_t DC_TILE = DC_THREADS * DC_BATCH;   // draws per workgroup of the decide kernel
+// LDS-staged coarse pyramid levels for the late pass's HiZ probes (north_star: "LDS-staged HiZ tiles"): implemented,
+// measured, and compiled into the experiments build only — 1 M draws with HiZ took 31.4 us with the tail of a 2048^2 pyramid
+// (levels 5..11, 5461 texels) staged per workgroup against 24.9 us reading the same texels through L2: a workgroup of 512
+// draws copies 22 KiB to serve the ~20 probes of its visible draws, and the LDS footprint costs a resident workgroup.
+#ifdef NV_EXPERIMENTS
+constexpr uint32_t DC_HIZ_TAIL = 5632; // texels a workgroup may stage (22 KiB)
+#else
+constexpr uint32_t DC_HIZ_TAIL = 1;
+#endif
 constexpr uint32_t DC_MESH_LDS = 64;  // meshes staged in LDS (13 KiB) when the table is registered and small enough
 
 
@@ -63,7 +72,8 @@ NV_DEV uint32_t lod_table_source(uint32_t k)
 // position, radius * scale}, i.e. the view-independent prefix of drawcull.comp.glsl:73-75 evaluated once at upload in the
 // reference's own operation order (bit-identical intermediates), d1.x = scale; only the view transform is left per pass.
 template <bool LATE, bool TASK, bool COMPACT, bool WORLD>
-NV_DEV DrawResult decide_draw(const DrawArgs& a, const char* meshBase, uint32_t di, const float4& d0, const float4& d1, const uint4& d2, uint32_t oldVis)
+NV_DEV DrawResult decide_draw(const DrawArgs& a, const char* meshBase, uint32_t di, const float4& d0, const float4& d1, const uint4& d2, uint32_t oldVis,
+                              const float* hizTail)
 {
 	const NvCullData& cd = a.cd;
 	DrawResult res = { 0, 0, oldVis };
@@ -96,7 +106,21 @@ NV_DEV DrawResult decide_draw(const DrawArgs& a, const char* meshBase, uint32_t 
 	visible = visible || cd.cullingEnabled == 0;
 
 	if (LATE && visible && cd.occlusionEnabled == 1)
-		visible = hiz_test(cd, a.pyr, c, radius);
+	{
+		// drawcull.comp.glsl:86-99.  Texels of the staged pyramid tail (levels >= a.stagedLevel, copied to LDS by the
+		// workgroup: north_star's "LDS-staged HiZ tiles") come from LDS, the finer levels from global memory.
+		const HizProbe p = hiz_prepare(cd, a.pyr, c, radius, a.pyr.mipOffset);
+		if (p.use & 16u)
+		{
+			const float* base = a.pyr.d_base;
+			const uint32_t sb = DC_HIZ_TAIL > 1 ? a.stagedBase : ~0u; // ~0u: nothing staged
+			const float t00 = p.o00 >= sb ? hizTail[p.o00 - sb] : base[p.o00];
+			const float t10 = p.o10 >= sb ? hizTail[p.o10 - sb] : base[p.o10];
+			const float t01 = p.o01 >= sb ? hizTail[p.o01 - sb] : base[p.o01];
+			const float t11 = p.o11 >= sb ? hizTail[p.o11 - sb] : base[p.o11];
+			visible = hiz_finish(p, t00, t10, t01, t11);
+		}
+	}
 
 	// TASK_CULL == 1 (src/config.h:8)
 	if (visible && (!LATE || cd.clusterOcclusionEnabled == 1 || oldVis == 0 || cd.postPass != 0))
@@ -279,6 +303,9 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 	// the Mesh table (center/radius, LOD errors, LOD ranges) is read by every draw: staged once per workgroup when
 	// nv_upload_meshes registered a table of at most DC_MESH_LDS meshes, otherwise gathered from global memory
 	__shared__ __attribute__((aligned(16))) uint32_t s_lodTable[MESH_LDS ? DC_MESH_LDS * DC_LOD_WORDS : 4];
+	// the coarse end of the depth pyramid (late pass, when the host asks for it): every level from a.stagedLevel up, at most
+	// DC_HIZ_TAIL texels (levels 5..11 of a 2048^2 pyramid = 5461)
+	__shared__ float s_hizTail[LATE ? DC_HIZ_TAIL : 1];
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
@@ -308,6 +335,14 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 		const uint32_t c = j * DC_THREADS + tid;
 		ld[j] = load_draw_record<SOA>(a, first + (c < n ? c : n - 1));
 	}
+	if (LATE && DC_HIZ_TAIL > 1 && a.stagedBase != ~0u)
+	{
+		const uint32_t n_tail = a.pyr.totalTexels - a.stagedBase;
+		for (uint32_t i = tid; i < n_tail && i < DC_HIZ_TAIL; i += DC_THREADS)
+			s_hizTail[i] = a.pyr.d_base[a.stagedBase + i];
+		if (!MESH_LDS)
+			__syncthreads();
+	}
 	const char* meshBase = stage_lod_commit<MESH_LDS>(a, st, s_lodTable);
 
 	// per wave-batch command counts -> LDS; merged per scatter tile below
@@ -323,7 +358,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 			if (NV_DBG(a, 1u)) // experiments: loads only
 				res.lodWord = __float_as_uint(ld[j].d0.x + ld[j].d1.x) + ld[j].d2.x + ld[j].oldVis == 12345u ? 0x100u : 0u;
 			else
-				res = decide_draw<LATE, TASK, MESH_LDS, SOA>(a, meshBase, first + c, ld[j].d0, ld[j].d1, ld[j].d2, ld[j].oldVis);
+				res = decide_draw<LATE, TASK, MESH_LDS, SOA>(a, meshBase, first + c, ld[j].d0, ld[j].d1, ld[j].d2, ld[j].oldVis, s_hizTail);
 			a.results[first + c] = (uint8_t)((res.lodWord & 7u) | ((res.lodWord >> 8 & 1u) << 3) | ((ld[j].oldVis != 0 ? 1u : 0u) << 4));
 			count = res.count;
 		}
