@@ -291,6 +291,42 @@ def cluster_config(ctx, iters, label, n_draws=156250, cpd=10, aos=False, scene_r
                 meshlets_per_s=m / (wall * 1e-6), parity=verdict(same))
 
 
+def config_task(ctx, iters, n_draws=15625, cpd=10, late=0):
+    """the task-shader form of the cluster cull (meshlet.task.glsl:53-149, nv_taskcull): per command a compacted 64-entry payload
+    + count instead of the global ordered list; config 3A's 10 M meshlets"""
+    dev = ctx.device
+    draws, meshlets, commands, n = synth.cluster_scene(n_draws, cpd)
+    cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, clusterBackfaceEnabled=1)
+    db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+    ctx.upload_meshlets(mlb, len(meshlets))
+    dccb = torch.from_numpy(synth.count4_for(n).view(np.int32).copy()).to(dev)
+    ncmd = len(commands)
+    payloads = torch.zeros(ncmd * 64, dtype=torch.int32, device=dev)
+    counts = torch.zeros(ncmd, dtype=torch.int32, device=dev)
+
+    def step(i):
+        ctx.taskcull(cd, late, dcb, dccb, db, mlb, None, None, payloads, counts)
+
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        step(i)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    po, co = np.zeros(ncmd * 64, np.uint32), np.zeros(ncmd, np.uint32)
+    oracle.taskcull(cd, late, commands, synth.count4_for(n), draws, meshlets, None, None, po, co)
+    cg, pg = counts.cpu().numpy().view(np.uint32), payloads.cpu().numpy().view(np.uint32).reshape(ncmd, 64)
+    same = (cg == co).all() and all((pg[i, :co[i]] == po.reshape(ncmd, 64)[i, :co[i]]).all() for i in np.nonzero(co)[0][:20000])
+    m = n * 64
+    algo = m * 12 + n * 68 + int(co.sum()) * 4 + ncmd * 4
+    return dict(config="T: task-shader form (nv_taskcull), %d meshlets" % m, visible=int(co.sum()), call_us=us, algorithmic_bytes=algo,
+                achieved_GBs=algo / us / 1e3, frac=algo / us / 1e3 / HBM, meshlets_per_s=m / (us * 1e-6), parity=verdict(same))
+
+
 def verdict(same):
     if not same:
         raise SystemExit("parity FAILURE against the CPU oracle")
@@ -305,6 +341,7 @@ if __name__ == "__main__":
     ctx = P.Context(0)
     runs = {"2": lambda: config2(ctx, a.iters), "2_aos": lambda: config2(P.Context(0), a.iters, soa=False), "2l": lambda: config2_late(ctx, a.iters), "3b": lambda: config3b(ctx, a.iters), "3b_fused": lambda: config3b(P.Context(0), a.iters, fused=True), "4": lambda: config4(ctx, a.iters),
             "4b": lambda: config4(ctx, a.iters, size=1024), "n4": lambda: config_n4(ctx, a.iters),
+            "task": lambda: config_task(ctx, a.iters),
             "big": lambda: cluster_config(ctx, max(5, a.iters // 3), "3A x10 (SoA mirror)"),
             "big_aos": lambda: cluster_config(P.Context(0), max(5, a.iters // 3), "3A x10 (AoS in place)", aos=True),
             # dense visibility: the same 10 M meshlets in a cloud of radius 40 seen from z = +60 (87 % of the
