@@ -163,6 +163,7 @@ int main(int argc, char** argv)
 
 	CHECK_NV(nv_upload_meshlets(ctx, stream, mlb, meshletCount));
 	CHECK_NV(nv_upload_meshes(ctx, stream, mb, meshCount));
+	CHECK_NV(nv_upload_draws(ctx, stream, db, drawCount, mb)); // the draw mirror (world spheres): next to uploadBuffer(db), src/niagara.cpp:1052
 	CHECK_NV(nv_set_option(ctx, NV_OPT_FUSED_COUNT_RESET, fused));
 	CHECK_NV(nv_set_option(ctx, NV_OPT_FUSED_SUBMIT, fused));
 
