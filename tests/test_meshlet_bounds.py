@@ -213,3 +213,77 @@ def test_scene_with_gpu_generated_bounds_through_the_passes():
         assert seen > 1000
     finally:
         ctx.close()
+
+
+KITTEN = "/root/reference/data/kitten.obj"
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(KITTEN), reason="the reference tree (data/kitten.obj) is not mounted here")
+def test_kitten_meshlets_through_the_cluster_cull():
+    """niagara's own asset.  kitten.obj (read where the reference tree is mounted, never copied) is cut into
+    meshlets in face order, the bounds come from orc_meshlet_bounds, and 600 instances go through the oracle's cluster cull:
+    every meshlet the cull drops has no front-facing triangle inside the frustum (per-triangle ground truth in fp64), and
+    sphere / cone contain the geometry.  The GPU suite generates the same bounds with nv_meshlet_bounds on the torus; the
+    asset itself does not travel to the GPU box."""
+    pos, faces = [], []
+    for line in open(KITTEN):
+        if line.startswith("v "):
+            pos.append([float(x) for x in line.split()[1:4]])
+        elif line.startswith("f "):
+            faces.append([int(t.split("/")[0]) - 1 for t in line.split()[1:4]])
+    pos, faces = np.array(pos, np.float32), np.array(faces, np.int64)
+    assert len(pos) == 14472 and len(faces) == 28944
+    # spatially coherent order (the clusterizer's job): sort faces by the Morton code of their centroid
+    cen = pos[faces].mean(axis=1)
+    g = np.clip(((cen - cen.min(0)) / (np.ptp(cen, axis=0) + 1e-9) * 1023).astype(np.int64), 0, 1023)
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3; return (v | (v << 2)) & 0x09249249
+    order = np.argsort(spread(g[:, 0]) | (spread(g[:, 1]) << 1) | (spread(g[:, 2]) << 2), kind="stable")
+    meshlets, data, vertices = build_meshlets(pos, faces[order])
+    f = oracle.meshlet_bounds(vertices, data, meshlets, want_float=True)
+    assert 300 < len(meshlets) < 2000 and (f[:, 7] < 1).mean() > 0.5
+    for k in range(0, len(meshlets), 7):
+        p, tri = meshlet_triangles(meshlets, data, vertices, k)
+        c, r = f[k, :3].astype(np.float64), float(f[k, 3])
+        assert (np.linalg.norm(tri.reshape(-1, 3) - c, axis=1) <= r * (1 + 1e-5) + 1e-7).all()
+    # 600 kitten instances around the camera through clustercull (commands: one per 64 meshlets of an instance)
+    n_draws = 600
+    draws = host.synth_draws(n_draws, 1, 12.0)
+    cpd = (len(meshlets) + 63) // 64
+    commands = np.zeros((n_draws * cpd + 63) // 64 * 64, dtype=L.TASKCMD)
+    k = np.arange(n_draws * cpd)
+    commands["drawId"][:len(k)] = k // cpd
+    commands["taskOffset"][:len(k)] = (k % cpd) * 64
+    commands["taskCount"][:len(k)] = np.minimum(64, len(meshlets) - (k % cpd) * 64)
+    cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, clusterBackfaceEnabled=1, draw_distance=40.0)
+    cib, cc4 = np.zeros(len(commands) * 64, np.uint32), np.zeros(4, np.uint32)
+    oracle.clustercull(cd, 0, commands, synth.count4_for(len(k)), draws, meshlets, None, None, cib, cc4)
+    visible = set(int(x) for x in cib[:cc4[0]])
+    assert 0.02 * len(k) * 64 < len(visible) < 0.9 * n_draws * len(meshlets)
+    V = cd["view"][0].astype(np.float64).reshape(4, 4).T
+    fr, zn, zf = cd["frustum"][0].astype(np.float64), float(cd["znear"][0]), float(cd["zfar"][0])
+    rng = np.random.default_rng(2)
+    checked = 0
+    for ci in rng.choice(len(k), 400, replace=False):
+        d = draws[commands["drawId"][ci]]
+        q, s, t = d["orientation"].astype(np.float64), float(d["scale"]), d["position"].astype(np.float64)
+        for lane in range(int(commands["taskCount"][ci])):
+            if (int(ci) | (lane << 24)) in visible:
+                continue
+            mi = int(commands["taskOffset"][ci]) + lane
+            _, tri = meshlet_triangles(meshlets, data, vertices, mi)
+            qv, w = q[:3], q[3]
+            pts = tri.reshape(-1, 3)
+            rot = pts + 2.0 * np.cross(qv, np.cross(qv, pts) + w * pts)
+            world = rot * s + t
+            view = (V[:3, :3] @ world.T).T + V[:3, 3]
+            tv, tw = view.reshape(-1, 3, 3), world.reshape(-1, 3, 3)
+            # facing in world space (the view matrix mirrors z, which would flip a normal recomputed from view-space corners;
+            # the shader transforms the object-space axis as a vector): camera at the origin
+            n = np.cross(tw[:, 1] - tw[:, 0], tw[:, 2] - tw[:, 0])
+            front = np.einsum("ij,ij->i", tw[:, 0], n) < -1e-7
+            inside = ((tv[..., 2] * fr[1] - np.abs(tv[..., 0]) * fr[0] > 1e-5) & (tv[..., 2] * fr[3] - np.abs(tv[..., 1]) * fr[2] > 1e-5)
+                      & (tv[..., 2] > zn + 1e-5) & (tv[..., 2] < zf - 1e-5)).any(axis=1)
+            assert not (front & inside).any(), (int(ci), lane)          # a culled meshlet hides nothing that could be seen
+            checked += 1
+    assert checked > 3000
