@@ -391,7 +391,8 @@ constexpr uint32_t CC_CHUNK_LATE = NV_CC_CHUNK_LATE;
 // workgroups' start-up chains is served sooner.  The host picks per launch from the command count of the PREVIOUS
 // clustercull (the kernel leaves it in a mapped host word; frame coherence; a wrong guess only costs speed).
 constexpr uint32_t CC_SHALLOW_COMMANDS = 500000;
-constexpr int CC_DB = 6;         // ring slots of the exact pass
+constexpr int CC_DB = 3;         // ring slots of the exact pass (r2 sweep on 3A: 6 slots 30.2 us / step, 3 slots 29.3; pass B is
+                                 // short in the sparse case and a deep ring is mostly redundant loads at its end)
 
 // ---- conservative frustum filter (exactness-preserving early-out)
 // The reference's sphere transform costs ~58 un-fused fp32 operations per meshlet and must be reproduced bit for bit
@@ -1165,7 +1166,8 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				// half of the command visited CC_PT visits ago, issue this command's texels, reissue the slot.  Every visit
 				// issues the same CC_UL loads (inactive probes and empty slots fetch texel 0 / re-read the last command), so
 				// all waits are counted; the first round, which follows CC_DL ring issues without texels, has its own counts.
-				constexpr int CC_DL = 4, CC_PT = 2;                  // ring slots, texel sets in flight
+				constexpr int CC_DL = 2, CC_PT = 1;                  // ring slots, texel sets in flight (r2 sweep, config 4: 4 + 2 gave
+				                                                     // 42.1 us and scratch spills, 2 + 1 gives 40.0 us and none)
 				constexpr int CC_RL = BITS ? 3 : 2, CC_UL = 4 + CC_RL; // loads per ring issue, per visit
 				static_assert(CC_DL % CC_PT == 0, "the texel set of a visit is chosen statically");
 				uint32_t curDraw = ~0u, certDraw = ~0u;
