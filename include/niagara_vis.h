@@ -177,14 +177,15 @@ const char* nv_version(void);
 int nv_status(nv_context* ctx, void* stream);
 
 /* Kernel-level timing with HIP events recorded on the launch stream (replaces the vkCmdWriteTimestamp pairs around
- * each pass, src/niagara.cpp:1537,1573,1705,1732).  While enabled, nv_clustercull brackets its cull kernel and its
- * scatter kernel, nv_drawcull and nv_depthreduce their launches.  nv_profile_read synchronises the recorded events,
+ * each pass, src/niagara.cpp:1537,1573,1705,1732).  While enabled, nv_clustercull brackets its cull kernel, its
+ * occlusion stage (late pass) and its scatter kernel, nv_drawcull and nv_depthreduce their launches.  nv_profile_read synchronises the recorded events,
  * returns the accumulated milliseconds and launch count per slot and resets the accumulators. */
 #define NV_PROF_CLUSTER_CULL 0
 #define NV_PROF_CLUSTER_SCATTER 1
 #define NV_PROF_DRAWCULL 2
 #define NV_PROF_DEPTHREDUCE 3
-#define NV_PROF_SLOTS 4
+#define NV_PROF_CLUSTER_HIZ 4 /* late pass with HiZ: the occlusion stage between the cull and the scatter kernel */
+#define NV_PROF_SLOTS 5
 int nv_profile_enable(nv_context* ctx, int enabled);
 int nv_profile_read(nv_context* ctx, float out_ms[NV_PROF_SLOTS], uint32_t out_count[NV_PROF_SLOTS]);
 

@@ -53,7 +53,7 @@ _SIGS = {
     "nv_status": (_i, [_vp, _vp]),
     "nv_set_option": (_i, [_vp, _i, _i]),
     "nv_profile_enable": (_i, [_vp, _i]),
-    "nv_profile_read": (_i, [_vp, C.POINTER(C.c_float * 4), C.POINTER(C.c_uint32 * 4)]),
+    "nv_profile_read": (_i, [_vp, C.POINTER(C.c_float * 5), C.POINTER(C.c_uint32 * 5)]),
     "nv_upload_meshlets": (_i, [_vp, _vp, _vp, _u32]),
     "nv_upload_meshes": (_i, [_vp, _vp, _vp, _u32]),
     "nv_upload_draws": (_i, [_vp, _vp, _vp, _u32, _vp]),

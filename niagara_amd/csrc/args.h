@@ -56,6 +56,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 // 8 lines cost 13 us, 78 k into 16 lines 20 us), spread over hundreds of lines they are free.
 constexpr uint32_t CC_MAX_SCATTER_TILES = 512;
 constexpr uint32_t CC_COUNT_STRIDE = 16; // words between two tile counters
+constexpr uint32_t CC_LISTS = 256;       // sub-lists of the late pass's survivor-command list (cluster_hiz_kernel)
 struct ClusterCounts
 {
 	uint32_t parity;   // read by the cull kernel; flipped by one thread of the scatter kernel
@@ -63,6 +64,9 @@ struct ClusterCounts
 	uint32_t base;     // the count word as the pass found it (0 with the fused reset), snapshot by the cull kernel: the scatter
 	                   // kernel's last tile overwrites the live word while other tiles may not have started yet
 	uint32_t pad[29];
+	uint32_t listOverflow[2]; // late pass with HiZ, banked like `counts`: a sub-list of ClusterArgs::candList ran out of room
+	uint32_t pad2[30];
+	uint32_t listCount[2][CC_LISTS * CC_COUNT_STRIDE]; // entries per sub-list, one counter per 64-byte line
 	uint32_t counts[2][CC_MAX_SCATTER_TILES * CC_COUNT_STRIDE];
 };
 
@@ -91,6 +95,8 @@ struct ClusterArgs
 	uint32_t* __restrict__ clusterCount4;
 	uint32_t* __restrict__ payloadCounts; // taskcull only
 	uint64_t* __restrict__ masks; // scratch: one 64-bit ballot per task command
+	uint32_t* __restrict__ candList; // scratch (late pass with HiZ): the commands that have frustum / cone survivors, CC_LISTS sub-lists in no particular order
+	uint32_t listStride;             // entries of room per sub-list
 	ClusterCounts* __restrict__ tileCounts;
 	uint32_t scatterTiles; // grid of the scatter kernel (<= CC_MAX_SCATTER_TILES)
 	uint32_t generations;  // workgroups of the cull kernel per CU (its grid = generations x CUs)
@@ -104,6 +110,7 @@ struct ClusterArgs
 #endif
 	uint32_t fusedReset; // NV_OPT_FUSED_COUNT_RESET
 	uint32_t fusedSubmit; // NV_OPT_FUSED_SUBMIT
+	uint32_t deferHiz;   // late pass with HiZ: the cull kernel leaves frustum / cone ballots and no tile counts, cluster_hiz_kernel finishes
 	unsigned long long* countsSink; // nv_set_counts_sink (nullptr: off)
 };
 

@@ -939,7 +939,10 @@ NV_DEV uint32_t make_dealing(uint32_t numChunks, uint32_t wave, uint32_t lane, u
 // kernels count what the filter rejects, or would have rejected, and leave the count in a mapped host word): a pass over
 // the commands of draws that drawcull already found visible — the production case — has nothing for the filter to remove,
 // and streaming its 8 bytes first only to re-read them with the cone costs a third of the launch.
-template <bool LATE, bool SOA, bool BITS, int CC_DA, bool DIRECT = false>
+// DEFER (late pass with HiZ: the early form, LATE = BITS = false): frustum / cone ballots only, no tile counts — the occlusion
+// stage (cluster_hiz_kernel) finishes the commands that have survivors; the visibility bits of the commands without any are
+// cleared here (clustercull.comp.glsl:125-131 with visible == false), so that the stage touches 3 % of the commands, not all.
+template <bool LATE, bool SOA, bool BITS, int CC_DA, bool DIRECT = false, bool DEFER = false>
 __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs a)
 {
 	const uint32_t lane = threadIdx.x & 63u;
@@ -1446,6 +1449,34 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 		// store sits between counted loads
 		if (updateBits) // clustercull.comp.glsl:125-131 for the whole segment
 			update_segment_visibility(a, lane < cnt && myIdx < numCmds, r.meshletVisibilityOffset, r.taskCount, ((uint64_t)visHi << 32) | visLo);
+		if (DEFER)
+		{
+			// no survivor of frustum and cone: nothing is visible, whatever the pyramid holds
+			const bool liveCmd = lane < cnt && myIdx < numCmds;
+			update_segment_visibility(a, liveCmd && (maskLo | maskHi) == 0, r.meshletVisibilityOffset, r.taskCount, 0ull);
+			// the others go on the occlusion stage's list: one returning add per segment that has any.  CC_LISTS sub-lists
+			// with a counter each (one list head measured +10 us on this kernel: ~2000 adds to one address are served one
+			// after the other at the memory side); the order within a sub-list is whatever the adds make it — the stage
+			// writes per command, so the results do not depend on it.  A sub-list that runs out of room raises a flag
+			// and the stage scans all commands instead: the list only saves time.
+			const uint64_t has = __ballot(liveCmd && (maskLo | maskHi) != 0);
+			if (has)
+			{
+				const uint32_t n = (uint32_t)__builtin_popcountll(has);
+				const uint32_t sub = w & (CC_LISTS - 1u);
+				uint32_t slot = 0;
+				if (lane == 0)
+					slot = atomicAdd(&a.tileCounts->listCount[bank][sub * CC_COUNT_STRIDE], n);
+				slot = __builtin_amdgcn_readfirstlane(slot);
+				if (slot + n <= a.listStride)
+				{
+					if (has >> lane & 1ull)
+						a.candList[sub * a.listStride + slot + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u))] = myIdx;
+				}
+				else if (lane == 0)
+					atomicOr(&a.tileCounts->listOverflow[bank], 1u);
+			}
+		}
 		if (lane < cnt && myIdx < numCmds)
 		{
 			const uint64_t m = ((uint64_t)maskHi << 32) | maskLo;
@@ -1467,7 +1498,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				if (lane & 3u)
 					pc = 0;
 			}
-			if (pc && !NV_DBG(a, 2048u)) // bit 11 (experiments): no tile counts
+			if (pc && !DEFER && !NV_DBG(a, 2048u)) // DEFER: the occlusion stage counts the final ballots; bit 11 (experiments): no tile counts
 				atomicAdd(&a.tileCounts->counts[bank][tileOf * CC_COUNT_STRIDE], pc);
 		}
 	}
@@ -1560,10 +1591,13 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 	{
 		a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE] = 0;
 		a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE + 1] = 0;
+		if (i < CC_LISTS)
+			a.tileCounts->listCount[bank ^ 1u][i * CC_COUNT_STRIDE] = 0;
 	}
 	if (tile == 0 && tid == 0)
 	{
 		a.tileCounts->parity = bank ^ 1u;
+		a.tileCounts->listOverflow[bank ^ 1u] = 0;
 		if (numTiles == 0 && a.hostHint)
 			__hip_atomic_store(a.hostHint + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		if (numTiles == 0) // no commands at all: the count word keeps its base, the submit words describe an empty grid
@@ -1721,6 +1755,286 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Late pass with HiZ, stage 2 (between the cull kernel and the scatter kernel): clustercull.comp.glsl:110-131 with one
+// LANE per frustum / cone survivor.
+//
+// Inside the cull kernel the occlusion probe costs a wave three dependent memory latencies per COMMAND (bounds -> texel
+// addresses -> texels) with only the command's survivors active, and the launch ended with the few waves that drew the
+// visible part of the scene (r1 / r2 measurements: 40-43 us against 25 us for the same pass without the probe, whatever
+// the ring depths, chunk sizes or priorities).  So the late pass defers it: the cull kernel runs in its early form
+// (frustum + cone only, no visibility words, no tile counts: ClusterArgs::deferHiz) and leaves the survivors' ballots;
+// this kernel compacts the survivors of CH_CMDS commands through LDS, probes them lane-parallel with the reference's own
+// sphere arithmetic (lane_sphere + hiz_test: the same functions the one-stage form called), clears the ballot bits of
+// the occluded ones, and then does per command — one command per lane — what the cull kernel's epilogue did: the
+// visibility-bit update, the `skip` of clusters the early pass already drew, the final ballot and the tile count.
+constexpr int CH_THREADS = 256; // lanes probing
+constexpr int CH_CMDS = 128;    // commands per block (threads 0 .. CH_CMDS - 1 own one each)
+constexpr int CH_U = 8;         // survivors per lane in flight: a round probes CH_THREADS * CH_U of the block's survivors
+
+// LDS-only barrier: __syncthreads() also waits for the global loads in flight (vmcnt counts them on gfx9), and the point
+// of this kernel is to keep them in flight across the LDS hand-overs
+#define NV_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// The kernel is a chain of memory latencies, not of bytes (10 M meshlets, config 4: 198 k survivors in 3 % of the
+// commands, up to ~1600 in one block), so it is laid out to be three latencies long whatever a block holds:
+//   commands + ballots  ->  { MeshDraws of the commands with survivors, their visibility words, bounds of CH_U survivors
+//   per lane }  ->  4 x CH_U texels per lane  ->  stores.
+// One round: U survivors per lane, straight-line — every load is unconditional (slots past the block's last survivor re-read
+// it, inactive probes fetch clamped texels) so that hipcc can count its waits and all U bounds, then all 4 U texels, are in
+// flight together.  The first round also hands the MeshDraws over through LDS, behind the bounds loads.
+template <int U, bool SOA, bool FIRST>
+NV_DEV void hiz_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint32_t tid, bool ownsDraw, const float4& d0, const float4& d1,
+                      const uint16_t* s_list, const uint32_t* s_taskOffset, float4 (*s_draw)[2], const uint32_t* s_mip, uint32_t* s_visLo, uint32_t* s_visHi)
+{
+	const float* __restrict__ texels = a.pyr.d_base;
+	uint32_t e[U];
+	uint2 b[U];
+#pragma unroll
+	for (int k = 0; k < U; ++k)
+	{
+		const uint32_t s = base + k * CH_THREADS + tid;
+		e[k] = s_list[s < total ? s : total - 1u];
+		const uint32_t mi = s_taskOffset[e[k] >> 6] + (e[k] & 63u);
+		if (SOA)
+			b[k] = a.soaBounds[mi];
+		else
+			b[k] = *reinterpret_cast<const uint2*>(a.meshlets + mi);
+	}
+	if (FIRST)
+	{
+		if (ownsDraw)
+		{
+			s_draw[tid][0] = d0;
+			s_draw[tid][1] = d1;
+		}
+		NV_LDS_BARRIER();
+	}
+	float depth[U];
+	uint32_t use[U];
+	float t00[U], t10[U], t01[U], t11[U];
+#pragma unroll
+	for (int k = 0; k < U; ++k)
+	{
+		const float4 q0 = s_draw[e[k] >> 6][0], q1 = s_draw[e[k] >> 6][1];
+		DrawUniform u;
+		u.pos = { q0.x, q0.y, q0.z };
+		u.scale = q0.w;
+		u.q = { q1.x, q1.y, q1.z };
+		u.qw = q1.w;
+		LaneData l;
+		l.b0 = b[k].x;
+		l.b1 = b[k].y;
+		l.cone = 0;
+		l.mvbWord = 0;
+		f3 c;
+		float r;
+		lane_sphere(a.cd, u, l, c, r);
+		const HizProbe p = hiz_prepare(a.cd, a.pyr, c, r, s_mip);
+		use[k] = p.use;
+		depth[k] = p.depthSphere;
+		t00[k] = texels[p.o00]; // in range also for an inactive probe (hiz_prepare)
+		t10[k] = texels[p.o10];
+		t01[k] = texels[p.o01];
+		t11[k] = texels[p.o11];
+	}
+#pragma unroll
+	for (int k = 0; k < U; ++k)
+	{
+		const uint32_t s = base + k * CH_THREADS + tid;
+		const HizProbe p = { 0, 0, 0, 0, use[k], depth[k] };
+		if (!hiz_finish(p, t00[k], t10[k], t01[k], t11[k]) && s < total)
+		{
+			const uint32_t owner = e[k] >> 6, bit = e[k] & 63u;
+			atomicAnd(bit < 32u ? &s_visLo[owner] : &s_visHi[owner], ~(1u << (bit & 31u)));
+		}
+	}
+}
+
+template <bool SOA, bool BITS>
+__global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
+{
+	__shared__ uint32_t s_mip[NV_MAX_MIPS];
+	__shared__ uint32_t s_visLo[CH_CMDS], s_visHi[CH_CMDS], s_taskOffset[CH_CMDS];
+	__shared__ float4 s_draw[CH_CMDS][2];
+	__shared__ uint16_t s_list[CH_CMDS * 64]; // (command within the block << 6) | lane, in command-major order
+	__shared__ uint32_t s_part[CH_THREADS / 64];
+
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63u;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	{
+		uint32_t off = 0;
+#pragma unroll
+		for (uint32_t i = 0; i < NV_MAX_MIPS; ++i)
+			off = tid == i ? a.pyr.mipOffset[i] : off;
+		if (tid < NV_MAX_MIPS)
+			s_mip[tid] = off;
+	}
+	// The cull kernel listed the commands that have survivors in CC_LISTS sub-lists; block b works on sub-list b % CC_LISTS
+	// together with the gridDim.x / CC_LISTS - 1 other blocks of that sub-list, in chunks: 8 listed commands per block while
+	// that covers the sub-list (a visible draw's ~10 commands bring up to 640 survivors: two or three per lane), more for
+	// a longer one.  The first chunk's entries are fetched together with the sub-list's length (entries past its end are
+	// ignored).  If a sub-list overflowed, every block scans its share of ALL commands instead.
+	const uint32_t sub = blockIdx.x % CC_LISTS, rank0 = blockIdx.x / CC_LISTS, sharers = gridDim.x / CC_LISTS;
+	const uint32_t* __restrict__ list = a.candList + sub * a.listStride;
+	const uint32_t specEntry = tid < 8u ? list[rank0 * 8u + tid] : 0u; // (in range: the buffer is padded)
+	const uint32_t bank = load_uniform_u32(&a.tileCounts->k2parity) & 1u; // the cull kernel of this pass wrote it
+	const uint32_t count0 = load_uniform_u32(&a.tileCounts->listCount[0][sub * CC_COUNT_STRIDE]);
+	const uint32_t count1 = load_uniform_u32(&a.tileCounts->listCount[1][sub * CC_COUNT_STRIDE]);
+	const uint32_t over0 = load_uniform_u32(&a.tileCounts->listOverflow[0]), over1 = load_uniform_u32(&a.tileCounts->listOverflow[1]);
+	const uint32_t numCmds = indirect_command_count(a);
+	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles);
+	const bool scan = (bank ? over1 : over0) != 0;
+	const uint32_t items = scan ? numCmds : (bank ? count1 : count0);
+	const uint32_t share = scan ? gridDim.x : sharers;
+	uint32_t per = (items + share - 1u) / share;
+	per = per < 8u ? 8u : (per > (uint32_t)CH_CMDS ? (uint32_t)CH_CMDS : per);
+	const uint32_t firstChunk = scan ? blockIdx.x : rank0;
+
+	for (uint32_t chunk = firstChunk; chunk * per < items; chunk += share)
+	{
+		const uint32_t li = chunk * per + tid;
+		const bool live = tid < per && li < items;
+		uint32_t idx = 0;
+		if (live)
+			idx = scan ? li : (per == 8u && chunk == rank0 ? specEntry : list[li]);
+		uint64_t cand = 0;
+		uint32_t drawId = 0, taskOffset = 0, taskCount = 0, lateDrawVisibility = 0, mvo = 0;
+		if (live && idx < numCmds)
+		{
+			cand = a.masks[idx];
+			const uint32_t* p = reinterpret_cast<const uint32_t*>(a.commands + idx);
+			drawId = p[0];
+			taskOffset = p[1];
+			taskCount = p[2];
+			lateDrawVisibility = p[3];
+			mvo = p[4];
+		}
+		// second latency, part 1: the command's MeshDraw and its <= 3 visibility words.  Unconditional, clamped loads (dummy
+		// commands and the lanes without a command read element 0): a branch around a load makes hipcc fall back to
+		// s_waitcnt vmcnt(0) at the join, and the loads behind it would wait for these
+		const float4* dp = reinterpret_cast<const float4*>(a.draws + (taskCount ? drawId : 0u));
+		const float4 d0 = dp[0], d1 = dp[1];
+		const uint32_t sh = mvo & 31u;
+		uint32_t oldw[3];
+		{
+			const uint32_t w0 = taskCount ? mvo >> 5 : 0u, wLast = taskCount ? (mvo + taskCount - 1u) >> 5 : 0u;
+#pragma unroll
+			for (uint32_t j = 0; j < 3; ++j) // word j holds the bits of lanes [32 j - sh, 32 j - sh + 32)
+				oldw[j] = a.mvb[w0 + j < wLast ? w0 + j : wLast];
+		}
+
+		const uint32_t pc = (uint32_t)__builtin_popcountll(cand);
+		uint32_t incl = pc;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1)
+		{
+			const uint32_t t = __shfl_up(incl, o, 64);
+			if ((int)lane >= o)
+				incl += t;
+		}
+		if (lane == 63)
+			s_part[wave] = incl;
+		if (tid < CH_CMDS)
+		{
+			s_visLo[tid] = (uint32_t)cand;
+			s_visHi[tid] = (uint32_t)(cand >> 32);
+			s_taskOffset[tid] = taskOffset;
+		}
+		NV_LDS_BARRIER();
+		uint32_t excl = incl - pc, total = 0;
+#pragma unroll
+		for (int w = 0; w < CH_THREADS / 64; ++w)
+		{
+			const uint32_t part = s_part[w];
+			excl += w < (int)wave ? part : 0u;
+			total += part;
+		}
+		for (uint64_t rest = cand; rest; rest &= rest - 1)
+			s_list[excl++] = (uint16_t)((tid << 6) | (uint32_t)__builtin_ctzll(rest));
+		NV_LDS_BARRIER();
+
+		// ---- one survivor per lane and slot: clustercull.comp.glsl:72-76 (sphere) and :110-123 (probe).  The first round is
+		// not a loop body: at a loop header hipcc merges the wait state of the back edge into it and waits for everything
+		// in flight (the MeshDraw and visibility words) before the first bounds load.
+#define NV_HIZ_ROUND(FIRST, base)                                                                                                                      \
+	do                                                                                                                                                 \
+	{                                                                                                                                                  \
+		const uint32_t rem = total - (base);                                                                                                           \
+		if (rem > 4u * CH_THREADS)                                                                                                                     \
+			hiz_round<8, SOA, FIRST>(a, base, total, tid, cand != 0, d0, d1, s_list, s_taskOffset, s_draw, s_mip, s_visLo, s_visHi);   \
+		else if (rem > 2u * CH_THREADS)                                                                                                                \
+			hiz_round<4, SOA, FIRST>(a, base, total, tid, cand != 0, d0, d1, s_list, s_taskOffset, s_draw, s_mip, s_visLo, s_visHi);   \
+		else if (rem > CH_THREADS)                                                                                                                     \
+			hiz_round<2, SOA, FIRST>(a, base, total, tid, cand != 0, d0, d1, s_list, s_taskOffset, s_draw, s_mip, s_visLo, s_visHi);   \
+		else                                                                                                                                           \
+			hiz_round<1, SOA, FIRST>(a, base, total, tid, cand != 0, d0, d1, s_list, s_taskOffset, s_draw, s_mip, s_visLo, s_visHi);   \
+	} while (0)
+		if (total == 0) // (uniform) nothing survived frustum and cone in this block: the cull kernel has cleared the bits
+			continue;
+		{
+			NV_HIZ_ROUND(true, 0u);
+			for (uint32_t base = CH_THREADS * CH_U; base < total; base += CH_THREADS * CH_U)
+				NV_HIZ_ROUND(false, base);
+		}
+#undef NV_HIZ_ROUND
+		NV_LDS_BARRIER();
+
+		// ---- one command per lane: `visible` is final.  clustercull.comp.glsl:97-99 (skip what the early pass drew),
+		// :125-131 (visibility bits: as update_segment_visibility, from the words loaded above — only this command's own
+		// bits of them are used, and nobody else writes those), the final ballot and the tile count.
+		uint64_t m = 0;
+		if (cand) // (commands without survivors: done by the cull kernel)
+		{
+			const uint64_t vis = ((uint64_t)s_visHi[tid] << 32) | s_visLo[tid];
+			const uint64_t valid = taskCount >= 64u ? ~0ull : (1ull << taskCount) - 1ull;
+			const uint64_t setAll = vis & valid, clrAll = valid & ~vis;
+			uint64_t old = 0;
+			uint32_t* words = a.mvb + (mvo >> 5);
+#pragma unroll
+			for (int j = 0; j < 3; ++j)
+			{
+				const int lo = 32 * j - (int)sh;
+				if (lo >= (int)taskCount)
+					break;
+				uint32_t setw, clrw;
+				if (lo >= 0)
+				{
+					old |= (uint64_t)oldw[j] << lo;
+					setw = (uint32_t)(setAll >> lo);
+					clrw = (uint32_t)(clrAll >> lo);
+				}
+				else
+				{
+					old |= (uint64_t)(oldw[j] >> (-lo));
+					setw = (uint32_t)(setAll << (-lo));
+					clrw = (uint32_t)(clrAll << (-lo));
+				}
+				setw &= ~oldw[j]; // only bits that change
+				clrw &= oldw[j];
+				if ((setw | clrw) == 0)
+					continue;
+				if (lo >= 0 && (uint32_t)lo + 32u <= taskCount) // the whole word belongs to this command: no other writer
+					words[j] = (oldw[j] & ~clrw) | setw;
+				else
+				{
+					if (clrw)
+						atomicAnd(words + j, ~clrw);
+					if (setw)
+						atomicOr(words + j, setw);
+				}
+			}
+			m = vis;
+			if (BITS && lateDrawVisibility == 1)
+				m &= ~old;
+			a.masks[idx] = m;
+		}
+		if (m) // the listed commands come in no particular order: one add per command
+			atomicAdd(&a.tileCounts->counts[bank][(idx / T2) * CC_COUNT_STRIDE], (uint32_t)__builtin_popcountll(m));
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // task-shader form (meshlet.task.glsl:135-143): survivors compacted per command into its 64-entry payload
 template <bool LATE, bool SOA>
 __global__ __launch_bounds__(CC_THREADS) void taskcull_kernel(ClusterArgs a)
@@ -1834,7 +2148,9 @@ template <bool LATE, bool SOA, int DEPTH, bool DIRECT = false>
 static void launch_cc(hipStream_t stream, const ClusterArgs& a, uint32_t gridBlocks)
 {
 	dim3 grid(gridBlocks), block(CC_THREADS);
-	if (a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0)
+	if (!LATE && a.deferHiz)
+		hipLaunchKernelGGL((cluster_mask_kernel<false, SOA, false, DEPTH, DIRECT, true>), grid, block, 0, stream, a);
+	else if (a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0)
 		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, true, DEPTH, DIRECT>), grid, block, 0, stream, a);
 	else
 		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, false, DEPTH, DIRECT>), grid, block, 0, stream, a);
@@ -1880,6 +2196,28 @@ bool clustercull_prefers_direct(uint32_t previousCommandCount, uint32_t previous
 }
 
 // one workgroup per scatter tile (context.hip: one per CU, at most CC_MAX_SCATTER_TILES); no workgroup waits on another
+// late pass with HiZ, stage 2: any grid size (grid-stride over blocks of CH_CMDS commands)
+int launch_cluster_hiz(hipStream_t stream, const ClusterArgs& a, bool soa, uint32_t gridBlocks)
+{
+	dim3 grid(gridBlocks), block(CH_THREADS);
+	const bool bits = a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0;
+	if (soa)
+	{
+		if (bits)
+			hipLaunchKernelGGL((cluster_hiz_kernel<true, true>), grid, block, 0, stream, a);
+		else
+			hipLaunchKernelGGL((cluster_hiz_kernel<true, false>), grid, block, 0, stream, a);
+	}
+	else
+	{
+		if (bits)
+			hipLaunchKernelGGL((cluster_hiz_kernel<false, true>), grid, block, 0, stream, a);
+		else
+			hipLaunchKernelGGL((cluster_hiz_kernel<false, false>), grid, block, 0, stream, a);
+	}
+	return (int)hipGetLastError();
+}
+
 int launch_cluster_scatter(hipStream_t stream, const ClusterArgs& a, uint32_t scatterBlocks)
 {
 	hipLaunchKernelGGL((cluster_scatter_kernel<16>), dim3(scatterBlocks), dim3(16 * 64), 0, stream, a);
@@ -1887,6 +2225,12 @@ int launch_cluster_scatter(hipStream_t stream, const ClusterArgs& a, uint32_t sc
 }
 
 size_t clustercull_mask_bytes() { return (size_t)(NV_TASK_WGLIMIT + 64) * sizeof(uint64_t); }
+
+// Room per sub-list of the late pass's survivor-command list: twice an even share of the largest pass.  Sub-list s takes the
+// waves w = s (mod CC_LISTS) of the cull kernel, whose commands are dealt evenly up to a few chunks per wave, so a sub-list
+// holds about 1 / CC_LISTS of the pass; if a launch shape ever breaks that, the overflow flag turns the list off for the pass.
+uint32_t clustercull_list_stride() { return 2u * (NV_TASK_WGLIMIT / CC_LISTS); }
+size_t clustercull_list_bytes() { return ((size_t)CC_LISTS * clustercull_list_stride() + 64) * sizeof(uint32_t); }
 
 int launch_taskcull(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t gridBlocks)
 {

@@ -21,7 +21,10 @@ int launch_cluster_mask(hipStream_t, const ClusterArgs&, int late, bool soa, uin
 bool clustercull_prefers_shallow(uint32_t previousCommandCount);
 bool clustercull_prefers_direct(uint32_t previousCommandCount, uint32_t previousPassedFilter, uint32_t percent);
 int launch_cluster_scatter(hipStream_t, const ClusterArgs&, uint32_t scatterBlocks);
+int launch_cluster_hiz(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
 size_t clustercull_mask_bytes();
+size_t clustercull_list_bytes();
+uint32_t clustercull_list_stride();
 int launch_taskcull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t gridBlocks);
 int launch_probe(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
 int launch_soa_split(hipStream_t, const NvMeshlet*, uint32_t count, uint32_t padded, uint2* bounds, uint32_t* cones);
@@ -52,6 +55,8 @@ struct nv_context
 	int numCUs;
 	uint64_t* masks; // per-command ballots between the two clustercull launches
 	nv::ClusterCounts* tileCounts;
+	uint32_t* candList; // late pass with HiZ: indices of the commands with survivors (cull kernel -> occlusion stage)
+	uint32_t listStride; // room per sub-list (entries)
 	// drawcull: per-draw result bytes between its two launches, and its own per-tile counts
 	uint8_t* drawResults;
 	size_t drawResultsCapacity;
@@ -211,6 +216,7 @@ int nv_create(nv_context** out_ctx, int device)
 	ctx->scatterTilesPerCU = 1;
 	ctx->directPercent = 35; // measured crossover (config 3A geometry at several densities): ~36 % of the commands passing the filter
 	ctx->forceDirect = -1;
+	ctx->listStride = nv::clustercull_list_stride();
 #ifdef NV_EXPERIMENTS
 	if (const char* v = getenv("NV_HIZ_LDS"))
 		ctx->hizLds = (uint32_t)atoi(v);
@@ -223,6 +229,8 @@ int nv_create(nv_context** out_ctx, int device)
 	// the experiments build only (tools/): the product library reads no environment variable
 	if (const char* v = getenv("NV_DEBUG_MODE"))
 		ctx->debugMode = (uint32_t)atoi(v);
+	if (const char* v = getenv("NV_HIZ_LIST_STRIDE")) // a small value forces the occlusion stage's scan fallback (tests)
+		ctx->listStride = (uint32_t)atoi(v) < nv::clustercull_list_stride() ? (uint32_t)atoi(v) : nv::clustercull_list_stride();
 	if (const char* v = getenv("NV_DEAL_SCALE"))
 		ctx->dealScale = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_CC_BLOCKS_PER_CU"))
@@ -230,6 +238,7 @@ int nv_create(nv_context** out_ctx, int device)
 #endif
 
 	if (hipMalloc(&ctx->masks, nv::clustercull_mask_bytes()) != hipSuccess || hipMalloc(&ctx->tileCounts, sizeof(nv::ClusterCounts)) != hipSuccess ||
+	    hipMalloc(&ctx->candList, nv::clustercull_list_bytes()) != hipSuccess ||
 	    hipMemset(ctx->tileCounts, 0, sizeof(nv::ClusterCounts)) != hipSuccess ||
 	    hipMalloc(&ctx->drawTileCounts, sizeof(nv::ClusterCounts)) != hipSuccess ||
 	    hipMemset(ctx->drawTileCounts, 0, sizeof(nv::ClusterCounts)) != hipSuccess || ensure_draw_results(ctx, 1u << 20) != NV_OK)
@@ -275,6 +284,8 @@ void nv_destroy(nv_context* ctx)
 		(void)hipFree(ctx->masks);
 	if (ctx->tileCounts)
 		(void)hipFree(ctx->tileCounts);
+	if (ctx->candList)
+		(void)hipFree(ctx->candList);
 	if (ctx->soaBounds)
 		(void)hipFree(ctx->soaBounds);
 	if (ctx->soaCones)
@@ -569,6 +580,8 @@ static int fill_cluster_args(nv_context* ctx, nv::ClusterArgs& a, const NvCullDa
 	a.soaCones = soa ? ctx->soaCones : nullptr;
 	a.mvb = d_meshletVisibility;
 	a.masks = ctx->masks;
+	a.candList = ctx->candList;
+	a.listStride = ctx->listStride;
 	a.tileCounts = ctx->tileCounts;
 	a.scatterTiles = scatter_grid(ctx);
 	a.generations = ctx->ccBlocksPerCU;
@@ -625,13 +638,27 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	bool direct = ctx->hintHost && nv::clustercull_prefers_direct(ctx->hintHost[0], ctx->hintHost[1], ctx->directPercent);
 	if (ctx->forceDirect >= 0)
 		direct = ctx->forceDirect != 0;
-	rc = nv::launch_cluster_mask(s, a, late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), shallow, direct);
+	// Late pass with HiZ = three launches: the cull kernel in its early form (frustum + cone ballots), the occlusion probe
+	// with one lane per survivor (clustercull.hip cluster_hiz_kernel: visibility bits, skip, tile counts), the scatter.
+	const bool twoStage = late && cull->clusterOcclusionEnabled == 1 && !(ctx->debugMode & 2097152u); // bit 21 (experiments): the probe inside the cull kernel (r1 form)
+	a.deferHiz = twoStage ? 1u : 0u;
+	rc = nv::launch_cluster_mask(s, a, twoStage ? 0 : late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), shallow, direct);
 	hipEvent_t e1 = prof_mark(ctx, s);
+	hipEvent_t eh = e1;
+	if (rc == 0 && twoStage)
+	{
+		// 4 blocks per sub-list of the survivor-command list
+		const uint32_t blocks = 4u * nv::CC_LISTS;
+		rc = nv::launch_cluster_hiz(s, a, a.soaBounds != nullptr, blocks);
+		eh = prof_mark(ctx, s);
+	}
 	if (rc == 0 && !(ctx->debugMode & 16u)) // bit 4 (experiments): ballots only
 		rc = nv::launch_cluster_scatter(s, a, a.scatterTiles);
 	hipEvent_t e2 = prof_mark(ctx, s);
 	prof_push(ctx, NV_PROF_CLUSTER_CULL, e0, e1);
-	prof_push(ctx, NV_PROF_CLUSTER_SCATTER, e1 ? e1 : nullptr, e2);
+	if (twoStage)
+		prof_push(ctx, NV_PROF_CLUSTER_HIZ, e1 ? e1 : nullptr, eh);
+	prof_push(ctx, NV_PROF_CLUSTER_SCATTER, eh ? eh : nullptr, e2);
 	return rc;
 }
 

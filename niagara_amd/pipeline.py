@@ -71,10 +71,10 @@ class Context:
         check(lib.nv_profile_enable(self.h, int(enabled)), "nv_profile_enable")
 
     def profile_read(self):
-        """{slot: (total_ms, launches)} for cluster_cull, cluster_scatter, drawcull, depthreduce"""
-        ms, cnt = (C.c_float * 4)(), (C.c_uint32 * 4)()
+        """{slot: (total_ms, launches)} for cluster_cull, cluster_scatter, drawcull, depthreduce, cluster_hiz"""
+        ms, cnt = (C.c_float * 5)(), (C.c_uint32 * 5)()
         check(lib.nv_profile_read(self.h, C.byref(ms), C.byref(cnt)), "nv_profile_read")
-        names = ("cluster_cull", "cluster_scatter", "drawcull", "depthreduce")
+        names = ("cluster_cull", "cluster_scatter", "drawcull", "depthreduce", "cluster_hiz")
         return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(names)}
 
     # ---- passes (argument order = descriptor order of the reference dispatches)

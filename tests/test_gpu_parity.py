@@ -874,3 +874,33 @@ def test_dense_passes_switch_to_the_direct_form(ctx, soa):
                         totals.append(_compare_cluster_pass(ctx, draws, meshlets, commands, n, c, late, mvb0, pyr, gp, soa))
                     _compare_cluster_pass(ctx, draws, meshlets, commands, n, sparse, late, mvb0, pyr, gp, soa)
     assert max(totals) > 0.3 * n * 64
+
+
+@pytest.mark.parametrize("soa", [True, False])
+def test_late_occlusion_stage_full_blocks_and_stale_grid_hint(ctx, soa):
+    """The late pass's occlusion stage (cluster_hiz_kernel) sizes its grid from the previous launch's command count and
+    compacts up to 256 x 64 survivors per block through LDS: a 64-command pass first (the next grid is 9 blocks, so the
+    40 k commands behind it go through the grid-stride loop ~17 times), then a scene in which every meshlet survives
+    frustum and cone (full candidate lists) in front of a pyramid that occludes part of it; twice, so that the second
+    pass also sees the visibility words the first one wrote."""
+    rng = np.random.default_rng(23)
+    tiny = _cluster_inputs(8, 8, seed=5)
+    draws, meshlets, commands, n, cd = _cluster_inputs(4000, 10, seed=6)
+    draws["position"] *= np.float32(0.01)                      # a cloud of radius 3 ...
+    dense = host.build_cull_data(cam_pos=(0, 0, 12), draw_count=len(draws), cullingEnabled=1, clusterBackfaceEnabled=0, clusterOcclusionEnabled=1)  # ... seen from outside
+    commands["lateDrawVisibility"][:n] = rng.integers(0, 2, n)
+    mvb0 = rng.integers(0, 2 ** 32, n * 2 + 3, dtype=np.uint64).astype(np.uint32)
+    pyr = oracle.Pyramid(256, 192)
+    depth = make_scene(seed=3)["depth"]
+    oracle.depthreduce(depth, pyr)
+    gp = P.DepthPyramid(ctx.device, 256, 192)
+    ctx.depthreduce(torch.from_numpy(depth).to(ctx.device), 256, 192, gp.desc)
+    dense["pyramidWidth"], dense["pyramidHeight"] = pyr.width, pyr.height
+    for post in (0, 1):
+        c = dense.copy()
+        c["postPass"] = post
+        t_draws, t_meshlets, t_commands, t_n, t_cd = tiny
+        _compare_cluster_pass(ctx, t_draws, t_meshlets, t_commands, t_n, t_cd, 0, None, None, None, soa)
+        ctx.status()
+        total = _compare_cluster_pass(ctx, draws, meshlets, commands, n, c, 1, mvb0, pyr, gp, soa)
+        assert 0.02 * n * 64 < total < 0.98 * n * 64, total    # the probe both keeps and removes

@@ -15,8 +15,11 @@ PLAIN = os.path.join(ROOT, "niagara_amd", "libniagara_vis_plain.so")
 PRODUCT = os.path.join(ROOT, "niagara_amd", "libniagara_vis.so")
 
 
-def _run(lib):
-    env = dict(os.environ, NV_LIBRARY_PATH=lib)
+EXPERIMENTS = os.path.join(ROOT, "niagara_amd", "libniagara_vis_exp.so")
+
+
+def _run(lib, **extra):
+    env = dict(os.environ, NV_LIBRARY_PATH=lib, **extra)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "plain_runner.py")], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     return [l for l in out.stdout.splitlines() if l and l[0].isdigit()]
@@ -35,3 +38,12 @@ def test_asm_rings_equal_plain_loads():
     a, b = _run(PRODUCT), _run(PLAIN)
     assert len(a) == 24 and a == b
     assert any(int(l.split()[5]) > 1000 for l in a)
+
+
+@pytest.mark.gpu
+def test_occlusion_stage_scan_fallback_equals_the_list():
+    """The late pass's occlusion stage takes its commands from the list the cull kernel left; when a sub-list runs out of
+    room the stage scans all commands instead.  The product sizes the sub-lists so that this cannot happen, so the fallback
+    is exercised through the experiments build (the only one that reads the environment) with room for 4 entries."""
+    a, b = _run(PRODUCT), _run(EXPERIMENTS, NV_HIZ_LIST_STRIDE="4")
+    assert len(a) == 24 and a == b
