@@ -95,8 +95,9 @@ struct ClusterArgs
 	uint32_t* __restrict__ clusterCount4;
 	uint32_t* __restrict__ payloadCounts; // taskcull only
 	uint64_t* __restrict__ masks; // scratch: one 64-bit ballot per task command
-	uint32_t* __restrict__ candList; // scratch (late pass with HiZ): the commands that have frustum / cone survivors, CC_LISTS sub-lists in no particular order
+	uint4* __restrict__ candList;    // scratch (late pass with HiZ): the commands that have frustum / cone survivors, two uint4 each, CC_LISTS sub-lists in no particular order
 	uint32_t listStride;             // entries of room per sub-list
+	uint32_t listMinPer;             // listed commands per block of the occlusion stage, at least (>= 4)
 	ClusterCounts* __restrict__ tileCounts;
 	uint32_t scatterTiles; // grid of the scatter kernel (<= CC_MAX_SCATTER_TILES)
 	uint32_t generations;  // workgroups of the cull kernel per CU (its grid = generations x CUs)

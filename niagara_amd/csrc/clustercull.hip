@@ -1162,6 +1162,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 			// top priority for pass B, because it is on the launch's critical path — late pass 44.8 -> 48.8 us, early pass
 			// unchanged: the boosted wave takes issue slots from the streaming waves that keep HBM busy; likewise
 			// keeping level 3 out of the streaming waves' rotation: early pass +1.5 us.)
+#ifdef NV_EXPERIMENTS // the r1 form of the late pass (NV_DEBUG_MODE bit 21): the product defers the probe to cluster_hiz_kernel
 			if (LATE && candMask && a.cd.clusterOcclusionEnabled == 1 && !NV_DBG(a, 1024u | 524288u)) // bit 19 (experiments): texels fetched per command
 			{
 				// Late pass with HiZ: the same ring for bounds + cone, and behind it the texel fetches of CC_PT commands in
@@ -1299,7 +1300,9 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				for (int j = 0; j < CC_PT; ++j)
 					ring_release(tex[j]);
 			}
-			else if (candMask && !NV_DBG(a, 1024u)) // bit 10 (experiments): no exact pass
+			else
+#endif
+			if (candMask && !NV_DBG(a, 1024u)) // bit 10 (experiments): no exact pass
 			{
 				uint32_t curDraw = ~0u, certDraw = ~0u;
 				DrawUniform du = {};
@@ -1470,8 +1473,12 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				slot = __builtin_amdgcn_readfirstlane(slot);
 				if (slot + n <= a.listStride)
 				{
-					if (has >> lane & 1ull)
-						a.candList[sub * a.listStride + slot + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u))] = myIdx;
+					if (has >> lane & 1ull) // an entry = the command's index, its five words and its ballot (32 B): the stage starts from it alone
+					{
+						uint4* e = a.candList + (size_t)(sub * a.listStride + slot + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u))) * 2u;
+						e[0] = make_uint4(myIdx, r.drawId, r.taskOffset, r.taskCount);
+						e[1] = make_uint4(r.lateDrawVisibility, r.meshletVisibilityOffset, maskLo, maskHi);
+					}
 				}
 				else if (lane == 0)
 					atomicOr(&a.tileCounts->listOverflow[bank], 1u);
@@ -1832,10 +1839,11 @@ NV_DEV void hiz_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint3
 		const HizProbe p = hiz_prepare(a.cd, a.pyr, c, r, s_mip);
 		use[k] = p.use;
 		depth[k] = p.depthSphere;
-		t00[k] = texels[p.o00]; // in range also for an inactive probe (hiz_prepare)
-		t10[k] = texels[p.o10];
-		t01[k] = texels[p.o01];
-		t11[k] = texels[p.o11];
+		const uint32_t zero = NV_DBG(a, 16777216u) ? 0u : ~0u; // bit 24 (experiments): every probe reads texel 0
+		t00[k] = texels[p.o00 & zero]; // in range also for an inactive probe (hiz_prepare)
+		t10[k] = texels[p.o10 & zero];
+		t01[k] = texels[p.o01 & zero];
+		t11[k] = texels[p.o11 & zero];
 	}
 #pragma unroll
 	for (int k = 0; k < U; ++k)
@@ -1871,13 +1879,21 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 			s_mip[tid] = off;
 	}
 	// The cull kernel listed the commands that have survivors in CC_LISTS sub-lists; block b works on sub-list b % CC_LISTS
-	// together with the gridDim.x / CC_LISTS - 1 other blocks of that sub-list, in chunks: 8 listed commands per block while
-	// that covers the sub-list (a visible draw's ~10 commands bring up to 640 survivors: two or three per lane), more for
-	// a longer one.  The first chunk's entries are fetched together with the sub-list's length (entries past its end are
-	// ignored).  If a sub-list overflowed, every block scans its share of ALL commands instead.
+	// together with the gridDim.x / CC_LISTS - 1 other blocks of that sub-list, in chunks: listMinPer (8) listed commands per
+	// block while that covers the sub-list (<= 512 survivors: two per lane), more for a longer one.  (Measured, config 4:
+	// 4 blocks x 8 commands 12.3 us, 5 x 4 14.2, 2 x 16 12.9, 1 x 32 13.6 — the stage is bound by its fixed chain of
+	// latencies and cold instruction fetches, not by the balance.)  The first chunk's entries are fetched
+	// together with the sub-list's length (entries past its end are ignored).  If a sub-list overflowed — a pass with more
+	// than a few hundred thousand such commands — every block scans its share of ALL commands instead: then nearly every
+	// command has survivors and contiguous ranges are balanced by themselves.
 	const uint32_t sub = blockIdx.x % CC_LISTS, rank0 = blockIdx.x / CC_LISTS, sharers = gridDim.x / CC_LISTS;
-	const uint32_t* __restrict__ list = a.candList + sub * a.listStride;
-	const uint32_t specEntry = tid < 8u ? list[rank0 * 8u + tid] : 0u; // (in range: the buffer is padded)
+	const uint4* __restrict__ list = a.candList + (size_t)sub * a.listStride * 2u;
+	uint4 spec0 = make_uint4(0, 0, 0, 0), spec1 = spec0;
+	if (tid < a.listMinPer) // (in range: the buffer is padded)
+	{
+		spec0 = list[(rank0 * a.listMinPer + tid) * 2u];
+		spec1 = list[(rank0 * a.listMinPer + tid) * 2u + 1u];
+	}
 	const uint32_t bank = load_uniform_u32(&a.tileCounts->k2parity) & 1u; // the cull kernel of this pass wrote it
 	const uint32_t count0 = load_uniform_u32(&a.tileCounts->listCount[0][sub * CC_COUNT_STRIDE]);
 	const uint32_t count1 = load_uniform_u32(&a.tileCounts->listCount[1][sub * CC_COUNT_STRIDE]);
@@ -1888,27 +1904,50 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 	const uint32_t items = scan ? numCmds : (bank ? count1 : count0);
 	const uint32_t share = scan ? gridDim.x : sharers;
 	uint32_t per = (items + share - 1u) / share;
-	per = per < 8u ? 8u : (per > (uint32_t)CH_CMDS ? (uint32_t)CH_CMDS : per);
+	per = per < a.listMinPer ? a.listMinPer : (per > (uint32_t)CH_CMDS ? (uint32_t)CH_CMDS : per);
 	const uint32_t firstChunk = scan ? blockIdx.x : rank0;
 
 	for (uint32_t chunk = firstChunk; chunk * per < items; chunk += share)
 	{
 		const uint32_t li = chunk * per + tid;
 		const bool live = tid < per && li < items;
+		if (NV_DBG(a, 4194304u)) // bit 22 (experiments): the list only
+			continue;
 		uint32_t idx = 0;
-		if (live)
-			idx = scan ? li : (per == 8u && chunk == rank0 ? specEntry : list[li]);
 		uint64_t cand = 0;
 		uint32_t drawId = 0, taskOffset = 0, taskCount = 0, lateDrawVisibility = 0, mvo = 0;
-		if (live && idx < numCmds)
+		if (scan)
 		{
-			cand = a.masks[idx];
-			const uint32_t* p = reinterpret_cast<const uint32_t*>(a.commands + idx);
-			drawId = p[0];
-			taskOffset = p[1];
-			taskCount = p[2];
-			lateDrawVisibility = p[3];
-			mvo = p[4];
+			idx = li;
+			if (live)
+			{
+				cand = a.masks[idx];
+				const uint32_t* p = reinterpret_cast<const uint32_t*>(a.commands + idx);
+				drawId = p[0];
+				taskOffset = p[1];
+				taskCount = p[2];
+				lateDrawVisibility = p[3];
+				mvo = p[4];
+			}
+		}
+		else if (live)
+		{
+			uint4 e0 = spec0, e1 = spec1;
+			if (!(per == a.listMinPer && chunk == rank0))
+			{
+				e0 = list[li * 2u];
+				e1 = list[li * 2u + 1u];
+			}
+			if (e0.x < numCmds)
+			{
+				idx = e0.x;
+				drawId = e0.y;
+				taskOffset = e0.z;
+				taskCount = e0.w;
+				lateDrawVisibility = e1.x;
+				mvo = e1.y;
+				cand = ((uint64_t)e1.w << 32) | e1.z;
+			}
 		}
 		// second latency, part 1: the command's MeshDraw and its <= 3 visibility words.  Unconditional, clamped loads (dummy
 		// commands and the lanes without a command read element 0): a branch around a load makes hipcc fall back to
@@ -1972,6 +2011,7 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 	} while (0)
 		if (total == 0) // (uniform) nothing survived frustum and cone in this block: the cull kernel has cleared the bits
 			continue;
+		if (!NV_DBG(a, 8388608u)) // bit 23 (experiments): no probes
 		{
 			NV_HIZ_ROUND(true, 0u);
 			for (uint32_t base = CH_THREADS * CH_U; base < total; base += CH_THREADS * CH_U)
@@ -2226,11 +2266,12 @@ int launch_cluster_scatter(hipStream_t stream, const ClusterArgs& a, uint32_t sc
 
 size_t clustercull_mask_bytes() { return (size_t)(NV_TASK_WGLIMIT + 64) * sizeof(uint64_t); }
 
-// Room per sub-list of the late pass's survivor-command list: twice an even share of the largest pass.  Sub-list s takes the
-// waves w = s (mod CC_LISTS) of the cull kernel, whose commands are dealt evenly up to a few chunks per wave, so a sub-list
-// holds about 1 / CC_LISTS of the pass; if a launch shape ever breaks that, the overflow flag turns the list off for the pass.
-uint32_t clustercull_list_stride() { return 2u * (NV_TASK_WGLIMIT / CC_LISTS); }
-size_t clustercull_list_bytes() { return ((size_t)CC_LISTS * clustercull_list_stride() + 64) * sizeof(uint32_t); }
+// Room per sub-list of the late pass's survivor-command list (32-B entries): 512 k listed commands in all.  The list serves the
+// sparse passes — a few per cent of the commands have survivors and they cluster per draw, so contiguous command ranges
+// are badly balanced; a pass that lists more than fits raises the overflow flag and the stage scans contiguous ranges,
+// which is as good when most commands have survivors.
+uint32_t clustercull_list_stride() { return 2048u; }
+size_t clustercull_list_bytes() { return ((size_t)CC_LISTS * clustercull_list_stride() + 64) * 2 * sizeof(uint4); }
 
 int launch_taskcull(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t gridBlocks)
 {

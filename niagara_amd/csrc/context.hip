@@ -55,8 +55,9 @@ struct nv_context
 	int numCUs;
 	uint64_t* masks; // per-command ballots between the two clustercull launches
 	nv::ClusterCounts* tileCounts;
-	uint32_t* candList; // late pass with HiZ: indices of the commands with survivors (cull kernel -> occlusion stage)
+	uint4* candList; // late pass with HiZ: the commands with survivors (cull kernel -> occlusion stage)
 	uint32_t listStride; // room per sub-list (entries)
+	uint32_t listSharers, listMinPer; // occlusion stage: blocks per sub-list, listed commands per block at least
 	// drawcull: per-draw result bytes between its two launches, and its own per-tile counts
 	uint8_t* drawResults;
 	size_t drawResultsCapacity;
@@ -217,6 +218,8 @@ int nv_create(nv_context** out_ctx, int device)
 	ctx->directPercent = 35; // measured crossover (config 3A geometry at several densities): ~36 % of the commands passing the filter
 	ctx->forceDirect = -1;
 	ctx->listStride = nv::clustercull_list_stride();
+	ctx->listSharers = 4;
+	ctx->listMinPer = 8;
 #ifdef NV_EXPERIMENTS
 	if (const char* v = getenv("NV_HIZ_LDS"))
 		ctx->hizLds = (uint32_t)atoi(v);
@@ -231,6 +234,10 @@ int nv_create(nv_context** out_ctx, int device)
 		ctx->debugMode = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_HIZ_LIST_STRIDE")) // a small value forces the occlusion stage's scan fallback (tests)
 		ctx->listStride = (uint32_t)atoi(v) < nv::clustercull_list_stride() ? (uint32_t)atoi(v) : nv::clustercull_list_stride();
+	if (const char* v = getenv("NV_HIZ_SHARERS"))
+		ctx->listSharers = (uint32_t)atoi(v) ? (uint32_t)atoi(v) : 4;
+	if (const char* v = getenv("NV_HIZ_MIN_PER"))
+		ctx->listMinPer = (uint32_t)atoi(v) >= 4 && (uint32_t)atoi(v) <= 64 ? (uint32_t)atoi(v) : 8;
 	if (const char* v = getenv("NV_DEAL_SCALE"))
 		ctx->dealScale = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_CC_BLOCKS_PER_CU"))
@@ -582,6 +589,7 @@ static int fill_cluster_args(nv_context* ctx, nv::ClusterArgs& a, const NvCullDa
 	a.masks = ctx->masks;
 	a.candList = ctx->candList;
 	a.listStride = ctx->listStride;
+	a.listMinPer = ctx->listMinPer;
 	a.tileCounts = ctx->tileCounts;
 	a.scatterTiles = scatter_grid(ctx);
 	a.generations = ctx->ccBlocksPerCU;
@@ -647,8 +655,7 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	hipEvent_t eh = e1;
 	if (rc == 0 && twoStage)
 	{
-		// 4 blocks per sub-list of the survivor-command list
-		const uint32_t blocks = 4u * nv::CC_LISTS;
+		const uint32_t blocks = ctx->listSharers * nv::CC_LISTS;
 		rc = nv::launch_cluster_hiz(s, a, a.soaBounds != nullptr, blocks);
 		eh = prof_mark(ctx, s);
 	}

@@ -878,11 +878,10 @@ def test_dense_passes_switch_to_the_direct_form(ctx, soa):
 
 @pytest.mark.parametrize("soa", [True, False])
 def test_late_occlusion_stage_full_blocks_and_stale_grid_hint(ctx, soa):
-    """The late pass's occlusion stage (cluster_hiz_kernel) sizes its grid from the previous launch's command count and
-    compacts up to 256 x 64 survivors per block through LDS: a 64-command pass first (the next grid is 9 blocks, so the
-    40 k commands behind it go through the grid-stride loop ~17 times), then a scene in which every meshlet survives
-    frustum and cone (full candidate lists) in front of a pyramid that occludes part of it; twice, so that the second
-    pass also sees the visibility words the first one wrote."""
+    """The late pass's occlusion stage (cluster_hiz_kernel) takes the commands with survivors from the sub-lists the cull
+    kernel left and compacts their survivors through LDS, 32 commands x 64 survivors per block here: a 64-command pass
+    first, then a scene in which every meshlet survives frustum and cone (full lists, several rounds per block) in front
+    of a pyramid that occludes part of it; with postPass 0 and 1 (with and without the skip of what the early pass drew)."""
     rng = np.random.default_rng(23)
     tiny = _cluster_inputs(8, 8, seed=5)
     draws, meshlets, commands, n, cd = _cluster_inputs(4000, 10, seed=6)
@@ -904,3 +903,44 @@ def test_late_occlusion_stage_full_blocks_and_stale_grid_hint(ctx, soa):
         ctx.status()
         total = _compare_cluster_pass(ctx, draws, meshlets, commands, n, c, 1, mvb0, pyr, gp, soa)
         assert 0.02 * n * 64 < total < 0.98 * n * 64, total    # the probe both keeps and removes
+
+
+def test_late_pass_with_more_survivor_commands_than_the_list_holds(ctx):
+    """The cull kernel of the late pass lists at most 256 x 2048 commands with survivors for the occlusion stage; a pass
+    with more (here 530 k commands, every meshlet inside the frustum, no cone test) raises the overflow flag and the stage
+    scans contiguous command ranges instead.  IDs and visibility words against the oracle, and a sparse pass afterwards
+    to see the flag cleared."""
+    rng = np.random.default_rng(29)
+    draws, meshlets, commands, n, _ = _cluster_inputs(53000, 10, seed=9)
+    assert n > 256 * 2048
+    draws["position"] *= np.float32(0.01)
+    dense = host.build_cull_data(cam_pos=(0, 0, 12), draw_count=len(draws), cullingEnabled=1, clusterBackfaceEnabled=0, clusterOcclusionEnabled=1)
+    commands["lateDrawVisibility"][:n] = rng.integers(0, 2, n)
+    mvb0 = rng.integers(0, 2 ** 32, n * 2 + 3, dtype=np.uint64).astype(np.uint32)
+    pyr = oracle.Pyramid(256, 192)
+    depth = make_scene(seed=3)["depth"]
+    oracle.depthreduce(depth, pyr)
+    gp = P.DepthPyramid(ctx.device, 256, 192)
+    ctx.depthreduce(torch.from_numpy(depth).to(ctx.device), 256, 192, gp.desc)
+    dense["pyramidWidth"], dense["pyramidHeight"] = pyr.width, pyr.height
+    dev = ctx.device
+    c4 = synth.count4_for(n)
+    db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+    ctx.upload_meshlets(mlb, len(meshlets))
+    dccb = torch.from_numpy(c4.view(np.int32).copy()).to(dev)
+    cib = torch.zeros(len(commands) * 64 + 256, dtype=torch.int32, device=dev)
+    ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+    sparse = dense.copy()
+    sparse["view"][0][14] += np.float32(500.0)
+    for cd in (dense, sparse, dense):
+        mvb_o = mvb0.copy()
+        cib_o, cc4_o = np.zeros(len(commands) * 64 + 256, np.uint32), np.zeros(4, np.uint32)
+        oracle.clustercull(cd, 1, commands, c4, draws, meshlets, mvb_o, pyr, cib_o, cc4_o, threads=oracle.max_threads())
+        d_mvb = torch.from_numpy(mvb0.view(np.int32).copy()).to(dev)
+        ccb.zero_()
+        ctx.clustercull(cd, 1, dcb, dccb, db, mlb, d_mvb, gp.desc, cib, ccb)
+        total = int(cc4_o[0])
+        assert int(ccb[0].item()) == total
+        assert (G.host_u32(cib)[:min(total, L.CLUSTER_LIMIT)] == cib_o[:min(total, L.CLUSTER_LIMIT)]).all()
+        assert (G.host_u32(d_mvb) == mvb_o).all()
+    ctx.status()
