@@ -944,3 +944,50 @@ def test_late_pass_with_more_survivor_commands_than_the_list_holds(ctx):
         assert (G.host_u32(cib)[:min(total, L.CLUSTER_LIMIT)] == cib_o[:min(total, L.CLUSTER_LIMIT)]).all()
         assert (G.host_u32(d_mvb) == mvb_o).all()
     ctx.status()
+
+
+def test_graph_replay_of_the_late_pass(ctx):
+    """the late pass with HiZ is three launches whose hand-over (ballots, the banked list of commands with survivors, tile
+    counts) lives in device memory: a captured pass replays correctly, also an odd number of times (the banks alternate)"""
+    rng = np.random.default_rng(31)
+    draws, meshlets, commands, n, cd = _cluster_inputs(3000, 6, seed=12)
+    draws["position"] *= np.float32(0.2)
+    commands["lateDrawVisibility"][:n] = rng.integers(0, 2, n)
+    mvb0 = rng.integers(0, 2 ** 32, n * 2 + 3, dtype=np.uint64).astype(np.uint32)
+    pyr = oracle.Pyramid(256, 192)
+    depth = make_scene(seed=3)["depth"]
+    oracle.depthreduce(depth, pyr)
+    dev = ctx.device
+    gp = P.DepthPyramid(dev, 256, 192)
+    ctx.depthreduce(torch.from_numpy(depth).to(dev), 256, 192, gp.desc)
+    cd["pyramidWidth"], cd["pyramidHeight"] = pyr.width, pyr.height
+    cd["clusterOcclusionEnabled"] = 1
+    c4 = synth.count4_for(n)
+    cib_o, cc4_o, mvb_o = np.zeros(n * 64 + 256, np.uint32), np.zeros(4, np.uint32), mvb0.copy()
+    oracle.clustercull(cd, 1, commands, c4, draws, meshlets, mvb_o, pyr, cib_o, cc4_o)
+    assert cc4_o[0] > 100
+    db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+    ctx.upload_meshlets(mlb, len(meshlets))
+    dccb = torch.from_numpy(c4.view(np.int32).copy()).to(dev)
+    cib = torch.zeros(n * 64 + 256, dtype=torch.int32, device=dev)
+    ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+    d_mvb0 = torch.from_numpy(mvb0.view(np.int32).copy()).to(dev)
+    d_mvb = d_mvb0.clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ctx.clustercull(cd, 1, dcb, dccb, db, mlb, d_mvb, gp.desc, cib, ccb)  # warm-up outside capture
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            ccb.zero_()
+            d_mvb.copy_(d_mvb0)
+            ctx.clustercull(cd, 1, dcb, dccb, db, mlb, d_mvb, gp.desc, cib, ccb)
+        for _ in range(5):
+            cib.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            total = int(ccb[0].item())
+            assert total == int(cc4_o[0])
+            assert (G.host_u32(cib)[:total] == cib_o[:total]).all()
+            assert (G.host_u32(d_mvb) == mvb_o).all()
+    ctx.status()

@@ -40,6 +40,39 @@ def timed(ctx, fn, iters, slot):
     return wall * 1e6, ms / max(1, n) * 1e3, prof
 
 
+def plain_wall(fn, iters):
+    """wall time per call with no event brackets between the launches"""
+    for i in range(3):
+        fn(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        fn(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e6
+
+
+def graph_wall(fn, iters):
+    """the same calls captured once into a HIP graph (the C ABI is stream-ordered and keeps its cross-launch state in device
+    memory, so a captured frame phase replays) and replayed: what is left of the launch gaps"""
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        fn(0)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            fn(0)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            g.replay()
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / iters * 1e6
+    return us
+
+
 def config2(ctx, iters, n_draws=1_000_000, copies=6, soa=True):
     """1 M MeshDraw spheres, frustum cull + LOD + ordered compaction: drawcull<LATE=0,TASK=0>"""
     dev = ctx.device
@@ -135,6 +168,8 @@ def config3b(ctx, iters, n_draws=15625 * 4, fused=False):
         pipe.render_clusters(cd, late=False)
 
     wall, k_us, prof = timed(ctx, step, iters, "cluster_cull")
+    wall_plain = plain_wall(step, iters)
+    wall_graph = graph_wall(step, iters)
     cmds = int(pipe.dccb[0].item())
     tested = int((P.from_device(pipe.dcb, L.TASKCMD)[:cmds]["taskCount"]).sum())
     # parity: every buffer of the chain against the oracle (the pipeline rewrote the draws' visibility offsets: use its copy)
@@ -153,8 +188,8 @@ def config3b(ctx, iters, n_draws=15625 * 4, fused=False):
             and (pipe.ccb.cpu().numpy().view(np.uint32) == cc4_o).all() and (pipe.cib[:nv].cpu().numpy().view(np.uint32) == cib_o[:nv]).all()
             and bool((pipe.dvb == 1).all().item()))
     return dict(config="3B: drawcull<0,1> -> tasksubmit -> clustercull<0> -> clustersubmit" + (" (NV_OPT_FUSED_SUBMIT + FUSED_COUNT_RESET: 4 launches)" if fused else " (8 launches)"), draws=n_draws, task_commands=cmds, meshlets_tested=tested,
-                visible=int(pipe.ccb[0].item()), step_us=wall, cluster_cull_us=k_us, cluster_scatter_us=prof["cluster_scatter"][0] / max(1, prof["cluster_scatter"][1]) * 1e3,
-                drawcull_us=prof["drawcull"][0] / max(1, prof["drawcull"][1]) * 1e3, meshlets_per_s=tested / (wall * 1e-6), parity=verdict(same))
+                visible=int(pipe.ccb[0].item()), step_us=wall_plain, step_us_with_events=wall, step_us_graph_replay=wall_graph, cluster_cull_us=k_us, cluster_scatter_us=prof["cluster_scatter"][0] / max(1, prof["cluster_scatter"][1]) * 1e3,
+                drawcull_us=prof["drawcull"][0] / max(1, prof["drawcull"][1]) * 1e3, meshlets_per_s=tested / (wall_plain * 1e-6), parity=verdict(same))
 
 
 def config4(ctx, iters, size=4096, n_draws=15625, cpd=10):
