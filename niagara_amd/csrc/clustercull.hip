@@ -1882,7 +1882,7 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 	// together with the gridDim.x / CC_LISTS - 1 other blocks of that sub-list, in chunks: listMinPer (8) listed commands per
 	// block while that covers the sub-list (<= 512 survivors: two per lane), more for a longer one.  (Measured, config 4:
 	// 4 blocks x 8 commands 12.3 us, 5 x 4 14.2, 2 x 16 12.9, 1 x 32 13.6 — the stage is bound by its fixed chain of
-	// latencies and cold instruction fetches, not by the balance.)  The first chunk's entries are fetched
+	// latencies and the probes' arithmetic, not by the balance.)  The first chunk's entries are fetched
 	// together with the sub-list's length (entries past its end are ignored).  If a sub-list overflowed — a pass with more
 	// than a few hundred thousand such commands — every block scans its share of ALL commands instead: then nearly every
 	// command has survivors and contiguous ranges are balanced by themselves.
@@ -2016,6 +2016,9 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 			NV_HIZ_ROUND(true, 0u);
 			for (uint32_t base = CH_THREADS * CH_U; base < total; base += CH_THREADS * CH_U)
 				NV_HIZ_ROUND(false, base);
+			if (NV_DBG(a, 33554432u)) // bit 25 (experiments): every round a second time (same result) — what the same code costs warm
+				for (uint32_t base = 0; base < total; base += CH_THREADS * CH_U)
+					NV_HIZ_ROUND(false, base);
 		}
 #undef NV_HIZ_ROUND
 		NV_LDS_BARRIER();
