@@ -991,3 +991,25 @@ def test_graph_replay_of_the_late_pass(ctx):
             assert (G.host_u32(cib)[:total] == cib_o[:total]).all()
             assert (G.host_u32(d_mvb) == mvb_o).all()
     ctx.status()
+
+
+def test_late_pass_with_no_commands_and_with_one(ctx):
+    """edge sizes of the three-launch late pass: an empty dispatch (the count word keeps its base, nothing is listed) between
+    two ordinary ones, and a dispatch of a single command"""
+    rng = np.random.default_rng(37)
+    draws, meshlets, commands, n, cd = _cluster_inputs(40, 3, seed=13)
+    draws["position"] *= np.float32(0.05)
+    cd["clusterOcclusionEnabled"] = 1
+    pyr = oracle.Pyramid(256, 192)
+    depth = make_scene(seed=3)["depth"]
+    oracle.depthreduce(depth, pyr)
+    gp = P.DepthPyramid(ctx.device, 256, 192)
+    ctx.depthreduce(torch.from_numpy(depth).to(ctx.device), 256, 192, gp.desc)
+    cd["pyramidWidth"], cd["pyramidHeight"] = pyr.width, pyr.height
+    commands["lateDrawVisibility"][:n] = rng.integers(0, 2, n)
+    mvb0 = rng.integers(0, 2 ** 32, n * 2 + 3, dtype=np.uint64).astype(np.uint32)
+    seen = _compare_cluster_pass(ctx, draws, meshlets, commands, n, cd, 1, mvb0, pyr, gp)
+    assert seen > 0
+    assert _compare_cluster_pass(ctx, draws, meshlets, commands, 0, cd, 1, mvb0, pyr, gp) == 0
+    assert _compare_cluster_pass(ctx, draws, meshlets, commands, n, cd, 1, mvb0, pyr, gp) == seen
+    _compare_cluster_pass(ctx, draws, meshlets, commands, 1, cd, 1, mvb0, pyr, gp)
