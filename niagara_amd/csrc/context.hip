@@ -86,6 +86,7 @@ struct nv_context
 	uint32_t ccBlocksPerCU;
 	uint32_t dealScale;
 	uint32_t scatterTilesPerCU;
+	uint32_t scatterTilesAbs; // experiments: absolute number of scatter tiles (0 = per CU)
 	uint32_t hizLds; // stage the coarse pyramid levels in LDS for drawcull's late pass (experiments: measured slower)
 	uint32_t directPercent; // share of commands passing the filter above which the next launch skips the filter pass
 	int forceDirect;        // experiments build: -1 = by statistic, 0 / 1 = always filter / always direct
@@ -170,7 +171,7 @@ int ensure_draw_results(nv_context* ctx, uint32_t drawCount)
 // one scatter workgroup per CU, capped by the per-tile count table
 uint32_t scatter_grid(const nv_context* ctx)
 {
-	uint32_t g = (uint32_t)ctx->numCUs * ctx->scatterTilesPerCU;
+	uint32_t g = ctx->scatterTilesAbs ? ctx->scatterTilesAbs : (uint32_t)ctx->numCUs * ctx->scatterTilesPerCU;
 	return g > nv::CC_MAX_SCATTER_TILES ? nv::CC_MAX_SCATTER_TILES : g;
 }
 
@@ -229,6 +230,8 @@ int nv_create(nv_context** out_ctx, int device)
 		ctx->directPercent = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_SCATTER_TILES_PER_CU"))
 		ctx->scatterTilesPerCU = (uint32_t)atoi(v) ? (uint32_t)atoi(v) : 1;
+	if (const char* v = getenv("NV_SCATTER_TILES"))
+		ctx->scatterTilesAbs = (uint32_t)atoi(v);
 	// the experiments build only (tools/): the product library reads no environment variable
 	if (const char* v = getenv("NV_DEBUG_MODE"))
 		ctx->debugMode = (uint32_t)atoi(v);
