@@ -19,7 +19,11 @@
 //     reference's for every lane either way;
 //   * visibility bits (late pass) are updated lane-parallel per segment from the ballots — <= 3 words per command, a
 //     plain store for a word the command owns, an atomic only for a shared edge word — instead of one atomicOr/And per
-//     lane (clustercull.comp.glsl:125-131).
+//     lane (clustercull.comp.glsl:125-131);
+//   * the late pass with HiZ is three launches: K1 in its early form (DEFER: frustum / cone ballots, the commands that have
+//     survivors listed), cluster_hiz_kernel with ONE LANE PER SURVIVOR for the occlusion probe, the visibility bits and the
+//     final ballots, then K2.  Inside K1 the probe cost three dependent memory latencies per command with only the
+//     command's survivors active, and the launch ended with the few waves that drew the visible part of the scene.
 #include "cullmath.h"
 #include "args.h"
 
