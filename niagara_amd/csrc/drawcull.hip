@@ -71,56 +71,75 @@ NV_DEV uint32_t lod_table_source(uint32_t k)
 // WORLD: the draw comes from the mirror of nv_upload_draws — d0 = the world-space sphere {rotateQuat(center, q) * scale +
 // position, radius * scale}, i.e. the view-independent prefix of drawcull.comp.glsl:73-75 evaluated once at upload in the
 // reference's own operation order (bit-identical intermediates), d1.x = scale; only the view transform is left per pass.
-template <bool LATE, bool TASK, bool COMPACT, bool WORLD>
-NV_DEV DrawResult decide_draw(const DrawArgs& a, const char* meshBase, uint32_t di, const float4& d0, const float4& d1, const uint4& d2, uint32_t oldVis,
-                              const float* hizTail)
+// The decision in three parts, so that the late pass can run the occlusion probe of a whole workgroup's visible draws on
+// compacted lanes (draw_decide_kernel): decide_pre = drawcull.comp.glsl:56-84 (the early-outs, the sphere in view space, the
+// frustum test), draw_probe = :86-99 (HiZ), decide_post = :101-118 + :154-155 (LOD, counts, the new drawVisibility word).
+struct DrawPre
 {
-	const NvCullData& cd = a.cd;
-	DrawResult res = { 0, 0, oldVis };
-
-	if (d2.z != cd.postPass) // drawData.postPass
-		return res;
-	if (!LATE && oldVis == 0)
-		return res;
-
-	const uint32_t meshIndex = d2.x;
-	const char* mesh = meshBase + (size_t)meshIndex * (COMPACT ? DC_LOD_WORDS * 4u : sizeof(NvMesh));
 	f3 c;
 	float radius, scale;
+	const char* mesh;
+	bool skip;    // the draw is not part of this pass (postPass mismatch / early pass and invisible last frame): nothing is written
+	bool visible; // frustum (or culling disabled)
+};
+
+template <bool LATE, bool COMPACT, bool WORLD>
+NV_DEV DrawPre decide_pre(const DrawArgs& a, const char* meshBase, const float4& d0, const float4& d1, const uint4& d2, uint32_t oldVis)
+{
+	const NvCullData& cd = a.cd;
+	DrawPre pre = { { 0.0f, 0.0f, 0.0f }, 0.0f, 0.0f, meshBase, true, false };
+	if (d2.z != cd.postPass) // drawData.postPass
+		return pre;
+	if (!LATE && oldVis == 0)
+		return pre;
+	pre.skip = false;
+
+	const uint32_t meshIndex = d2.x;
+	pre.mesh = meshBase + (size_t)meshIndex * (COMPACT ? DC_LOD_WORDS * 4u : sizeof(NvMesh));
 	if (WORLD)
 	{
-		c = view_point(cd.view, f3{ d0.x, d0.y, d0.z });
-		radius = d0.w;
-		scale = d1.x;
+		pre.c = view_point(cd.view, f3{ d0.x, d0.y, d0.z });
+		pre.radius = d0.w;
+		pre.scale = d1.x;
 	}
 	else
 	{
-		const float4 cr = *reinterpret_cast<const float4*>(mesh); // center.xyz, radius
+		const float4 cr = *reinterpret_cast<const float4*>(pre.mesh); // center.xyz, radius
 		f3 q = { d1.x, d1.y, d1.z };
-		c = sphere_center(cd, f3{ cr.x, cr.y, cr.z }, q, d1.w, d0.w, f3{ d0.x, d0.y, d0.z });
-		radius = cr.w * d0.w;
-		scale = d0.w;
+		pre.c = sphere_center(cd, f3{ cr.x, cr.y, cr.z }, q, d1.w, d0.w, f3{ d0.x, d0.y, d0.z });
+		pre.radius = cr.w * d0.w;
+		pre.scale = d0.w;
 	}
+	pre.visible = frustum_test(cd, pre.c, pre.radius) || cd.cullingEnabled == 0;
+	return pre;
+}
 
-	bool visible = frustum_test(cd, c, radius);
-	visible = visible || cd.cullingEnabled == 0;
+// drawcull.comp.glsl:86-99.  Texels of the staged pyramid tail (experiments build: levels copied to LDS by the workgroup,
+// north_star's "LDS-staged HiZ tiles") come from LDS, the others from global memory.
+NV_DEV bool draw_probe(const DrawArgs& a, f3 c, float radius, const float* hizTail)
+{
+	const HizProbe p = hiz_prepare(a.cd, a.pyr, c, radius, a.pyr.mipOffset);
+	if (!(p.use & 16u))
+		return true;
+	const float* base = a.pyr.d_base;
+	const uint32_t sb = DC_HIZ_TAIL > 1 ? a.stagedBase : ~0u; // ~0u: nothing staged
+	const float t00 = p.o00 >= sb ? hizTail[p.o00 - sb] : base[p.o00];
+	const float t10 = p.o10 >= sb ? hizTail[p.o10 - sb] : base[p.o10];
+	const float t01 = p.o01 >= sb ? hizTail[p.o01 - sb] : base[p.o01];
+	const float t11 = p.o11 >= sb ? hizTail[p.o11 - sb] : base[p.o11];
+	return hiz_finish(p, t00, t10, t01, t11);
+}
 
-	if (LATE && visible && cd.occlusionEnabled == 1)
-	{
-		// drawcull.comp.glsl:86-99.  Texels of the staged pyramid tail (levels >= a.stagedLevel, copied to LDS by the
-		// workgroup: north_star's "LDS-staged HiZ tiles") come from LDS, the finer levels from global memory.
-		const HizProbe p = hiz_prepare(cd, a.pyr, c, radius, a.pyr.mipOffset);
-		if (p.use & 16u)
-		{
-			const float* base = a.pyr.d_base;
-			const uint32_t sb = DC_HIZ_TAIL > 1 ? a.stagedBase : ~0u; // ~0u: nothing staged
-			const float t00 = p.o00 >= sb ? hizTail[p.o00 - sb] : base[p.o00];
-			const float t10 = p.o10 >= sb ? hizTail[p.o10 - sb] : base[p.o10];
-			const float t01 = p.o01 >= sb ? hizTail[p.o01 - sb] : base[p.o01];
-			const float t11 = p.o11 >= sb ? hizTail[p.o11 - sb] : base[p.o11];
-			visible = hiz_finish(p, t00, t10, t01, t11);
-		}
-	}
+template <bool LATE, bool TASK, bool COMPACT>
+NV_DEV DrawResult decide_post(const DrawArgs& a, const DrawPre& pre, bool visible, uint32_t di, uint32_t oldVis)
+{
+	const NvCullData& cd = a.cd;
+	DrawResult res = { 0, 0, oldVis };
+	if (pre.skip)
+		return res;
+	const char* mesh = pre.mesh;
+	const f3 c = pre.c;
+	const float radius = pre.radius, scale = pre.scale;
 
 	// TASK_CULL == 1 (src/config.h:8)
 	if (visible && (!LATE || cd.clusterOcclusionEnabled == 1 || oldVis == 0 || cd.postPass != 0))
@@ -347,6 +366,68 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 
 	// per wave-batch command counts -> LDS; merged per scatter tile below
 	__shared__ uint32_t s_waveCount[DC_BATCH * DC_WAVES];
+	DrawPre pre[DC_BATCH];
+	bool visible[DC_BATCH];
+#pragma unroll
+	for (int j = 0; j < DC_BATCH; ++j)
+	{
+		const uint32_t c = j * DC_THREADS + tid;
+		pre[j] = decide_pre<LATE, MESH_LDS, SOA>(a, meshBase, ld[j].d0, ld[j].d1, ld[j].d2, ld[j].oldVis);
+		if (c >= n)
+			pre[j].skip = true;
+		visible[j] = !pre[j].skip && pre[j].visible;
+	}
+	// Late pass: the occlusion probe (~360 instructions, two dependent loads) is needed by the few per cent of the draws
+	// that pass the frustum test, i.e. by one or two lanes of nearly every wave — executed in place it costs every wave
+	// the full instruction stream (1 M draws: decide 16.5 us against 10.1 us without the probe).  The workgroup's
+	// requests are compacted through LDS instead and probed on consecutive lanes: once per workgroup in the sparse case,
+	// never more often than in place.
+	if (LATE && a.cd.occlusionEnabled == 1) // (uniform)
+	{
+		__shared__ float4 s_req[DC_TILE];
+		__shared__ uint16_t s_reqSlot[DC_TILE];
+		__shared__ uint32_t s_reqCount, s_seen[DC_TILE / 32];
+		if (tid == 0)
+			s_reqCount = 0;
+		if (tid < DC_TILE / 32)
+			s_seen[tid] = 0;
+		__syncthreads();
+#pragma unroll
+		for (int j = 0; j < DC_BATCH; ++j)
+		{
+			const uint64_t want = __ballot(visible[j]);
+			if (want)
+			{
+				uint32_t slot = 0;
+				if (lane == 0)
+					slot = atomicAdd(&s_reqCount, (uint32_t)__builtin_popcountll(want));
+				slot = __builtin_amdgcn_readfirstlane(slot) + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+				if (visible[j])
+				{
+					s_req[slot] = make_float4(pre[j].c.x, pre[j].c.y, pre[j].c.z, pre[j].radius);
+					s_reqSlot[slot] = (uint16_t)(j * DC_THREADS + tid);
+				}
+			}
+		}
+		__syncthreads();
+		const uint32_t requests = s_reqCount;
+		for (uint32_t r = tid; r < requests; r += DC_THREADS)
+		{
+			const float4 q = s_req[r];
+			if (draw_probe(a, f3{ q.x, q.y, q.z }, q.w, s_hizTail))
+			{
+				const uint32_t slot = s_reqSlot[r];
+				atomicOr(&s_seen[slot >> 5], 1u << (slot & 31u));
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int j = 0; j < DC_BATCH; ++j)
+		{
+			const uint32_t slot = j * DC_THREADS + tid;
+			visible[j] = visible[j] && (s_seen[slot >> 5] >> (slot & 31u) & 1u) != 0;
+		}
+	}
 #pragma unroll
 	for (int j = 0; j < DC_BATCH; ++j)
 	{
@@ -358,7 +439,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 			if (NV_DBG(a, 1u)) // experiments: loads only
 				res.lodWord = __float_as_uint(ld[j].d0.x + ld[j].d1.x) + ld[j].d2.x + ld[j].oldVis == 12345u ? 0x100u : 0u;
 			else
-				res = decide_draw<LATE, TASK, MESH_LDS, SOA>(a, meshBase, first + c, ld[j].d0, ld[j].d1, ld[j].d2, ld[j].oldVis, s_hizTail);
+				res = decide_post<LATE, TASK, MESH_LDS>(a, pre[j], visible[j], first + c, ld[j].oldVis);
 			a.results[first + c] = (uint8_t)((res.lodWord & 7u) | ((res.lodWord >> 8 & 1u) << 3) | ((ld[j].oldVis != 0 ? 1u : 0u) << 4));
 			count = res.count;
 		}
