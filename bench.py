@@ -6,7 +6,10 @@ Workload (config.workload = "config3A"): BASELINE.json configs[2] — synthetic 
 clusterBackfaceEnabled = 1) with ordered compaction of the visible IDs.  One "step" = one pass of the hot path over
 one batch: reset of the count word (the caller's vkCmdFillBuffer, src/niagara.cpp:1586; fused into the pass through
 NV_OPT_FUSED_COUNT_RESET unless --explicit-reset) + nv_clustercull, with inputs resident in HBM.  Steps rotate over `--copies` distinct input sets so that every pass streams from HBM rather
-than from the 256 MiB Infinity Cache.  N > 1: the pool shards by contiguous command ranges, every rank culls its own
+than from the 256 MiB Infinity Cache.  The steps are independent passes (different batches), so they are issued round-robin on
+`--streams` HIP streams (default 2; one nv_context, output list and count word per stream): the latency-bound scatter launch
+of one pass overlaps the ramp of the next pass's cull launch.  `value` / `ms_per_step` are that throughput;
+`roofline.ms_per_pass_single_stream` is one pass after the other on one stream, and the kernels are timed that way.  N > 1: the pool shards by contiguous command ranges, every rank culls its own
 10 M meshlets (weak scaling) and the only collective is the all-reduce of the passes' visible counts (RCCL; the rows of
 `--counts-batch` passes, written by the scatter launches, share one asynchronous all-reduce; 1 = one collective per pass).
 
@@ -41,6 +44,8 @@ def parse():
     ap.add_argument("--counts-batch", type=int, default=8, help="N > 1: passes whose counts share one all-reduce (1 = one collective per pass)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for functional tests)")
     ap.add_argument("--shared-device", action="store_true", help="functional test only: all ranks use cuda:0 (needs --backend gloo)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent passes in flight: steps are issued round-robin on this many HIP streams, one nv_context (scratch, outputs) per stream; 1 = strictly one pass after the other")
     ap.add_argument("--explicit-reset", action="store_true",
                     help="reference contract: zero the count word with a separate launch (nv_reset_count) instead of NV_OPT_FUSED_COUNT_RESET")
     return ap.parse_args()
@@ -97,9 +102,17 @@ def main():
     copies = max(1, args.copies)
     draws, meshlets, cd, count4 = make_inputs(n_draws, cpd, rank, world)
 
-    ctx = P.Context(local_rank)
+    # Independent passes overlap: a pass is a bandwidth-bound cull launch followed by a latency-bound scatter launch, so the
+    # scatter of pass i (16 waves per CU, ~6 us) and the ramp of the cull launch of pass i + 1 can share the chip.  Steps are
+    # issued round-robin on `--streams` HIP streams, each with its own nv_context (ballot scratch, tile counts, hints), output
+    # list and count word; every step still does the whole pass, and all of them complete inside the timed region.
+    S = max(1, args.streams)
+    ctxs = [P.Context(local_rank) for _ in range(S)]
+    ctx = ctxs[0]
     if not args.explicit_reset:
-        ctx.set_option(P.NV_OPT_FUSED_COUNT_RESET, 1)  # the pass absorbs the caller's vkCmdFillBuffer(ccb, 0, 4, 0)
+        for c in ctxs:
+            c.set_option(P.NV_OPT_FUSED_COUNT_RESET, 1)  # the pass absorbs the caller's vkCmdFillBuffer(ccb, 0, 4, 0)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
     db = P.to_device(draws, dev)
     mlb = torch.empty(copies * n_meshlets * L.MESHLET.itemsize, dtype=torch.uint8, device=dev)
     one = torch.from_numpy(meshlets.view(np.uint8).reshape(-1))
@@ -107,23 +120,44 @@ def main():
         mlb[c * one.numel():(c + 1) * one.numel()].copy_(one)
     dcbs = [P.to_device(synth.make_task_commands(n_draws, cpd, meshlet_base=c * n_meshlets), dev) for c in range(copies)]
     dccb = torch.from_numpy(count4.view(np.int32).copy()).to(dev)
-    cib = torch.zeros(min(n_meshlets, L.CLUSTER_LIMIT) + 256, dtype=torch.int32, device=dev)
-    ccb = torch.zeros(4, dtype=torch.int32, device=dev)
-    # N > 1: the passes' counts are summed over the ranks; batched, asynchronous, written by the scatter launch (shard.CountsReducer)
+    cibs = [torch.zeros(min(n_meshlets, L.CLUSTER_LIMIT) + 256, dtype=torch.int32, device=dev) for _ in range(S)]
+    ccbs = [torch.zeros(4, dtype=torch.int32, device=dev) for _ in range(S)]
+    cib, ccb = cibs[0], ccbs[0]
+    # N > 1: the passes' counts are summed over the ranks; batched, asynchronous, written by the scatter launch (shard.CountsReducer,
+    # one per stream: a stream's reducer sees that stream's passes)
     B = max(1, args.counts_batch)
-    red = shard.CountsReducer(ctx, dev, B)
+    reds = [shard.CountsReducer(c, dev, B) for c in ctxs]
     if not args.aos:
-        ctx.upload_meshlets(mlb, copies * n_meshlets)
+        for c in ctxs:
+            c.upload_meshlets(mlb, copies * n_meshlets)
     torch.cuda.synchronize()
 
-    def step(i):
+    def one_pass(s, j, i):
+        """pass i of the run = pass j of stream s (issued on the current stream)"""
         if args.explicit_reset:
-            ctx.reset_count(ccb)  # the caller's vkCmdFillBuffer(ccb, 0, 4, 0) as its own launch
-        red.before_pass(i)
-        ctx.clustercull(cd, 0, dcbs[i % copies], dccb, db, mlb, None, None, cib, ccb)
-        red.after_pass(i)
+            ctxs[s].reset_count(ccbs[s])  # the caller's vkCmdFillBuffer(ccb, 0, 4, 0) as its own launch
+        reds[s].before_pass(j)
+        ctxs[s].clustercull(cd, 0, dcbs[i % copies], dccb, db, mlb, None, None, cibs[s], ccbs[s])
+        reds[s].after_pass(j)
 
-    drain = red.drain
+    def step(i):
+        s = i % S
+        if S == 1:
+            one_pass(0, i, i)
+        else:
+            with torch.cuda.stream(streams[s]):
+                one_pass(s, i // S, i)
+
+    def passes_of(s, n):
+        return (n - s + S - 1) // S if n > s else 0
+
+    def drain(n):
+        for s in range(S):
+            if S == 1:
+                reds[s].drain(passes_of(s, n))
+            else:
+                with torch.cuda.stream(streams[s]):
+                    reds[s].drain(passes_of(s, n))
 
     for i in range(args.warmup):
         step(i)
@@ -143,7 +177,26 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    last_counts = red.last(args.steps) if world > 1 else None
+    s_last = (args.steps - 1) % S
+    last_counts = reds[s_last].last(passes_of(s_last, args.steps)) if world > 1 else None
+    visible_by_stream = [int(c[0].item()) for c in ccbs]
+
+    # ---- one pass after the other on ONE stream (what a single pass costs end to end), same number of steps, untimed by `value`
+    single = shard.CountsReducer(ctx, dev, B)
+
+    def serial_step(i):
+        if args.explicit_reset:
+            ctx.reset_count(ccb)
+        single.before_pass(i)
+        ctx.clustercull(cd, 0, dcbs[i % copies], dccb, db, mlb, None, None, cib, ccb)
+        single.after_pass(i)
+
+    t2 = time.perf_counter()
+    for i in range(args.steps):
+        serial_step(i)
+    single.drain(args.steps)
+    torch.cuda.synchronize()
+    serial = time.perf_counter() - t2
 
     # ---- roofline leg: the same `steps` passes again with the library's HIP events bracketing each kernel on the
     # launch stream (nv_profile_*).  It is a separate loop because an event record is itself a barrier packet: three
@@ -151,8 +204,8 @@ def main():
     ctx.profile(True)
     t1 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
-    drain(args.steps)
+        serial_step(i)  # one stream: the kernels are timed without a neighbour pass on the chip
+    single.drain(args.steps)
     torch.cuda.synchronize()
     profiled = time.perf_counter() - t1
     prof = ctx.profile_read()
@@ -201,8 +254,9 @@ def main():
             "config": {"workload": "config3A: %d meshlets/GPU, %d task commands over %d draws, cone+frustum clustercull (LATE=0) + ordered compaction"
                                    % (n_meshlets, n_cmd, n_draws),
                        "meshlets_per_gpu": n_meshlets, "commands_per_gpu": n_cmd, "draws_per_gpu": n_draws,
+                       "streams": S, "passes_in_flight": "steps issued round-robin on %d HIP streams, one nv_context / output list per stream; the scatter launch of a pass overlaps the next pass's cull launch" % S if S > 1 else "one pass after the other",
                        "input_copies_rotated": copies, "count_reset": "explicit launch" if args.explicit_reset else "fused (NV_OPT_FUSED_COUNT_RESET)", "meshlet_layout": "AoS24" if args.aos else "SoA12",
-                       "visible_per_gpu": visible, "visible_total": total_visible, "sharding": "commands x%d" % world,
+                       "visible_per_gpu": visible, "visible_per_stream": visible_by_stream, "visible_total": total_visible, "sharding": "commands x%d" % world,
                        "counts_allreduce": ("none (N=1)" if world == 1 else "one async all-reduce of [%d, 3] int64 per %d passes, rows written by the scatter launch" % (B, B))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_measured_in_run": False, "traffic_source": traffic_note,
@@ -210,8 +264,12 @@ def main():
                          "algorithmic_bytes": algo_bytes, "launches_timed": cull_n,
                          "scatter_kernel_avg_us": scatter_avg_s * 1e6, "ms_per_step_with_events": profiled / args.steps * 1e3,
                          "pass_algorithmic_bytes": pass_bytes,
-                         # the whole pass (cull + scatter launches) against the roofline, from the un-instrumented timed region
-                         "pass_frac": pass_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+                         # one pass after the other on one stream, un-instrumented: what a single pass takes end to end
+                         "ms_per_pass_single_stream": serial / args.steps * 1e3,
+                         # the whole pass (cull + scatter launches) against the roofline: from that single-stream time, and
+                         # from the timed region's throughput (passes overlapping on `streams` streams)
+                         "pass_frac": pass_bytes / (serial / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         "pass_frac_overlapped": pass_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
             "library": niagara_amd.SO_PATH,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -24,8 +24,8 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("batch", [8, 1, 3])
-def test_bench_two_ranks_on_one_device(batch):
+@pytest.mark.parametrize("batch, streams", [(8, 2), (1, 2), (3, 2), (8, 1), (3, 3)])
+def test_bench_two_ranks_on_one_device(batch, streams):
     """python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --backend gloo --shared-device: rc 0, one JSON
     line, and the all-reduced visible count of the last pass = the sum of what the oracle sees in the two shards"""
     import oracle
@@ -36,13 +36,14 @@ def test_bench_two_ranks_on_one_device(batch):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
            str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--shared-device", "--steps", str(steps), "--warmup", "3",
-           "--counts-batch", str(batch), "--draws", str(draws_per_rank), "--no-cpu-baseline"]
+           "--counts-batch", str(batch), "--streams", str(streams), "--draws", str(draws_per_rank), "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["steps"] == steps and rec["scaling"] == "weak"
+    assert rec["n_gpus"] == 2 and rec["steps"] == steps and rec["scaling"] == "weak" and rec["config"]["streams"] == streams
+    assert len(set(rec["config"]["visible_per_stream"])) == 1  # every stream's last pass saw the same scene
     want = []
     for rank in range(2):
         draws, meshlets, cd, c4 = bench.make_inputs(draws_per_rank, cpd, rank, 2)
