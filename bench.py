@@ -270,6 +270,9 @@ def main():
                          # from the timed region's throughput (passes overlapping on `streams` streams)
                          "pass_frac": pass_bytes / (serial / args.steps) / 1e9 / HBM_PEAK_GBS,
                          "pass_frac_overlapped": pass_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+            "note": ("value and ms_per_step are THROUGHPUT figures: the %d steps are independent passes issued round-robin on %d HIP streams, so consecutive "
+                     "passes overlap (scatter launch of one under the cull launch of the next) and ms_per_step can be shorter than one pass; a single pass end to end takes "
+                     "roofline.ms_per_pass_single_stream, and the kernels were timed one pass after the other" % (args.steps, S)) if S > 1 else "one pass after the other on one stream",
             "library": niagara_amd.SO_PATH,
         }
         if world == 1 and not args.no_cpu_baseline:
