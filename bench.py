@@ -7,7 +7,7 @@ clusterBackfaceEnabled = 1) with ordered compaction of the visible IDs.  One "st
 one batch: reset of the count word (the caller's vkCmdFillBuffer, src/niagara.cpp:1586; fused into the pass through
 NV_OPT_FUSED_COUNT_RESET unless --explicit-reset) + nv_clustercull, with inputs resident in HBM.  Steps rotate over `--copies` distinct input sets so that every pass streams from HBM rather
 than from the 256 MiB Infinity Cache.  The steps are independent passes (different batches), so they are issued round-robin on
-`--streams` HIP streams (default 2; one nv_context, output list and count word per stream): the latency-bound scatter launch
+`--streams` HIP streams (default 3; one nv_context, output list and count word per stream): the latency-bound scatter launch
 of one pass overlaps the ramp of the next pass's cull launch.  `value` / `ms_per_step` are that throughput;
 `roofline.ms_per_pass_single_stream` is one pass after the other on one stream, and the kernels are timed that way.  N > 1: the pool shards by contiguous command ranges, every rank culls its own
 10 M meshlets (weak scaling) and the only collective is the all-reduce of the passes' visible counts (RCCL; the rows of
@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--counts-batch", type=int, default=8, help="N > 1: passes whose counts share one all-reduce (1 = one collective per pass)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for functional tests)")
     ap.add_argument("--shared-device", action="store_true", help="functional test only: all ranks use cuda:0 (needs --backend gloo)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="independent passes in flight: steps are issued round-robin on this many HIP streams, one nv_context (scratch, outputs) per stream; 1 = strictly one pass after the other")
     ap.add_argument("--explicit-reset", action="store_true",
                     help="reference contract: zero the count word with a separate launch (nv_reset_count) instead of NV_OPT_FUSED_COUNT_RESET")
@@ -191,10 +191,15 @@ def main():
         ctx.clustercull(cd, 0, dcbs[i % copies], dccb, db, mlb, None, None, cib, ccb)
         single.after_pass(i)
 
-    t2 = time.perf_counter()
-    for i in range(args.steps):
+    n_prof = max(args.steps, 100)  # (a short run still averages the single-stream pass and the kernels over 100 launches)
+    for i in range(5):
         serial_step(i)
-    single.drain(args.steps)
+    single.drain(5)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for i in range(n_prof):
+        serial_step(i)
+    single.drain(n_prof)
     torch.cuda.synchronize()
     serial = time.perf_counter() - t2
 
@@ -203,9 +208,9 @@ def main():
     # records per pass serialise the launches and cost ~10 us per pass, which would deflate `value` by ~25 %.
     ctx.profile(True)
     t1 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(n_prof):
         serial_step(i)  # one stream: the kernels are timed without a neighbour pass on the chip
-    single.drain(args.steps)
+    single.drain(n_prof)
     torch.cuda.synchronize()
     profiled = time.perf_counter() - t1
     prof = ctx.profile_read()
@@ -262,13 +267,13 @@ def main():
                          "traffic": traffic, "traffic_measured_in_run": False, "traffic_source": traffic_note,
                          "kernel": "cluster_mask_kernel", "kernel_avg_us": kernel_avg_s * 1e6,
                          "algorithmic_bytes": algo_bytes, "launches_timed": cull_n,
-                         "scatter_kernel_avg_us": scatter_avg_s * 1e6, "ms_per_step_with_events": profiled / args.steps * 1e3,
+                         "scatter_kernel_avg_us": scatter_avg_s * 1e6, "ms_per_step_with_events": profiled / n_prof * 1e3,
                          "pass_algorithmic_bytes": pass_bytes,
                          # one pass after the other on one stream, un-instrumented: what a single pass takes end to end
-                         "ms_per_pass_single_stream": serial / args.steps * 1e3,
+                         "ms_per_pass_single_stream": serial / n_prof * 1e3,
                          # the whole pass (cull + scatter launches) against the roofline: from that single-stream time, and
                          # from the timed region's throughput (passes overlapping on `streams` streams)
-                         "pass_frac": pass_bytes / (serial / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         "pass_frac": pass_bytes / (serial / n_prof) / 1e9 / HBM_PEAK_GBS,
                          "pass_frac_overlapped": pass_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
             "note": ("value and ms_per_step are THROUGHPUT figures: the %d steps are independent passes issued round-robin on %d HIP streams, so consecutive "
                      "passes overlap (scatter launch of one under the cull launch of the next) and ms_per_step can be shorter than one pass; a single pass end to end takes "

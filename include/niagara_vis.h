@@ -201,6 +201,12 @@ int nv_profile_read(nv_context* ctx, float out_ms[NV_PROF_SLOTS], uint32_t out_c
  * last workgroup of their scatter launches knows the final count.  nv_tasksubmit / nv_clustersubmit can then be
  * skipped (calling them anyway is harmless: they are idempotent); two launches less per frame phase. */
 #define NV_OPT_FUSED_SUBMIT 2
+/* NV_OPT_CULL_WORKGROUPS_PER_CU (default 6, 1..8): workgroups per CU of nv_clustercull's cull launch.  6 fill a CU and give
+ * one pass its shortest time; a caller that keeps several independent passes in flight (contexts on different streams:
+ * the cluster passes of several views) gets more throughput from 3, which let two passes' cull launches share the chip
+ * (10 M meshlets, three passes in flight: 23.5 instead of 24.7 us per pass; a single pass: 26.3 instead of 25.0 us).
+ * Speed only: the results do not depend on it. */
+#define NV_OPT_CULL_WORKGROUPS_PER_CU 3
 int nv_set_option(nv_context* ctx, int option, int value);
 
 /* ---- scene upload hook (next to uploadBuffer(mlb), src/niagara.cpp:1055) ----

@@ -335,6 +335,11 @@ int nv_set_option(nv_context* ctx, int option, int value)
 	case NV_OPT_FUSED_SUBMIT:
 		ctx->fusedSubmit = value ? 1u : 0u;
 		return NV_OK;
+	case NV_OPT_CULL_WORKGROUPS_PER_CU:
+		if (value < 1 || value > 8)
+			return NV_EINVAL;
+		ctx->ccBlocksPerCU = (uint32_t)value;
+		return NV_OK;
 	default:
 		return NV_EINVAL;
 	}
@@ -636,7 +641,7 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	if (ctx->debugMode & 8u)
 	{
 		if (!ctx->timing)
-			(void)hipMalloc(&ctx->timing, (size_t)persistent_grid(ctx, ctx->ccBlocksPerCU) * 4 * 8 * sizeof(unsigned long long));
+			(void)hipMalloc(&ctx->timing, (size_t)persistent_grid(ctx, 8) * 4 * 8 * sizeof(unsigned long long)); // (room for any NV_OPT_CULL_WORKGROUPS_PER_CU)
 		a.probeOut = ctx->timing;
 	}
 #endif

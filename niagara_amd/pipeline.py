@@ -37,6 +37,7 @@ def from_device(t, dtype, count=None):
 
 NV_OPT_FUSED_COUNT_RESET = 1
 NV_OPT_FUSED_SUBMIT = 2
+NV_OPT_CULL_WORKGROUPS_PER_CU = 3
 
 
 class Context:

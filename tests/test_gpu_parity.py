@@ -1013,3 +1013,31 @@ def test_late_pass_with_no_commands_and_with_one(ctx):
     assert _compare_cluster_pass(ctx, draws, meshlets, commands, 0, cd, 1, mvb0, pyr, gp) == 0
     assert _compare_cluster_pass(ctx, draws, meshlets, commands, n, cd, 1, mvb0, pyr, gp) == seen
     _compare_cluster_pass(ctx, draws, meshlets, commands, 1, cd, 1, mvb0, pyr, gp)
+
+
+def test_cull_workgroups_option_changes_nothing_but_speed():
+    """NV_OPT_CULL_WORKGROUPS_PER_CU (a throughput knob for callers with several passes in flight): every allowed value gives
+    the oracle's list, early pass and the three-launch late pass; values outside 1..8 are refused"""
+    rng = np.random.default_rng(41)
+    ctx = P.Context(0)
+    draws, meshlets, commands, n, cd = _cluster_inputs(3000, 7, seed=14)
+    draws["position"] *= np.float32(0.3)
+    commands["lateDrawVisibility"][:n] = rng.integers(0, 2, n)
+    mvb0 = rng.integers(0, 2 ** 32, n * 2 + 3, dtype=np.uint64).astype(np.uint32)
+    pyr = oracle.Pyramid(256, 192)
+    depth = make_scene(seed=3)["depth"]
+    oracle.depthreduce(depth, pyr)
+    gp = P.DepthPyramid(ctx.device, 256, 192)
+    ctx.depthreduce(torch.from_numpy(depth).to(ctx.device), 256, 192, gp.desc)
+    late = cd.copy()
+    late["pyramidWidth"], late["pyramidHeight"], late["clusterOcclusionEnabled"] = pyr.width, pyr.height, 1
+    for bad in (0, 9, -1):
+        with pytest.raises(P.NvError):
+            ctx.set_option(P.NV_OPT_CULL_WORKGROUPS_PER_CU, bad)
+    seen = set()
+    for wg in (1, 3, 6, 8):
+        ctx.set_option(P.NV_OPT_CULL_WORKGROUPS_PER_CU, wg)
+        seen.add(_compare_cluster_pass(ctx, draws, meshlets, commands, n, cd, 0, None, None, None))
+        seen.add(_compare_cluster_pass(ctx, draws, meshlets, commands, n, late, 1, mvb0, pyr, gp))
+    assert len(seen) == 2 and min(seen) > 0
+    ctx.close()
