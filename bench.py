@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--shared-device", action="store_true", help="functional test only: all ranks use cuda:0 (needs --backend gloo)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent passes in flight: steps are issued round-robin on this many HIP streams, one nv_context (scratch, outputs) per stream; 1 = strictly one pass after the other")
+    ap.add_argument("--scatter-waves", type=int, default=0, help="NV_OPT_SCATTER_WAVES (4, 8 or 16); 0 = 8 with several streams, 16 with one")
     ap.add_argument("--explicit-reset", action="store_true",
                     help="reference contract: zero the count word with a separate launch (nv_reset_count) instead of NV_OPT_FUSED_COUNT_RESET")
     return ap.parse_args()
@@ -112,6 +113,11 @@ def main():
     if not args.explicit_reset:
         for c in ctxs:
             c.set_option(P.NV_OPT_FUSED_COUNT_RESET, 1)  # the pass absorbs the caller's vkCmdFillBuffer(ccb, 0, 4, 0)
+    scatter_waves = args.scatter_waves if args.scatter_waves else (8 if S > 1 else 16)
+    for c in ctxs:
+        # several passes in flight: the scatter launch with 8 instead of 16 waves per workgroup leaves more of the CUs' wave slots to the
+        # neighbour pass's cull launch (the same setting in every leg of this run, also the single-stream ones)
+        c.set_option(P.NV_OPT_SCATTER_WAVES, scatter_waves)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
     db = P.to_device(draws, dev)
     mlb = torch.empty(copies * n_meshlets * L.MESHLET.itemsize, dtype=torch.uint8, device=dev)
@@ -126,38 +132,32 @@ def main():
     # N > 1: the passes' counts are summed over the ranks; batched, asynchronous, written by the scatter launch (shard.CountsReducer,
     # one per stream: a stream's reducer sees that stream's passes)
     B = max(1, args.counts_batch)
-    reds = [shard.CountsReducer(c, dev, B) for c in ctxs]
+    reds = [shard.CountsReducer(ctxs[s], dev, B, stream=streams[s] if S > 1 else None) for s in range(S)]
     if not args.aos:
         for c in ctxs:
             c.upload_meshlets(mlb, copies * n_meshlets)
     torch.cuda.synchronize()
-
-    def one_pass(s, j, i):
-        """pass i of the run = pass j of stream s (issued on the current stream)"""
-        if args.explicit_reset:
-            ctxs[s].reset_count(ccbs[s])  # the caller's vkCmdFillBuffer(ccb, 0, 4, 0) as its own launch
-        reds[s].before_pass(j)
-        ctxs[s].clustercull(cd, 0, dcbs[i % copies], dccb, db, mlb, None, None, cibs[s], ccbs[s])
-        reds[s].after_pass(j)
+    # every argument of a pass marshalled once (Context.bind_clustercull): at ~24 us per step the per-call marshalling of the
+    # Python layer (stream lookup, eight data_ptr() calls, a stream context) is what the host cannot afford, not the launch
+    calls = [[ctxs[s].bind_clustercull(streams[s] if S > 1 else None, cd, 0, dcbs[c], dccb, db, mlb, None, None, cibs[s], ccbs[s]) for c in range(copies)]
+             for s in range(S)]
 
     def step(i):
+        """pass i of the run = pass i // S of stream i % S"""
         s = i % S
-        if S == 1:
-            one_pass(0, i, i)
-        else:
+        if args.explicit_reset:  # the caller's vkCmdFillBuffer(ccb, 0, 4, 0) as its own launch, on the pass's stream
             with torch.cuda.stream(streams[s]):
-                one_pass(s, i // S, i)
+                ctxs[s].reset_count(ccbs[s])
+        reds[s].before_pass(i // S)
+        calls[s][i % copies]()
+        reds[s].after_pass(i // S)
 
     def passes_of(s, n):
         return (n - s + S - 1) // S if n > s else 0
 
     def drain(n):
         for s in range(S):
-            if S == 1:
-                reds[s].drain(passes_of(s, n))
-            else:
-                with torch.cuda.stream(streams[s]):
-                    reds[s].drain(passes_of(s, n))
+            reds[s].drain(passes_of(s, n))
 
     for i in range(args.warmup):
         step(i)
@@ -184,11 +184,13 @@ def main():
     # ---- one pass after the other on ONE stream (what a single pass costs end to end), same number of steps, untimed by `value`
     single = shard.CountsReducer(ctx, dev, B)
 
+    serial_calls = [ctx.bind_clustercull(None, cd, 0, dcbs[c], dccb, db, mlb, None, None, cib, ccb) for c in range(copies)]
+
     def serial_step(i):
         if args.explicit_reset:
             ctx.reset_count(ccb)
         single.before_pass(i)
-        ctx.clustercull(cd, 0, dcbs[i % copies], dccb, db, mlb, None, None, cib, ccb)
+        serial_calls[i % copies]()
         single.after_pass(i)
 
     n_prof = max(args.steps, 100)  # (a short run still averages the single-stream pass and the kernels over 100 launches)
@@ -259,7 +261,7 @@ def main():
             "config": {"workload": "config3A: %d meshlets/GPU, %d task commands over %d draws, cone+frustum clustercull (LATE=0) + ordered compaction"
                                    % (n_meshlets, n_cmd, n_draws),
                        "meshlets_per_gpu": n_meshlets, "commands_per_gpu": n_cmd, "draws_per_gpu": n_draws,
-                       "streams": S, "passes_in_flight": "steps issued round-robin on %d HIP streams, one nv_context / output list per stream; the scatter launch of a pass overlaps the next pass's cull launch" % S if S > 1 else "one pass after the other",
+                       "streams": S, "scatter_waves_per_workgroup": scatter_waves, "passes_in_flight": "steps issued round-robin on %d HIP streams, one nv_context / output list per stream; the scatter launch of a pass overlaps the next pass's cull launch" % S if S > 1 else "one pass after the other",
                        "input_copies_rotated": copies, "count_reset": "explicit launch" if args.explicit_reset else "fused (NV_OPT_FUSED_COUNT_RESET)", "meshlet_layout": "AoS24" if args.aos else "SoA12",
                        "visible_per_gpu": visible, "visible_per_stream": visible_by_stream, "visible_total": total_visible, "sharding": "commands x%d" % world,
                        "counts_allreduce": ("none (N=1)" if world == 1 else "one async all-reduce of [%d, 3] int64 per %d passes, rows written by the scatter launch" % (B, B))},

@@ -207,6 +207,11 @@ int nv_profile_read(nv_context* ctx, float out_ms[NV_PROF_SLOTS], uint32_t out_c
  * (10 M meshlets, three passes in flight: 23.5 instead of 24.7 us per pass; a single pass: 26.3 instead of 25.0 us).
  * Speed only: the results do not depend on it. */
 #define NV_OPT_CULL_WORKGROUPS_PER_CU 3
+/* NV_OPT_SCATTER_WAVES (default 16; 4 or 8): waves per workgroup of nv_clustercull's scatter launch.  16 (one command per
+ * lane) is the shortest launch; 4 leave the other wave slots of every CU to a neighbour pass's cull launch when several
+ * passes are in flight (10 M meshlets, three passes in flight: 23.3 instead of 24.8 us per pass; a single pass: 31.5
+ * instead of 30.1 us).  Speed only. */
+#define NV_OPT_SCATTER_WAVES 4
 int nv_set_option(nv_context* ctx, int option, int value);
 
 /* ---- scene upload hook (next to uploadBuffer(mlb), src/niagara.cpp:1055) ----

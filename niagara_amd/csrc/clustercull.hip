@@ -2242,7 +2242,6 @@ bool clustercull_prefers_direct(uint32_t previousCommandCount, uint32_t previous
 	return previousCommandCount != 0 && (uint64_t)previousPassedFilter * 100u > (uint64_t)previousCommandCount * percent;
 }
 
-// one workgroup per scatter tile (context.hip: one per CU, at most CC_MAX_SCATTER_TILES); no workgroup waits on another
 // late pass with HiZ, stage 2: any grid size (grid-stride over blocks of CH_CMDS commands)
 int launch_cluster_hiz(hipStream_t stream, const ClusterArgs& a, bool soa, uint32_t gridBlocks)
 {
@@ -2265,9 +2264,17 @@ int launch_cluster_hiz(hipStream_t stream, const ClusterArgs& a, bool soa, uint3
 	return (int)hipGetLastError();
 }
 
-int launch_cluster_scatter(hipStream_t stream, const ClusterArgs& a, uint32_t scatterBlocks)
+// one workgroup per scatter tile (context.hip: one per CU, at most CC_MAX_SCATTER_TILES); no workgroup waits on another.
+// waves = 16 (one command per lane: the shortest launch) or 4 / 8 (NV_OPT_SCATTER_WAVES: fewer wave slots per CU, for callers
+// that keep several passes in flight — the launch then shares the chip with a neighbour pass's cull launch)
+int launch_cluster_scatter(hipStream_t stream, const ClusterArgs& a, uint32_t scatterBlocks, uint32_t waves)
 {
-	hipLaunchKernelGGL((cluster_scatter_kernel<16>), dim3(scatterBlocks), dim3(16 * 64), 0, stream, a);
+	if (waves == 4u)
+		hipLaunchKernelGGL((cluster_scatter_kernel<4>), dim3(scatterBlocks), dim3(4 * 64), 0, stream, a);
+	else if (waves == 8u)
+		hipLaunchKernelGGL((cluster_scatter_kernel<8>), dim3(scatterBlocks), dim3(8 * 64), 0, stream, a);
+	else
+		hipLaunchKernelGGL((cluster_scatter_kernel<16>), dim3(scatterBlocks), dim3(16 * 64), 0, stream, a);
 	return (int)hipGetLastError();
 }
 

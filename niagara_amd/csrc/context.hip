@@ -20,7 +20,7 @@ namespace nv
 int launch_cluster_mask(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t maskBlocks, bool shallow, bool direct);
 bool clustercull_prefers_shallow(uint32_t previousCommandCount);
 bool clustercull_prefers_direct(uint32_t previousCommandCount, uint32_t previousPassedFilter, uint32_t percent);
-int launch_cluster_scatter(hipStream_t, const ClusterArgs&, uint32_t scatterBlocks);
+int launch_cluster_scatter(hipStream_t, const ClusterArgs&, uint32_t scatterBlocks, uint32_t waves);
 int launch_cluster_hiz(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
 size_t clustercull_mask_bytes();
 size_t clustercull_list_bytes();
@@ -86,6 +86,7 @@ struct nv_context
 	uint32_t ccBlocksPerCU;
 	uint32_t dealScale;
 	uint32_t scatterTilesPerCU;
+	uint32_t scatterWaves; // NV_OPT_SCATTER_WAVES: waves per workgroup of the cluster scatter launch (16; 4 / 8)
 	uint32_t scatterTilesAbs; // experiments: absolute number of scatter tiles (0 = per CU)
 	uint32_t hizLds; // stage the coarse pyramid levels in LDS for drawcull's late pass (experiments: measured slower)
 	uint32_t directPercent; // share of commands passing the filter above which the next launch skips the filter pass
@@ -216,6 +217,7 @@ int nv_create(nv_context** out_ctx, int device)
 	ctx->ccBlocksPerCU = 6;
 	ctx->dealScale = 100;
 	ctx->scatterTilesPerCU = 1;
+	ctx->scatterWaves = 16;
 	ctx->directPercent = 35; // measured crossover (config 3A geometry at several densities): ~36 % of the commands passing the filter
 	ctx->forceDirect = -1;
 	ctx->listStride = nv::clustercull_list_stride();
@@ -334,6 +336,11 @@ int nv_set_option(nv_context* ctx, int option, int value)
 		return NV_OK;
 	case NV_OPT_FUSED_SUBMIT:
 		ctx->fusedSubmit = value ? 1u : 0u;
+		return NV_OK;
+	case NV_OPT_SCATTER_WAVES:
+		if (value != 4 && value != 8 && value != 16)
+			return NV_EINVAL;
+		ctx->scatterWaves = (uint32_t)value;
 		return NV_OK;
 	case NV_OPT_CULL_WORKGROUPS_PER_CU:
 		if (value < 1 || value > 8)
@@ -668,7 +675,7 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 		eh = prof_mark(ctx, s);
 	}
 	if (rc == 0 && !(ctx->debugMode & 16u)) // bit 4 (experiments): ballots only
-		rc = nv::launch_cluster_scatter(s, a, a.scatterTiles);
+		rc = nv::launch_cluster_scatter(s, a, a.scatterTiles, ctx->scatterWaves);
 	hipEvent_t e2 = prof_mark(ctx, s);
 	prof_push(ctx, NV_PROF_CLUSTER_CULL, e0, e1);
 	if (twoStage)

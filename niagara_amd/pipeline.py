@@ -38,6 +38,7 @@ def from_device(t, dtype, count=None):
 NV_OPT_FUSED_COUNT_RESET = 1
 NV_OPT_FUSED_SUBMIT = 2
 NV_OPT_CULL_WORKGROUPS_PER_CU = 3
+NV_OPT_SCATTER_WAVES = 4
 
 
 class Context:
@@ -111,6 +112,22 @@ class Context:
     def clustercull(self, cull, late, dcb, dccb, db, mlb, mvb, pyramid, cib, ccb):
         check(lib.nv_clustercull(self.h, _stream(), C.c_void_p(cull.ctypes.data), int(late), _ptr(dcb), _ptr(dccb), _ptr(db), _ptr(mlb),
                                  _ptr(mvb), None if pyramid is None else C.byref(pyramid), _ptr(cib), _ptr(ccb)), "nv_clustercull")
+
+    def bind_clustercull(self, stream, cull, late, dcb, dccb, db, mlb, mvb, pyramid, cib, ccb):
+        """nv_clustercull with every argument marshalled once: returns a zero-argument callable that launches the pass on
+        `stream` (a torch.cuda.Stream, or None for the current one).  For callers that issue many passes back to back: the
+        per-call marshalling (stream lookup, data_ptr() of eight tensors) costs more host time than a 25 us pass leaves."""
+        st = C.c_void_p((torch.cuda.current_stream() if stream is None else stream).cuda_stream)
+        keep = (stream, cull, dcb, dccb, db, mlb, mvb, pyramid, cib, ccb)  # the closure keeps the buffers alive
+        args = (self.h, st, C.c_void_p(cull.ctypes.data), int(late), _ptr(dcb), _ptr(dccb), _ptr(db), _ptr(mlb), _ptr(mvb),
+                None if pyramid is None else C.byref(pyramid), _ptr(cib), _ptr(ccb))
+        fn = lib.nv_clustercull
+
+        def launch(_keep=keep):
+            rc = fn(*args)
+            if rc:
+                check(rc, "nv_clustercull")
+        return launch
 
     def clustersubmit(self, ccb, cib):
         check(lib.nv_clustersubmit(self.h, _stream(), _ptr(ccb), _ptr(cib)), "nv_clustersubmit")

@@ -47,10 +47,14 @@ class CountsReducer:
         red.drain(steps); total = red.last(steps)          # int64[3], summed over the ranks
     """
 
-    def __init__(self, ctx, device, batch=8):
+    def __init__(self, ctx, device, batch=8, stream=None):
+        import contextlib
         import torch
         import torch.distributed as dist
         self.ctx, self.dist, self.B = ctx, dist, max(1, int(batch))
+        # the stream the context's passes are launched on (None: the current one): the collective is ordered behind it and
+        # waits are issued on it
+        self._on = (lambda: torch.cuda.stream(stream)) if stream is not None else contextlib.nullcontext
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.blocks = [torch.zeros((self.B, 3), dtype=torch.int64, device=device) for _ in range(2)]
         self.pending = [None, None]
@@ -60,26 +64,29 @@ class CountsReducer:
             return
         blk, row = (i // self.B) % 2, i % self.B
         if row == 0 and self.pending[blk] is not None:
-            self.pending[blk].wait()  # the block's previous reduction (issued 2 B passes ago)
+            with self._on():
+                self.pending[blk].wait()  # the block's previous reduction (issued 2 B passes ago)
             self.pending[blk] = None
         self.ctx.set_counts_sink(self.blocks[blk][row])
 
     def after_pass(self, i):
         if self.world > 1 and i % self.B == self.B - 1:
             blk = (i // self.B) % 2
-            self.pending[blk] = self.dist.all_reduce(self.blocks[blk], async_op=True)
+            with self._on():
+                self.pending[blk] = self.dist.all_reduce(self.blocks[blk], async_op=True)
 
     def drain(self, n_steps):
         """reduces the rows of a batch the loop left unfinished, then waits for everything in flight"""
         if self.world == 1:
             return
-        if n_steps % self.B:
-            blk = (n_steps // self.B) % 2
-            self.pending[blk] = self.dist.all_reduce(self.blocks[blk], async_op=True)
-        for k in range(2):
-            if self.pending[k] is not None:
-                self.pending[k].wait()
-                self.pending[k] = None
+        with self._on():
+            if n_steps % self.B:
+                blk = (n_steps // self.B) % 2
+                self.pending[blk] = self.dist.all_reduce(self.blocks[blk], async_op=True)
+            for k in range(2):
+                if self.pending[k] is not None:
+                    self.pending[k].wait()
+                    self.pending[k] = None
 
     def last(self, n_steps):
         """the summed counts of pass n_steps - 1 (after drain)"""

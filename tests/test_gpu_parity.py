@@ -1016,8 +1016,8 @@ def test_late_pass_with_no_commands_and_with_one(ctx):
 
 
 def test_cull_workgroups_option_changes_nothing_but_speed():
-    """NV_OPT_CULL_WORKGROUPS_PER_CU (a throughput knob for callers with several passes in flight): every allowed value gives
-    the oracle's list, early pass and the three-launch late pass; values outside 1..8 are refused"""
+    """NV_OPT_CULL_WORKGROUPS_PER_CU and NV_OPT_SCATTER_WAVES (throughput knobs for callers with several passes in flight):
+    every allowed value gives the oracle's list, early pass and the three-launch late pass; other values are refused"""
     rng = np.random.default_rng(41)
     ctx = P.Context(0)
     draws, meshlets, commands, n, cd = _cluster_inputs(3000, 7, seed=14)
@@ -1034,9 +1034,12 @@ def test_cull_workgroups_option_changes_nothing_but_speed():
     for bad in (0, 9, -1):
         with pytest.raises(P.NvError):
             ctx.set_option(P.NV_OPT_CULL_WORKGROUPS_PER_CU, bad)
+    with pytest.raises(P.NvError):
+        ctx.set_option(P.NV_OPT_SCATTER_WAVES, 5)
     seen = set()
-    for wg in (1, 3, 6, 8):
+    for wg, sw in ((1, 16), (3, 4), (6, 8), (8, 4), (6, 16)):
         ctx.set_option(P.NV_OPT_CULL_WORKGROUPS_PER_CU, wg)
+        ctx.set_option(P.NV_OPT_SCATTER_WAVES, sw)
         seen.add(_compare_cluster_pass(ctx, draws, meshlets, commands, n, cd, 0, None, None, None))
         seen.add(_compare_cluster_pass(ctx, draws, meshlets, commands, n, late, 1, mvb0, pyr, gp))
     assert len(seen) == 2 and min(seen) > 0

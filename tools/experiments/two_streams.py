@@ -37,6 +37,10 @@ ctxs, streams, cibs, ccbs = [], [], [], []
 for s in range(S):
     c = P.Context(0)
     c.set_option(P.NV_OPT_FUSED_COUNT_RESET, 1)
+    if os.environ.get("TS_SCATTER_WAVES"):
+        c.set_option(P.NV_OPT_SCATTER_WAVES, int(os.environ["TS_SCATTER_WAVES"]))
+    if os.environ.get("TS_CULL_WG"):
+        c.set_option(P.NV_OPT_CULL_WORKGROUPS_PER_CU, int(os.environ["TS_CULL_WG"]))
     c.upload_meshlets(mlb, copies * n_meshlets)
     ctxs.append(c)
     streams.append(torch.cuda.Stream())
