@@ -8,6 +8,8 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 run() { env "$@" python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline; }
 env "$@" rocprofv3 --kernel-trace --stats -f csv -d $out/kt -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $out/kt.log 2>&1
+# the same with one pass after the other (bench.py times the kernels that way: its roofline leg runs on one stream)
+env "$@" rocprofv3 --kernel-trace --stats -f csv -d $out/kt1 -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --streams 1 > $out/kt1.log 2>&1
 i=0
 for pmc in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" \

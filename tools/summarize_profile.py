@@ -26,6 +26,13 @@ def newest(pattern):
 
 for f in newest(src + "/kt/**/*kernel_stats.csv"):
     lines += [l[:230] for l in open(f).read().strip().split("\n")]
+lines += ["```", "", "## kernel stats, one pass after the other (`bench.py --streams 1 ...`, kernel-trace)", "",
+          "The default command issues its timed steps on three HIP streams, so the table above averages launches that shared the",
+          "chip with neighbour passes (timed region: longer individually, shorter per step) and launches that did not (the",
+          "single-stream and event-instrumented legs).  bench.py's `roofline` times the kernels one pass after the other; the trace",
+          "of that mode:", "", "```"]
+for f in newest(src + "/kt1/**/*kernel_stats.csv"):
+    lines += [l[:230] for l in open(f).read().strip().split("\n")[:4]]
 lines += ["```", "", "## bench.py line of the traced run", "", "```"]
 log = os.path.join(src, "kt.log")
 if os.path.exists(log):
