@@ -26,6 +26,10 @@ from scenes import make_scene  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7000
 ctx = P.Context(0)
+if os.environ.get("FUZZ_SCATTER_WAVES"):  # the throughput knobs must not change a result
+    ctx.set_option(P.NV_OPT_SCATTER_WAVES, int(os.environ["FUZZ_SCATTER_WAVES"]))
+if os.environ.get("FUZZ_CULL_WG"):
+    ctx.set_option(P.NV_OPT_CULL_WORKGROUPS_PER_CU, int(os.environ["FUZZ_CULL_WG"]))
 dev = ctx.device
 threads = oracle.max_threads()
 pyr = oracle.Pyramid(256, 192)
