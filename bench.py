@@ -5,16 +5,21 @@ Workload (config.workload = "config3A"): BASELINE.json configs[2] — synthetic 
 156 250 full MeshTaskCommands over 15 625 draws, per-meshlet cone + frustum cull (`clustercull`, LATE = 0,
 clusterBackfaceEnabled = 1) with ordered compaction of the visible IDs.  One "step" = one pass of the hot path over
 one batch: reset of the count word (the caller's vkCmdFillBuffer, src/niagara.cpp:1586; fused into the pass through
-NV_OPT_FUSED_COUNT_RESET unless --explicit-reset) + nv_clustercull, with inputs resident in HBM.  Steps rotate over `--copies` distinct input sets so that every pass streams from HBM rather
-than from the 256 MiB Infinity Cache.  The steps are independent passes (different batches), so they are issued round-robin on
-`--streams` HIP streams (default 3; one nv_context, output list and count word per stream): the latency-bound scatter launch
-of one pass overlaps the ramp of the next pass's cull launch.  `value` / `ms_per_step` are that throughput;
-`roofline.ms_per_pass_single_stream` is one pass after the other on one stream, and the kernels are timed that way.  N > 1: the pool shards by contiguous command ranges, every rank culls its own
-10 M meshlets (weak scaling) and the only collective is the all-reduce of the passes' visible counts (RCCL; the rows of
-`--counts-batch` passes, written by the scatter launches, share one asynchronous all-reduce; 1 = one collective per pass).
+NV_OPT_FUSED_COUNT_RESET unless --explicit-reset) + nv_clustercull, with inputs resident in HBM.  Steps rotate over
+`--copies` distinct input sets so that every pass streams from HBM rather than from the 256 MiB Infinity Cache.
 
-Prints ONE JSON line (rank 0):  metric/value/unit as in BASELINE.json + "roofline" (dominant kernel, HIP events on
-the launch stream) + "cpu_baseline" (the CPU oracle timed on this host's cores; a reported baseline, not a target).
+ONE regime: `value` / `ms_per_step` = one pass after the other on ONE stream — what a frame's
+dependent cull pass costs end to end — and `roofline` times the dominant kernel in that same mode (HIP events on the launch
+stream, a second loop of the same passes).  What several independent passes in flight reach (three views on three
+streams, contexts sharing one scene mirror) is reported next to it as `throughput_overlapped`, never as `value`.
+
+N > 1: the pool shards by contiguous command ranges and the only collective is the all-reduce of the passes' visible
+counts (RCCL; the rows of `--counts-batch` passes, written by the scatter launches, share one asynchronous all-reduce).
+Default = weak scaling (10 M meshlets per GPU); `--total-meshlets T` = strong scaling (the T-meshlet pool split over the
+ranks; `--gpus 8 --total-meshlets 100000000` is BASELINE config 5).
+
+Prints ONE JSON line (rank 0):  metric/value/unit as in BASELINE.json + "roofline" (dominant kernel) + "cpu_baseline"
+(the CPU oracle timed on this host's cores; a reported baseline, not a target).
 """
 import argparse
 import json
@@ -35,8 +40,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--draws", type=int, default=15625, help="draws per GPU (x commands-per-draw x 64 = meshlets)")
+    ap.add_argument("--draws", type=int, default=15625, help="weak scaling: draws per GPU (x commands-per-draw x 64 = meshlets per GPU)")
     ap.add_argument("--commands-per-draw", type=int, default=10)
+    ap.add_argument("--total-meshlets", type=int, default=0,
+                    help="strong scaling: the size of the WHOLE pool, split over the ranks by contiguous command ranges (100000000 with --gpus 8 = BASELINE config 5)")
     ap.add_argument("--copies", type=int, default=4, help="distinct input sets rotated through (cache-cold passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=4.0)
@@ -44,27 +51,50 @@ def parse():
     ap.add_argument("--counts-batch", type=int, default=8, help="N > 1: passes whose counts share one all-reduce (1 = one collective per pass)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for functional tests)")
     ap.add_argument("--shared-device", action="store_true", help="functional test only: all ranks use cuda:0 (needs --backend gloo)")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="independent passes in flight: steps are issued round-robin on this many HIP streams, one nv_context (scratch, outputs) per stream; 1 = strictly one pass after the other")
-    ap.add_argument("--scatter-waves", type=int, default=0, help="NV_OPT_SCATTER_WAVES (4, 8 or 16); 0 = 8 with several streams, 16 with one")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="streams of the timed region: 1 (default) = strictly one pass after the other; > 1 issues the steps round-robin on that many HIP streams "
+                         "(independent passes in flight) and says so in the line")
+    ap.add_argument("--overlap-streams", type=int, default=3, help="streams of the `throughput_overlapped` side leg (N = 1 only; 0 = skip it)")
+    ap.add_argument("--scatter-waves", type=int, default=0, help="NV_OPT_SCATTER_WAVES (4, 8 or 16) of the timed region; 0 = 16 with one stream, 8 with several")
     ap.add_argument("--explicit-reset", action="store_true",
                     help="reference contract: zero the count word with a separate launch (nv_reset_count) instead of NV_OPT_FUSED_COUNT_RESET")
     return ap.parse_args()
 
 
-def make_inputs(n_draws, cpd, rank, world):
-    """the rank's shard of the synthetic pool: (draws, meshlets, CullData, dccb words).  The pool's commands are
-    [0, world * n_draws * cpd); shard.command_range gives the rank its contiguous range, whose draws are the matching
-    slice of niagara's draw generator (src/niagara.cpp:978-997) and whose meshlets come from a per-rank seed."""
+def make_commands(b, e, cpd, meshlet_base=0):
+    """full task commands (taskCount 64) for the global command range [b, e) of the pool: command g belongs to draw g // cpd;
+    drawId is local to the rank's draw slice (which starts at draw b // cpd), meshlets and visibility slots are the rank's own,
+    packed from 0.  Padded with zeroed dummy commands to a multiple of 64 like tasksubmit leaves it."""
+    from niagara_amd import layouts as L
+    n = e - b
+    c = np.zeros((n + 63) // 64 * 64, dtype=L.TASKCMD)
+    k = np.arange(n, dtype=np.uint32)
+    c["drawId"][:n] = (k + np.uint32(b)) // cpd - np.uint32(b // cpd)
+    c["taskOffset"][:n] = k * 64 + meshlet_base
+    c["taskCount"][:n] = 64
+    c["meshletVisibilityOffset"][:n] = k * 64
+    return c
+
+
+def make_inputs(args, rank, world):
+    """the rank's shard of the synthetic pool: (draws, meshlets, CullData, command range).  The pool's commands shard by
+    contiguous ranges (shard.command_range); a rank's draws are the matching slice of niagara's draw generator
+    (src/niagara.cpp:978-997) — a draw whose commands straddle a shard boundary is present on both sides — and its meshlets
+    come from a per-rank seed."""
     from niagara_amd import host, shard, synth
-    n_cmd = n_draws * cpd
-    b, e = shard.command_range(n_cmd * world, rank, world)
-    assert (b, e) == (rank * n_cmd, (rank + 1) * n_cmd)
-    draws = host.synth_draws(n_draws * world, 1, 300.0)[b // cpd:e // cpd].copy()
-    draws["meshletVisibilityOffset"] = np.arange(n_draws, dtype=np.uint32) * (cpd * 64)
-    meshlets = synth.make_meshlets(n_cmd * 64, seed=2 + rank)
-    cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, clusterBackfaceEnabled=1)
-    return draws, meshlets, cd, synth.count4_for(n_cmd)
+    cpd = args.commands_per_draw
+    if args.total_meshlets:
+        total_cmd = args.total_meshlets // 64
+    else:
+        total_cmd = args.draws * cpd * world
+    b, e = shard.command_range(total_cmd, rank, world)
+    d0, d1 = b // cpd, (e + cpd - 1) // cpd
+    total_draws = (total_cmd + cpd - 1) // cpd
+    draws = host.synth_draws(total_draws, 1, 300.0)[d0:d1].copy()
+    draws["meshletVisibilityOffset"] = np.arange(d1 - d0, dtype=np.uint32) * (cpd * 64)
+    meshlets = synth.make_meshlets((e - b) * 64, seed=2 + rank)
+    cd = host.build_cull_data(draw_count=d1 - d0, cullingEnabled=1, clusterBackfaceEnabled=1)
+    return draws, meshlets, cd, (b, e), total_cmd
 
 
 def main():
@@ -95,49 +125,48 @@ def main():
         dist.all_reduce(torch.zeros(1, dtype=torch.int64, device=dev))
         torch.cuda.synchronize()
 
-    # ---- inputs: the pool of world x C commands shards by contiguous command ranges (niagara_amd/shard.py);
-    # rank r owns [r C, (r+1) C) and the 10 M meshlets they reference (weak scaling); draws follow their commands
-    n_draws, cpd = args.draws, args.commands_per_draw
-    n_cmd = n_draws * cpd
-    n_meshlets = n_cmd * 64
+    # ---- inputs: the pool shards by contiguous command ranges (niagara_amd/shard.py)
+    cpd = args.commands_per_draw
     copies = max(1, args.copies)
-    draws, meshlets, cd, count4 = make_inputs(n_draws, cpd, rank, world)
+    draws, meshlets, cd, (cmd_b, cmd_e), total_cmd = make_inputs(args, rank, world)
+    n_cmd = cmd_e - cmd_b
+    n_meshlets = n_cmd * 64
+    n_draws = len(draws)
+    total_meshlets = total_cmd * 64
+    count4 = synth.count4_for(n_cmd)
 
-    # Independent passes overlap: a pass is a bandwidth-bound cull launch followed by a latency-bound scatter launch, so the
-    # scatter of pass i (16 waves per CU, ~6 us) and the ramp of the cull launch of pass i + 1 can share the chip.  Steps are
-    # issued round-robin on `--streams` HIP streams, each with its own nv_context (ballot scratch, tile counts, hints), output
-    # list and count word; every step still does the whole pass, and all of them complete inside the timed region.
     S = max(1, args.streams)
-    ctxs = [P.Context(local_rank) for _ in range(S)]
+    OS = max(0, args.overlap_streams) if world == 1 else 0
+    ctxs = [P.Context(local_rank) for _ in range(max(S, OS, 1))]
     ctx = ctxs[0]
+    for c in ctxs[1:]:
+        c.share_scene(ctx)  # ONE SoA mirror for all streams' contexts (scratch stays per context)
     if not args.explicit_reset:
         for c in ctxs:
             c.set_option(P.NV_OPT_FUSED_COUNT_RESET, 1)  # the pass absorbs the caller's vkCmdFillBuffer(ccb, 0, 4, 0)
     scatter_waves = args.scatter_waves if args.scatter_waves else (8 if S > 1 else 16)
     for c in ctxs:
-        # several passes in flight: the scatter launch with 8 instead of 16 waves per workgroup leaves more of the CUs' wave slots to the
-        # neighbour pass's cull launch (the same setting in every leg of this run, also the single-stream ones)
         c.set_option(P.NV_OPT_SCATTER_WAVES, scatter_waves)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
+    extra_streams = [torch.cuda.Stream(device=dev) for _ in range(len(ctxs))]
+    streams = extra_streams[:S] if S > 1 else [torch.cuda.current_stream(dev)]
     db = P.to_device(draws, dev)
     mlb = torch.empty(copies * n_meshlets * L.MESHLET.itemsize, dtype=torch.uint8, device=dev)
     one = torch.from_numpy(meshlets.view(np.uint8).reshape(-1))
     for c in range(copies):
         mlb[c * one.numel():(c + 1) * one.numel()].copy_(one)
-    dcbs = [P.to_device(synth.make_task_commands(n_draws, cpd, meshlet_base=c * n_meshlets), dev) for c in range(copies)]
+    dcbs = [P.to_device(make_commands(cmd_b, cmd_e, cpd, meshlet_base=c * n_meshlets), dev) for c in range(copies)]
     dccb = torch.from_numpy(count4.view(np.int32).copy()).to(dev)
-    cibs = [torch.zeros(min(n_meshlets, L.CLUSTER_LIMIT) + 256, dtype=torch.int32, device=dev) for _ in range(S)]
-    ccbs = [torch.zeros(4, dtype=torch.int32, device=dev) for _ in range(S)]
+    cibs = [torch.zeros(min(n_meshlets, L.CLUSTER_LIMIT) + 256, dtype=torch.int32, device=dev) for _ in ctxs]
+    ccbs = [torch.zeros(4, dtype=torch.int32, device=dev) for _ in ctxs]
     cib, ccb = cibs[0], ccbs[0]
     # N > 1: the passes' counts are summed over the ranks; batched, asynchronous, written by the scatter launch (shard.CountsReducer,
     # one per stream: a stream's reducer sees that stream's passes)
     B = max(1, args.counts_batch)
     reds = [shard.CountsReducer(ctxs[s], dev, B, stream=streams[s] if S > 1 else None) for s in range(S)]
     if not args.aos:
-        for c in ctxs:
-            c.upload_meshlets(mlb, copies * n_meshlets)
+        ctx.upload_meshlets(mlb, copies * n_meshlets)
     torch.cuda.synchronize()
-    # every argument of a pass marshalled once (Context.bind_clustercull): at ~24 us per step the per-call marshalling of the
+    # every argument of a pass marshalled once (Context.bind_clustercull): at ~25-30 us per step the per-call marshalling of the
     # Python layer (stream lookup, eight data_ptr() calls, a stream context) is what the host cannot afford, not the launch
     calls = [[ctxs[s].bind_clustercull(streams[s] if S > 1 else None, cd, 0, dcbs[c], dccb, db, mlb, None, None, cibs[s], ccbs[s]) for c in range(copies)]
              for s in range(S)]
@@ -167,23 +196,27 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- timed region: exactly `steps` passes, no instrumentation
+    # ---- timed region: exactly `steps` passes, no instrumentation.  It ends when this rank's passes AND the reductions of all
+    # of their counts have completed; the MAX over the ranks of that time is the job's time (no closing barrier: the MAX
+    # all-reduce below does what it would, outside the clock).
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    drain(args.steps)  # every pass's reduction has completed inside the timed region
+    for s in streams:
+        s.synchronize()
+    t_passes = time.perf_counter()
+    drain(args.steps)  # every pass's reduction completes inside the timed region
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    collective_wait = time.perf_counter() - t_passes  # what the job waited for collectives after its last pass had finished
     s_last = (args.steps - 1) % S
-    last_counts = reds[s_last].last(passes_of(s_last, args.steps)) if world > 1 else None
-    visible_by_stream = [int(c[0].item()) for c in ccbs]
+    last_counts = reds[s_last].last(passes_of(s_last, args.steps))
+    visible_by_stream = [int(c[0].item()) for c in ccbs[:S]]
 
-    # ---- one pass after the other on ONE stream (what a single pass costs end to end), same number of steps, untimed by `value`
+    # ---- roofline leg: the same passes again with the library's HIP events bracketing each kernel on the launch stream
+    # (nv_profile_*), one pass after the other on ONE stream — the mode `value` is measured in when --streams is 1.  It is a
+    # separate loop because an event record is itself a barrier packet: three records per pass cost ~10 us per pass.
     single = shard.CountsReducer(ctx, dev, B)
-
     serial_calls = [ctx.bind_clustercull(None, cd, 0, dcbs[c], dccb, db, mlb, None, None, cib, ccb) for c in range(copies)]
 
     def serial_step(i):
@@ -193,25 +226,23 @@ def main():
         serial_calls[i % copies]()
         single.after_pass(i)
 
-    n_prof = max(args.steps, 100)  # (a short run still averages the single-stream pass and the kernels over 100 launches)
-    for i in range(5):
-        serial_step(i)
-    single.drain(5)
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    for i in range(n_prof):
-        serial_step(i)
-    single.drain(n_prof)
-    torch.cuda.synchronize()
-    serial = time.perf_counter() - t2
-
-    # ---- roofline leg: the same `steps` passes again with the library's HIP events bracketing each kernel on the
-    # launch stream (nv_profile_*).  It is a separate loop because an event record is itself a barrier packet: three
-    # records per pass serialise the launches and cost ~10 us per pass, which would deflate `value` by ~25 %.
+    n_prof = max(args.steps, 100)  # (a short run still averages the kernels over 100 launches)
+    serial = None
+    if S > 1:  # the timed region overlapped passes: also report what one pass after the other takes
+        for i in range(5):
+            serial_step(i)
+        single.drain(5)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for i in range(n_prof):
+            serial_step(i)
+        single.drain(n_prof)
+        torch.cuda.synchronize()
+        serial = (time.perf_counter() - t2) / n_prof
     ctx.profile(True)
     t1 = time.perf_counter()
     for i in range(n_prof):
-        serial_step(i)  # one stream: the kernels are timed without a neighbour pass on the chip
+        serial_step(i)
     single.drain(n_prof)
     torch.cuda.synchronize()
     profiled = time.perf_counter() - t1
@@ -221,13 +252,33 @@ def main():
 
     visible = int(ccb[0].item())
     visible_ids = cib[:min(visible, L.CLUSTER_LIMIT)].cpu().numpy().view(np.uint32)  # the list the profiled run's last pass left: checked against the oracle below
+
+    # ---- side leg (N = 1): independent passes in flight on `--overlap-streams` streams, contexts sharing one scene mirror, the
+    # scatter launch with 8 waves per workgroup.  A throughput figure for multi-view callers; never `value`.
+    overlapped = None
+    if OS > 1:
+        for c in ctxs[:OS]:
+            c.set_option(P.NV_OPT_SCATTER_WAVES, 8)
+        ocalls = [[ctxs[s].bind_clustercull(extra_streams[s], cd, 0, dcbs[c], dccb, db, mlb, None, None, cibs[s], ccbs[s]) for c in range(copies)] for s in range(OS)]
+        for i in range(max(OS * 2, 6)):
+            ocalls[i % OS][i % copies]()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for i in range(n_prof):
+            ocalls[i % OS][i % copies]()
+        torch.cuda.synchronize()
+        o_step = (time.perf_counter() - t3) / n_prof
+        overlapped = {"value": n_meshlets / o_step, "unit": "meshlets/s", "ms_per_step": o_step * 1e3, "streams": OS, "scatter_waves_per_workgroup": 8,
+                      "what": "%d independent passes in flight (contexts on %d HIP streams sharing one scene mirror): the scatter launch of one pass overlaps "
+                              "the next pass's cull launch; a frame's dependent passes cannot do this" % (OS, OS)}
+        for c in ctxs[:OS]:
+            c.set_option(P.NV_OPT_SCATTER_WAVES, scatter_waves)
+
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, collective_wait], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        total_visible = int(last_counts[2].item())
-    else:
-        total_visible = visible
+        elapsed, collective_wait = float(t[0].item()), float(t[1].item())
+    total_visible = int(last_counts[2].item())
 
     cull_ms, cull_n = prof["cluster_cull"]
     scat_ms, scat_n = prof["cluster_scatter"]
@@ -241,52 +292,58 @@ def main():
     pass_bytes = n_meshlets * per_meshlet + n_cmd * 68 + visible * 4 + 4
     algo_bytes = n_meshlets * per_meshlet + n_cmd * 68 + n_cmd * 8
     achieved = algo_bytes / kernel_avg_s / 1e9
+    step_s = elapsed / args.steps
+    single_s = step_s if S == 1 else serial
 
     traffic, traffic_note = pmc_traffic(n_meshlets, args)
 
     if rank == 0:
+        if args.total_meshlets:
+            workload = ("config5: %d meshlets sharded over %d GPUs by contiguous command ranges (%d on rank 0)" % (total_meshlets, world, n_meshlets)
+                        if world > 1 else "config3A shape at %d meshlets" % total_meshlets)
+        else:
+            workload = "config3A: %d meshlets/GPU, %d task commands over %d draws" % (n_meshlets, n_cmd, n_draws)
         out = {
             "metric": "meshlets culled+compacted /sec",
-            "value": n_meshlets * world * args.steps / elapsed,
+            "value": total_meshlets * args.steps / elapsed,
             "unit": "meshlets/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": step_s * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_meshlets else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "config3A: %d meshlets/GPU, %d task commands over %d draws, cone+frustum clustercull (LATE=0) + ordered compaction"
-                                   % (n_meshlets, n_cmd, n_draws),
-                       "meshlets_per_gpu": n_meshlets, "commands_per_gpu": n_cmd, "draws_per_gpu": n_draws,
-                       "streams": S, "scatter_waves_per_workgroup": scatter_waves, "passes_in_flight": "steps issued round-robin on %d HIP streams, one nv_context / output list per stream; the scatter launch of a pass overlaps the next pass's cull launch" % S if S > 1 else "one pass after the other",
+            "config": {"workload": workload + ", cone+frustum clustercull (LATE=0) + ordered compaction",
+                       "meshlets_total": total_meshlets, "meshlets_rank0": n_meshlets, "commands_rank0": n_cmd, "draws_rank0": n_draws,
+                       "streams": S, "scatter_waves_per_workgroup": scatter_waves,
+                       "regime": "one pass after the other on one stream" if S == 1 else "steps issued round-robin on %d HIP streams (independent passes in flight)" % S,
                        "input_copies_rotated": copies, "count_reset": "explicit launch" if args.explicit_reset else "fused (NV_OPT_FUSED_COUNT_RESET)", "meshlet_layout": "AoS24" if args.aos else "SoA12",
-                       "visible_per_gpu": visible, "visible_per_stream": visible_by_stream, "visible_total": total_visible, "sharding": "commands x%d" % world,
+                       "visible_rank0": visible, "visible_per_stream": visible_by_stream, "visible_total": total_visible, "sharding": "commands x%d" % world,
                        "counts_allreduce": ("none (N=1)" if world == 1 else "one async all-reduce of [%d, 3] int64 per %d passes, rows written by the scatter launch" % (B, B))},
+            "collective_wait_ms": collective_wait * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_measured_in_run": False, "traffic_source": traffic_note,
-                         "kernel": "cluster_mask_kernel", "kernel_avg_us": kernel_avg_s * 1e6,
+                         "kernel": "cluster_mask_kernel", "kernel_avg_us": kernel_avg_s * 1e6, "timed_in": "one pass after the other on one stream (HIP events on the launch stream)",
                          "algorithmic_bytes": algo_bytes, "launches_timed": cull_n,
                          "scatter_kernel_avg_us": scatter_avg_s * 1e6, "ms_per_step_with_events": profiled / n_prof * 1e3,
                          "pass_algorithmic_bytes": pass_bytes,
-                         # one pass after the other on one stream, un-instrumented: what a single pass takes end to end
-                         "ms_per_pass_single_stream": serial / n_prof * 1e3,
-                         # the whole pass (cull + scatter launches) against the roofline: from that single-stream time, and
-                         # from the timed region's throughput (passes overlapping on `streams` streams)
-                         "pass_frac": pass_bytes / (serial / n_prof) / 1e9 / HBM_PEAK_GBS,
-                         "pass_frac_overlapped": pass_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
-            "note": ("value and ms_per_step are THROUGHPUT figures: the %d steps are independent passes issued round-robin on %d HIP streams, so consecutive "
-                     "passes overlap (scatter launch of one under the cull launch of the next) and ms_per_step can be shorter than one pass; a single pass end to end takes "
-                     "roofline.ms_per_pass_single_stream, and the kernels were timed one pass after the other" % (args.steps, S)) if S > 1 else "one pass after the other on one stream",
+                         # the whole pass (cull + scatter launches) against the roofline, one pass after the other, un-instrumented
+                         "ms_per_pass_single_stream": single_s * 1e3,
+                         "pass_frac": pass_bytes / single_s / 1e9 / HBM_PEAK_GBS},
+            "throughput_overlapped": overlapped,
             "library": niagara_amd.SO_PATH,
         }
+        if S == 1 and kernel_avg_s > step_s * 1.02:
+            out["note"] = "inconsistent: the dominant kernel's event time exceeds ms_per_step"
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, cd, draws, meshlets, n_cmd, visible, visible_ids)
+            out["cpu_baseline"] = cpu_baseline(args, cd, draws, meshlets, cmd_b, cmd_e, visible, visible_ids)
         print(json.dumps(out), flush=True)
 
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 
@@ -309,11 +366,12 @@ def pmc_traffic(n_meshlets, args):
     return None, None
 
 
-def cpu_baseline(args, cd, draws, meshlets, n_cmd, gpu_visible, gpu_ids):
+def cpu_baseline(args, cd, draws, meshlets, cmd_b, cmd_e, gpu_visible, gpu_ids):
     """the CPU oracle (oracle/ = test infrastructure; here ONLY as the timed baseline and as a checker) on this host"""
     import oracle
     from niagara_amd import synth
-    commands = synth.make_task_commands(len(draws), args.commands_per_draw)
+    n_cmd = cmd_e - cmd_b
+    commands = make_commands(cmd_b, cmd_e, args.commands_per_draw)
     c4 = synth.count4_for(n_cmd)
     threads = oracle.max_threads()
     cib = np.zeros(n_cmd * 64, np.uint32)
@@ -333,7 +391,7 @@ def cpu_baseline(args, cd, draws, meshlets, n_cmd, gpu_visible, gpu_ids):
     best, med = min(times), sorted(times)[len(times) // 2]
     return {"value": n_cmd * 64 / med, "unit": "meshlets/s", "cores": threads, "kind": "port", "best_pass_value": n_cmd * 64 / best,
             "visible_list": "bit-identical to the GPU's (%d IDs)" % len(gpu_ids),
-            "sample": "%d passes of the full %d-meshlet config3A batch, OpenMP oracle: median pass %.1f ms (value), best pass %.1f ms"
+            "sample": "%d passes of the full %d-meshlet batch, OpenMP oracle: median pass %.1f ms (value), best pass %.1f ms"
                       % (len(times), n_cmd * 64, med * 1e3, best * 1e3)}
 
 

@@ -214,6 +214,24 @@ int nv_profile_read(nv_context* ctx, float out_ms[NV_PROF_SLOTS], uint32_t out_c
 #define NV_OPT_SCATTER_WAVES 4
 int nv_set_option(nv_context* ctx, int option, int value);
 
+/* ---- capacities ----
+ * The pass entry points only enqueue: none of them allocates, frees or synchronises, so all of them can be recorded into a
+ * HIP graph (stream capture) with growing arguments.  nv_create sizes the library's scratch for 1 M draws and
+ * NV_TASK_WGLIMIT task commands (the size niagara allocates dcb for, src/niagara.cpp:1070); nv_reserve raises the
+ * per-draw scratch to maxDraws before the first pass over that many (it may synchronise the device: call it at scene
+ * load, next to createBuffer(dvb), src/niagara.cpp:1060).  nv_drawcull over more draws than were reserved returns
+ * NV_ENOMEM and enqueues nothing.  maxCommands is accepted for symmetry; values above NV_TASK_WGLIMIT buy nothing (the
+ * passes clamp there like the shaders do). */
+int nv_reserve(nv_context* ctx, uint32_t maxDraws, uint32_t maxCommands);
+
+/* Several contexts of ONE device (one per stream: several views or frames in flight) can use one set of scene mirrors:
+ * after nv_share_scene(dst, src) the two contexts share what nv_upload_meshlets / nv_upload_meshes / nv_upload_draws /
+ * nv_update_draws built or build from then on through either of them (reference-counted; dst's previous mirrors are
+ * released; destroying one context leaves the other's mirrors alone).  Scratch (ballots, tile counts, result bytes)
+ * stays per context.  An upload through one context is ordered on THAT call's stream only: the caller orders it
+ * against passes the sharing contexts have in flight on other streams, as it would for its own buffer uploads. */
+int nv_share_scene(nv_context* dst, nv_context* src);
+
 /* ---- scene upload hook (next to uploadBuffer(mlb), src/niagara.cpp:1055) ----
  * Builds the library-owned SoA mirror of the 12 cull bytes of every meshlet
  * (bounds: 4 x fp16 = 8 B, cone: 4 x s8 = 4 B).  nv_clustercull uses the mirror when

@@ -52,6 +52,8 @@ _SIGS = {
     "nv_version": (C.c_char_p, []),
     "nv_status": (_i, [_vp, _vp]),
     "nv_set_option": (_i, [_vp, _i, _i]),
+    "nv_reserve": (_i, [_vp, _u32, _u32]),
+    "nv_share_scene": (_i, [_vp, _vp]),
     "nv_profile_enable": (_i, [_vp, _i]),
     "nv_profile_read": (_i, [_vp, C.POINTER(C.c_float * 5), C.POINTER(C.c_uint32 * 5)]),
     "nv_upload_meshlets": (_i, [_vp, _vp, _vp, _u32]),

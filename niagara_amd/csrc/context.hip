@@ -3,6 +3,7 @@
 // stream (nv_status and scratch growth are the only synchronising calls).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <new>
 #include <vector>
 #include <stdlib.h>
@@ -29,7 +30,7 @@ int launch_taskcull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_
 int launch_probe(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
 int launch_soa_split(hipStream_t, const NvMeshlet*, uint32_t count, uint32_t padded, uint2* bounds, uint32_t* cones);
 int launch_drawcull(hipStream_t, const DrawArgs&, int late, int task);
-int launch_draw_split(hipStream_t, const NvMeshDraw*, const NvMesh*, uint32_t first, uint32_t count, float4* world, uint2* scaleMesh, uint32_t* postPass);
+int launch_draw_split(hipStream_t, const NvMeshDraw*, const NvMesh*, uint32_t meshCount, uint32_t first, uint32_t count, float4* world, uint2* scaleMesh, uint32_t* postPass);
 size_t drawcull_result_bytes(uint32_t drawCount);
 int launch_tasksubmit(hipStream_t, uint32_t* count4, NvMeshTaskCommand* commands);
 int launch_reset_count(hipStream_t, uint32_t* a, uint32_t* b);
@@ -49,20 +50,13 @@ struct ProfRecord
 	hipEvent_t begin, end;
 };
 
-struct nv_context
+// What the upload hooks build from the caller's scene buffers: the SoA mirrors and the Mesh-table registration.  One
+// per context by default; nv_share_scene makes several contexts of one device (several streams, several views in
+// flight) use ONE instance, so that three contexts do not hold three identical 480 MB mirrors.  Reference-counted.
+struct nv_scene
 {
+	std::atomic<int> refs;
 	int device;
-	int numCUs;
-	uint64_t* masks; // per-command ballots between the two clustercull launches
-	nv::ClusterCounts* tileCounts;
-	uint4* candList; // late pass with HiZ: the commands with survivors (cull kernel -> occlusion stage)
-	uint32_t listStride; // room per sub-list (entries)
-	uint32_t listSharers, listMinPer; // occlusion stage: blocks per sub-list, listed commands per block at least
-	// drawcull: per-draw result bytes between its two launches, and its own per-tile counts
-	uint8_t* drawResults;
-	size_t drawResultsCapacity;
-	nv::ClusterCounts* drawTileCounts;
-	unsigned long long* totalsPartials; // nv_trianglecull / nv_cluster_expand: per-workgroup partial totals (3 x u64 x grid)
 	// SoA mirror of the meshlet cull bytes
 	const NvMeshlet* mirroredFrom;
 	uint32_t mirroredCount;
@@ -80,6 +74,23 @@ struct nv_context
 	// Mesh table registered by nv_upload_meshes (pointer identity + count): lets drawcull stage it in LDS
 	const NvMesh* meshesFrom;
 	uint32_t meshCount;
+};
+
+struct nv_context
+{
+	int device;
+	int numCUs;
+	uint64_t* masks; // per-command ballots between the two clustercull launches
+	nv::ClusterCounts* tileCounts;
+	uint4* candList; // late pass with HiZ: the commands with survivors (cull kernel -> occlusion stage)
+	uint32_t listStride; // room per sub-list (entries)
+	uint32_t listSharers, listMinPer; // occlusion stage: blocks per sub-list, listed commands per block at least
+	// drawcull: per-draw result bytes between its two launches, and its own per-tile counts
+	uint8_t* drawResults;
+	size_t drawResultsCapacity;
+	nv::ClusterCounts* drawTileCounts;
+	unsigned long long* totalsPartials; // nv_trianglecull / nv_cluster_expand: per-workgroup partial totals (3 x u64 x grid)
+	nv_scene* scene; // mirrors + registrations (shared between contexts by nv_share_scene)
 	// launch shape of the cull kernel (workgroups per CU) and the dealing's start-delay compensation in percent; constants
 	// in the product, environment-tunable (with the NV_DEBUG_MODE bit mask) only in the NV_EXPERIMENTS build
 	uint32_t debugMode;
@@ -149,24 +160,68 @@ NvPyramidDesc null_pyramid()
 	return p;
 }
 
-// per-draw result bytes between drawcull's two launches; growth is rare and synchronises the device
-int ensure_draw_results(nv_context* ctx, uint32_t drawCount)
+// Per-draw result bytes between drawcull's two launches.  Sized by nv_create (1 M draws) and nv_reserve only: a pass entry
+// point never allocates or synchronises (it would stall the device behind an "asynchronous enqueue" and break a stream
+// capture); a pass over more draws than were reserved returns NV_ENOMEM.
+int reserve_draw_results(nv_context* ctx, uint32_t drawCount)
 {
 	const size_t need = nv::drawcull_result_bytes(drawCount);
 	if (need <= ctx->drawResultsCapacity)
 		return NV_OK;
-	hipError_t e = hipDeviceSynchronize();
+	hipError_t e = hipDeviceSynchronize(); // a drawcull still in flight on any stream may be reading the old scratch
 	if (e != hipSuccess)
 		return (int)e;
 	if (ctx->drawResults)
 		(void)hipFree(ctx->drawResults);
 	ctx->drawResults = nullptr;
 	ctx->drawResultsCapacity = 0;
-	const size_t cap = need < (size_t(1) << 21) ? (size_t(1) << 21) : need + need / 2;
+	const size_t cap = need < (size_t(1) << 21) ? (size_t(1) << 21) : need;
 	if (hipMalloc(&ctx->drawResults, cap) != hipSuccess)
 		return NV_ENOMEM;
 	ctx->drawResultsCapacity = cap;
 	return NV_OK;
+}
+
+nv_scene* scene_new(int device)
+{
+	nv_scene* sc = new (std::nothrow) nv_scene();
+	if (!sc)
+		return nullptr;
+	sc->refs.store(1);
+	sc->device = device;
+	sc->mirroredFrom = nullptr;
+	sc->mirroredCount = 0;
+	sc->soaBounds = nullptr;
+	sc->soaCones = nullptr;
+	sc->soaCapacity = 0;
+	sc->drawsFrom = nullptr;
+	sc->drawsMeshes = nullptr;
+	sc->drawsCount = 0;
+	sc->soaWorld = nullptr;
+	sc->soaScaleMesh = nullptr;
+	sc->soaPostPass = nullptr;
+	sc->drawsCapacity = 0;
+	sc->meshesFrom = nullptr;
+	sc->meshCount = 0;
+	return sc;
+}
+
+// drops one reference; the last one frees the mirrors (the caller has made the owning device current)
+void scene_release(nv_scene* sc)
+{
+	if (!sc || sc->refs.fetch_sub(1) != 1)
+		return;
+	if (sc->soaBounds)
+		(void)hipFree(sc->soaBounds);
+	if (sc->soaCones)
+		(void)hipFree(sc->soaCones);
+	if (sc->soaWorld)
+		(void)hipFree(sc->soaWorld);
+	if (sc->soaScaleMesh)
+		(void)hipFree(sc->soaScaleMesh);
+	if (sc->soaPostPass)
+		(void)hipFree(sc->soaPostPass);
+	delete sc;
 }
 
 // one scatter workgroup per CU, capped by the per-tile count table
@@ -186,7 +241,7 @@ uint32_t persistent_grid(const nv_context* ctx, uint32_t blocksPerCU)
 
 extern "C" {
 
-const char* nv_version(void) { return "niagara_vis 0.1 (gfx950)"; }
+const char* nv_version(void) { return "niagara_vis 0.3 (gfx950)"; } // 0.2: NV_PROF_SLOTS 4 -> 5; 0.3: nv_reserve, nv_share_scene
 
 int nv_create(nv_context** out_ctx, int device)
 {
@@ -205,11 +260,18 @@ int nv_create(nv_context** out_ctx, int device)
 		return NV_ENOMEM;
 	memset(ctx, 0, sizeof(*ctx));
 	ctx->device = device;
+	ctx->scene = scene_new(device);
+	if (!ctx->scene)
+	{
+		delete ctx;
+		return NV_ENOMEM;
+	}
 
 	hipDeviceProp_t prop;
 	hipError_t e = hipGetDeviceProperties(&prop, device);
 	if (e != hipSuccess)
 	{
+		scene_release(ctx->scene);
 		delete ctx;
 		return (int)e;
 	}
@@ -246,14 +308,15 @@ int nv_create(nv_context** out_ctx, int device)
 	if (const char* v = getenv("NV_DEAL_SCALE"))
 		ctx->dealScale = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_CC_BLOCKS_PER_CU"))
-		ctx->ccBlocksPerCU = (uint32_t)atoi(v) ? (uint32_t)atoi(v) : 6;
+		ctx->ccBlocksPerCU = (uint32_t)atoi(v) ? ((uint32_t)atoi(v) > 8 ? 8u : (uint32_t)atoi(v)) : 6; // (the stamp buffer holds 8 per CU)
 #endif
 
 	if (hipMalloc(&ctx->masks, nv::clustercull_mask_bytes()) != hipSuccess || hipMalloc(&ctx->tileCounts, sizeof(nv::ClusterCounts)) != hipSuccess ||
 	    hipMalloc(&ctx->candList, nv::clustercull_list_bytes()) != hipSuccess ||
 	    hipMemset(ctx->tileCounts, 0, sizeof(nv::ClusterCounts)) != hipSuccess ||
 	    hipMalloc(&ctx->drawTileCounts, sizeof(nv::ClusterCounts)) != hipSuccess ||
-	    hipMemset(ctx->drawTileCounts, 0, sizeof(nv::ClusterCounts)) != hipSuccess || ensure_draw_results(ctx, 1u << 20) != NV_OK)
+	    hipMemset(ctx->drawTileCounts, 0, sizeof(nv::ClusterCounts)) != hipSuccess || reserve_draw_results(ctx, 1u << 20) != NV_OK ||
+	    hipMalloc(&ctx->totalsPartials, (size_t)persistent_grid(ctx, 8) * 3 * sizeof(unsigned long long)) != hipSuccess)
 	{
 		nv_destroy(ctx);
 		return NV_ENOMEM;
@@ -298,16 +361,7 @@ void nv_destroy(nv_context* ctx)
 		(void)hipFree(ctx->tileCounts);
 	if (ctx->candList)
 		(void)hipFree(ctx->candList);
-	if (ctx->soaBounds)
-		(void)hipFree(ctx->soaBounds);
-	if (ctx->soaCones)
-		(void)hipFree(ctx->soaCones);
-	if (ctx->soaWorld)
-		(void)hipFree(ctx->soaWorld);
-	if (ctx->soaScaleMesh)
-		(void)hipFree(ctx->soaScaleMesh);
-	if (ctx->soaPostPass)
-		(void)hipFree(ctx->soaPostPass);
+	scene_release(ctx->scene);
 	if (ctx->timing)
 		(void)hipFree(ctx->timing);
 	delete ctx->prof;
@@ -350,6 +404,32 @@ int nv_set_option(nv_context* ctx, int option, int value)
 	default:
 		return NV_EINVAL;
 	}
+}
+
+int nv_reserve(nv_context* ctx, uint32_t maxDraws, uint32_t maxCommands)
+{
+	if (!ctx)
+		return NV_EINVAL;
+	(void)maxCommands; // the per-command scratch (ballots, survivor lists) is sized for NV_TASK_WGLIMIT by nv_create: the passes never process more
+	DeviceGuard guard(ctx->device);
+	return reserve_draw_results(ctx, maxDraws);
+}
+
+int nv_share_scene(nv_context* dst, nv_context* src)
+{
+	if (!dst || !src || dst->device != src->device)
+		return NV_EINVAL;
+	if (dst->scene == src->scene)
+		return NV_OK;
+	DeviceGuard guard(dst->device);
+	// passes of dst still in flight read dst's current mirrors
+	hipError_t e = hipDeviceSynchronize();
+	if (e != hipSuccess)
+		return (int)e;
+	src->scene->refs.fetch_add(1);
+	scene_release(dst->scene);
+	dst->scene = src->scene;
+	return NV_OK;
 }
 
 int nv_profile_enable(nv_context* ctx, int enabled)
@@ -416,29 +496,30 @@ int nv_upload_meshlets(nv_context* ctx, void* stream, const NvMeshlet* d_meshlet
 	DeviceGuard guard(ctx->device);
 	// one extra 64-entry block so that a command's 64-lane window never leaves the mirror
 	uint32_t padded = round_up(meshletCount, 64) + 64;
-	if (padded > ctx->soaCapacity)
+	if (padded > ctx->scene->soaCapacity)
 	{
-		hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+		// a pass of this or of a sharing context may still be reading the old mirror on another stream
+		hipError_t e = hipDeviceSynchronize();
 		if (e != hipSuccess)
 			return (int)e;
-		if (ctx->soaBounds)
-			(void)hipFree(ctx->soaBounds);
-		if (ctx->soaCones)
-			(void)hipFree(ctx->soaCones);
-		ctx->soaBounds = nullptr;
-		ctx->soaCones = nullptr;
-		ctx->soaCapacity = 0;
-		ctx->mirroredFrom = nullptr;
-		if (hipMalloc(&ctx->soaBounds, (size_t)padded * sizeof(uint2)) != hipSuccess ||
-		    hipMalloc(&ctx->soaCones, (size_t)padded * sizeof(uint32_t)) != hipSuccess)
+		if (ctx->scene->soaBounds)
+			(void)hipFree(ctx->scene->soaBounds);
+		if (ctx->scene->soaCones)
+			(void)hipFree(ctx->scene->soaCones);
+		ctx->scene->soaBounds = nullptr;
+		ctx->scene->soaCones = nullptr;
+		ctx->scene->soaCapacity = 0;
+		ctx->scene->mirroredFrom = nullptr;
+		if (hipMalloc(&ctx->scene->soaBounds, (size_t)padded * sizeof(uint2)) != hipSuccess ||
+		    hipMalloc(&ctx->scene->soaCones, (size_t)padded * sizeof(uint32_t)) != hipSuccess)
 			return NV_ENOMEM;
-		ctx->soaCapacity = padded;
+		ctx->scene->soaCapacity = padded;
 	}
-	int rc = nv::launch_soa_split((hipStream_t)stream, d_meshlets, meshletCount, padded, ctx->soaBounds, ctx->soaCones);
+	int rc = nv::launch_soa_split((hipStream_t)stream, d_meshlets, meshletCount, padded, ctx->scene->soaBounds, ctx->scene->soaCones);
 	if (rc)
 		return rc;
-	ctx->mirroredFrom = d_meshlets;
-	ctx->mirroredCount = meshletCount;
+	ctx->scene->mirroredFrom = d_meshlets;
+	ctx->scene->mirroredCount = meshletCount;
 	return NV_OK;
 }
 
@@ -447,8 +528,8 @@ int nv_upload_meshes(nv_context* ctx, void* stream, const NvMesh* d_meshes, uint
 	(void)stream;
 	if (!ctx || (!d_meshes && meshCount))
 		return NV_EINVAL;
-	ctx->meshesFrom = d_meshes;
-	ctx->meshCount = meshCount;
+	ctx->scene->meshesFrom = d_meshes;
+	ctx->scene->meshCount = meshCount;
 	return NV_OK;
 }
 
@@ -459,39 +540,40 @@ int nv_upload_draws(nv_context* ctx, void* stream, const NvMeshDraw* d_draws, ui
 	DeviceGuard guard(ctx->device);
 	if (!d_draws)
 	{
-		ctx->drawsFrom = nullptr;
-		ctx->drawsMeshes = nullptr;
-		ctx->drawsCount = 0;
+		ctx->scene->drawsFrom = nullptr;
+		ctx->scene->drawsMeshes = nullptr;
+		ctx->scene->drawsCount = 0;
 		return NV_OK;
 	}
-	if (drawCount > ctx->drawsCapacity)
+	if (drawCount > ctx->scene->drawsCapacity)
 	{
-		hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+		//  a drawcull of this or of a sharing context may still be reading the old mirror on another stream
+		hipError_t e = hipDeviceSynchronize();
 		if (e != hipSuccess)
 			return (int)e;
-		if (ctx->soaWorld)
-			(void)hipFree(ctx->soaWorld);
-		if (ctx->soaScaleMesh)
-			(void)hipFree(ctx->soaScaleMesh);
-		if (ctx->soaPostPass)
-			(void)hipFree(ctx->soaPostPass);
-		ctx->soaWorld = nullptr;
-		ctx->soaScaleMesh = nullptr;
-		ctx->soaPostPass = nullptr;
-		ctx->drawsCapacity = 0;
-		ctx->drawsFrom = nullptr;
+		if (ctx->scene->soaWorld)
+			(void)hipFree(ctx->scene->soaWorld);
+		if (ctx->scene->soaScaleMesh)
+			(void)hipFree(ctx->scene->soaScaleMesh);
+		if (ctx->scene->soaPostPass)
+			(void)hipFree(ctx->scene->soaPostPass);
+		ctx->scene->soaWorld = nullptr;
+		ctx->scene->soaScaleMesh = nullptr;
+		ctx->scene->soaPostPass = nullptr;
+		ctx->scene->drawsCapacity = 0;
+		ctx->scene->drawsFrom = nullptr;
 		const size_t cap = (size_t)drawCount + 64;
-		if (hipMalloc(&ctx->soaWorld, cap * sizeof(float4)) != hipSuccess || hipMalloc(&ctx->soaScaleMesh, cap * sizeof(uint2)) != hipSuccess ||
-		    hipMalloc(&ctx->soaPostPass, cap * sizeof(uint32_t)) != hipSuccess)
+		if (hipMalloc(&ctx->scene->soaWorld, cap * sizeof(float4)) != hipSuccess || hipMalloc(&ctx->scene->soaScaleMesh, cap * sizeof(uint2)) != hipSuccess ||
+		    hipMalloc(&ctx->scene->soaPostPass, cap * sizeof(uint32_t)) != hipSuccess)
 			return NV_ENOMEM;
-		ctx->drawsCapacity = drawCount;
+		ctx->scene->drawsCapacity = drawCount;
 	}
-	int rc = nv::launch_draw_split((hipStream_t)stream, d_draws, d_meshes, 0, drawCount, ctx->soaWorld, ctx->soaScaleMesh, ctx->soaPostPass);
+	int rc = nv::launch_draw_split((hipStream_t)stream, d_draws, d_meshes, ctx->scene->meshesFrom == d_meshes ? ctx->scene->meshCount : 0u, 0, drawCount, ctx->scene->soaWorld, ctx->scene->soaScaleMesh, ctx->scene->soaPostPass);
 	if (rc)
 		return rc;
-	ctx->drawsFrom = d_draws;
-	ctx->drawsMeshes = d_meshes;
-	ctx->drawsCount = drawCount;
+	ctx->scene->drawsFrom = d_draws;
+	ctx->scene->drawsMeshes = d_meshes;
+	ctx->scene->drawsCount = drawCount;
 	return NV_OK;
 }
 
@@ -499,13 +581,14 @@ int nv_update_draws(nv_context* ctx, void* stream, const NvMeshDraw* d_draws, ui
 {
 	if (!ctx || !d_draws)
 		return NV_EINVAL;
-	if (!ctx->drawsFrom || d_draws < ctx->drawsFrom || d_draws >= ctx->drawsFrom + ctx->drawsCount || ctx->drawsFrom + (d_draws - ctx->drawsFrom) != d_draws)
+	if (!ctx->scene->drawsFrom || d_draws < ctx->scene->drawsFrom || d_draws >= ctx->scene->drawsFrom + ctx->scene->drawsCount || ctx->scene->drawsFrom + (d_draws - ctx->scene->drawsFrom) != d_draws)
 		return NV_OK; // nothing registered for this buffer: the passes read it in place anyway
-	const size_t base = (size_t)(d_draws - ctx->drawsFrom) + first;
-	if (base > ctx->drawsCount || count > ctx->drawsCount - base)
+	const size_t base = (size_t)(d_draws - ctx->scene->drawsFrom) + first;
+	if (base > ctx->scene->drawsCount || count > ctx->scene->drawsCount - base)
 		return NV_EINVAL;
 	DeviceGuard guard(ctx->device);
-	return nv::launch_draw_split((hipStream_t)stream, ctx->drawsFrom, ctx->drawsMeshes, (uint32_t)base, count, ctx->soaWorld, ctx->soaScaleMesh, ctx->soaPostPass);
+	return nv::launch_draw_split((hipStream_t)stream, ctx->scene->drawsFrom, ctx->scene->drawsMeshes,
+	                             ctx->scene->meshesFrom == ctx->scene->drawsMeshes ? ctx->scene->meshCount : 0u, (uint32_t)base, count, ctx->scene->soaWorld, ctx->scene->soaScaleMesh, ctx->scene->soaPostPass);
 }
 
 int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late, int task, const NvMeshDraw* d_draws,
@@ -518,21 +601,21 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 		return NV_EINVAL;
 	DeviceGuard guard(ctx->device);
 
-	int rc = ensure_draw_results(ctx, cull->drawCount);
-	if (rc)
-		return rc;
+	if (nv::drawcull_result_bytes(cull->drawCount) > ctx->drawResultsCapacity)
+		return NV_ENOMEM; // nv_reserve(ctx, maxDraws, ...) first: a pass never allocates
+	int rc = NV_OK;
 
 	nv::DrawArgs a;
 	a.cd = *cull;
 	a.pyr = pyramid ? *pyramid : null_pyramid();
 	a.draws = d_draws;
 	// the mirror serves the registered buffer and any sub-range of it that starts on a record (a pass over a shard of the draws)
-	const size_t drawOffset = ctx->drawsFrom && d_draws >= ctx->drawsFrom ? (size_t)(d_draws - ctx->drawsFrom) : ~size_t(0);
-	const bool mirrored = ctx->soaWorld && drawOffset != ~size_t(0) && ctx->drawsFrom + drawOffset == d_draws &&
-	                      drawOffset + cull->drawCount <= ctx->drawsCount && ctx->drawsMeshes == d_meshes; // (the mirror folds THAT table's bounds in)
-	a.soaWorld = mirrored ? ctx->soaWorld + drawOffset : nullptr;
-	a.soaScaleMesh = mirrored ? ctx->soaScaleMesh + drawOffset : nullptr;
-	a.soaPostPass = mirrored ? ctx->soaPostPass + drawOffset : nullptr;
+	const size_t drawOffset = ctx->scene->drawsFrom && d_draws >= ctx->scene->drawsFrom ? (size_t)(d_draws - ctx->scene->drawsFrom) : ~size_t(0);
+	const bool mirrored = ctx->scene->soaWorld && drawOffset != ~size_t(0) && ctx->scene->drawsFrom + drawOffset == d_draws &&
+	                      drawOffset + cull->drawCount <= ctx->scene->drawsCount && ctx->scene->drawsMeshes == d_meshes; // (the mirror folds THAT table's bounds in)
+	a.soaWorld = mirrored ? ctx->scene->soaWorld + drawOffset : nullptr;
+	a.soaScaleMesh = mirrored ? ctx->scene->soaScaleMesh + drawOffset : nullptr;
+	a.soaPostPass = mirrored ? ctx->scene->soaPostPass + drawOffset : nullptr;
 	a.meshes = d_meshes;
 	a.commands = d_commands;
 	a.count4 = d_count4;
@@ -545,7 +628,7 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 #endif
 	a.fusedReset = ctx->fusedReset;
 	a.fusedSubmit = ctx->fusedSubmit;
-	a.meshCount = ctx->meshesFrom == d_meshes ? ctx->meshCount : 0u;
+	a.meshCount = ctx->scene->meshesFrom == d_meshes ? ctx->scene->meshCount : 0u;
 	// LDS-staged coarse pyramid levels for the late pass's HiZ probes: measured slower than reading them through L2 (a
 	// workgroup of 512 draws stages 22 KiB to serve the ~20 probes of its visible draws) — off unless asked for
 	a.stagedBase = ~0u;
@@ -597,9 +680,9 @@ static int fill_cluster_args(nv_context* ctx, nv::ClusterArgs& a, const NvCullDa
 	a.count4 = d_count4;
 	a.draws = d_draws;
 	a.meshlets = d_meshlets;
-	const bool soa = ctx->mirroredFrom == d_meshlets && ctx->soaBounds;
-	a.soaBounds = soa ? ctx->soaBounds : nullptr;
-	a.soaCones = soa ? ctx->soaCones : nullptr;
+	const bool soa = ctx->scene->mirroredFrom == d_meshlets && ctx->scene->soaBounds;
+	a.soaBounds = soa ? ctx->scene->soaBounds : nullptr;
+	a.soaCones = soa ? ctx->scene->soaCones : nullptr;
 	a.mvb = d_meshletVisibility;
 	a.masks = ctx->masks;
 	a.candList = ctx->candList;
@@ -716,8 +799,6 @@ int nv_cluster_expand(nv_context* ctx, void* stream, const NvMeshTaskCommand* d_
 		return NV_EINVAL;
 	DeviceGuard guard(ctx->device);
 	const uint32_t grid = persistent_grid(ctx, 8);
-	if (!ctx->totalsPartials && hipMalloc(&ctx->totalsPartials, (size_t)grid * 3 * sizeof(unsigned long long)) != hipSuccess)
-		return NV_ENOMEM;
 	return nv::launch_cluster_expand((hipStream_t)stream, d_commands, d_meshlets, d_clusterIndices, d_clusterCount4, d_records, recordCapacity,
 	                                 d_totals3, ctx->totalsPartials, grid);
 }
@@ -743,8 +824,6 @@ int nv_trianglecull(nv_context* ctx, void* stream, const NvGlobals* globals, con
 	a.capacity = maskCapacity;
 	a.totals = reinterpret_cast<unsigned long long*>(d_totals3);
 	const uint32_t grid = persistent_grid(ctx, 8);
-	if (!ctx->totalsPartials && hipMalloc(&ctx->totalsPartials, (size_t)grid * 3 * sizeof(unsigned long long)) != hipSuccess)
-		return NV_ENOMEM;
 	a.partials = ctx->totalsPartials;
 	return nv::launch_trianglecull((hipStream_t)stream, a, grid);
 }
@@ -759,8 +838,8 @@ int nv_meshlet_bounds(nv_context* ctx, void* stream, const NvVertex* d_vertices,
 	const uint32_t cap = persistent_grid(ctx, 16);
 	int rc = nv::launch_meshlet_bounds((hipStream_t)stream, d_vertices, d_meshletData, d_meshlets, meshletCount, d_bounds8, blocks < cap ? blocks : cap);
 	// a mirror built from these records is stale now (its registration is by pointer, its contents a snapshot)
-	if (rc == 0 && ctx->mirroredFrom == d_meshlets)
-		ctx->mirroredFrom = nullptr;
+	if (rc == 0 && ctx->scene->mirroredFrom == d_meshlets)
+		ctx->scene->mirroredFrom = nullptr;
 	return rc;
 }
 

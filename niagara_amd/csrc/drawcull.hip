@@ -796,7 +796,7 @@ int launch_drawcull(hipStream_t stream, const DrawArgs& a, int late, int task)
 // Mirror of the decision's inputs (nv_upload_draws / nv_update_draws), draws [first, first + count): the world-space
 // sphere — drawcull.comp.glsl:73-75 up to the view transform, in the reference's operation order — plus {scale, meshIndex}
 // and postPass as their own streams.
-__global__ __launch_bounds__(256) void draw_split_kernel(const NvMeshDraw* __restrict__ draws, const NvMesh* __restrict__ meshes, uint32_t first, uint32_t count,
+__global__ __launch_bounds__(256) void draw_split_kernel(const NvMeshDraw* __restrict__ draws, const NvMesh* __restrict__ meshes, uint32_t meshCount, uint32_t first, uint32_t count,
                                                         float4* __restrict__ world, uint2* __restrict__ scaleMesh, uint32_t* __restrict__ postPass)
 {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -805,7 +805,11 @@ __global__ __launch_bounds__(256) void draw_split_kernel(const NvMeshDraw* __res
 	const float4* p = reinterpret_cast<const float4*>(draws + first + i);
 	const float4 d0 = p[0], d1 = p[1];
 	const uint4 ids = *reinterpret_cast<const uint4*>(p + 2);
-	const float4 cr = *reinterpret_cast<const float4*>(meshes + ids.x); // center.xyz, radius
+	// A draw the passes always skip (postPass mismatch, never visible) may carry any meshIndex: the decide kernel never reads
+	// its Mesh, so the mirror must not either.  With a registered table the index is clamped — the entry of such a
+	// draw is never used; a valid index is untouched.
+	const uint32_t mi = meshCount && ids.x >= meshCount ? 0u : ids.x;
+	const float4 cr = *reinterpret_cast<const float4*>(meshes + mi); // center.xyz, radius
 	const f3 r = rotate_quat(f3{ cr.x, cr.y, cr.z }, f3{ d1.x, d1.y, d1.z }, d1.w);
 	// the same three statements as sphere_center() (cullmath.h) before view_point()
 	world[first + i] = make_float4(r.x * d0.w + d0.x, r.y * d0.w + d0.y, r.z * d0.w + d0.z, cr.w * d0.w);
@@ -813,11 +817,11 @@ __global__ __launch_bounds__(256) void draw_split_kernel(const NvMeshDraw* __res
 	postPass[first + i] = ids.z;
 }
 
-int launch_draw_split(hipStream_t stream, const NvMeshDraw* draws, const NvMesh* meshes, uint32_t first, uint32_t count, float4* world, uint2* scaleMesh,
+int launch_draw_split(hipStream_t stream, const NvMeshDraw* draws, const NvMesh* meshes, uint32_t meshCount, uint32_t first, uint32_t count, float4* world, uint2* scaleMesh,
                       uint32_t* postPass)
 {
 	if (count)
-		hipLaunchKernelGGL(draw_split_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, draws, meshes, first, count, world, scaleMesh, postPass);
+		hipLaunchKernelGGL(draw_split_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, draws, meshes, meshCount, first, count, world, scaleMesh, postPass);
 	return (int)hipGetLastError();
 }
 

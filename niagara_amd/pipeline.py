@@ -69,6 +69,14 @@ class Context:
     def set_option(self, option, value):
         check(lib.nv_set_option(self.h, int(option), int(value)), "nv_set_option")
 
+    def reserve(self, max_draws, max_commands=0):
+        """scratch for passes over up to max_draws draws (nv_create reserves 1 M): pass entry points never allocate"""
+        check(lib.nv_reserve(self.h, int(max_draws), int(max_commands)), "nv_reserve")
+
+    def share_scene(self, other):
+        """use `other`'s scene mirrors (meshlet SoA, draw mirror, mesh table) instead of building this context's own"""
+        check(lib.nv_share_scene(self.h, other.h), "nv_share_scene")
+
     def profile(self, enabled):
         check(lib.nv_profile_enable(self.h, int(enabled)), "nv_profile_enable")
 
@@ -207,7 +215,7 @@ class VisibilityPipeline:
         mi = np.minimum(draws["meshIndex"].astype(np.int64), max(0, len(meshes) - 1))
         worst_meshlets = int(per_mesh[mi].sum()) if len(draws) and len(meshes) else 0
         worst_tasks = int(((per_mesh[mi] + 63) // 64).sum()) if len(draws) and len(meshes) else 0
-        if tcap < min(worst_tasks, L.TASK_WGLIMIT) + 64 or ccap < min(worst_meshlets, L.CLUSTER_LIMIT):
+        if tcap < min(worst_tasks, L.TASK_WGLIMIT) or ccap < min(worst_meshlets, L.CLUSTER_LIMIT):
             raise NvError("task_capacity %d / cluster_capacity %d cannot hold what this scene can emit (%d task commands, %d meshlets): the passes "
                           "drop output only at the reference's limits, never at a smaller buffer's end" % (tcap, ccap, worst_tasks, worst_meshlets))
         self.dcb = torch.zeros(tcap * L.TASKCMD.itemsize + 64 * L.TASKCMD.itemsize, dtype=torch.uint8, device=dev)
@@ -216,11 +224,12 @@ class VisibilityPipeline:
         self.ccb = torch.zeros(4, dtype=torch.int32, device=dev)
         self.depth_w, self.depth_h = depth_size
         self.pyramid = DepthPyramid(dev, *depth_size)
+        self.ctx.reserve(self.draw_count, tcap)
+        self.ctx.upload_meshes(self.mb, self.mesh_count)
         if use_soa and self.meshlet_count:
             self.ctx.upload_meshlets(self.mlb, self.meshlet_count)
         if use_soa and self.draw_count:
             self.ctx.upload_draws(self.db, self.draw_count, self.mb)
-        self.ctx.upload_meshes(self.mb, self.mesh_count)
 
     # src/niagara.cpp:1530-1574
     def cull(self, cull_data, late, task=True, post_pass=0):

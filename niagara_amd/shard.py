@@ -44,7 +44,10 @@ class CountsReducer:
 
         red = CountsReducer(ctx, device, batch)
         for i in range(steps): red.before_pass(i); ctx.clustercull(...); red.after_pass(i)
-        red.drain(steps); total = red.last(steps)          # int64[3], summed over the ranks
+        red.drain(steps); total = red.last(steps)          # int64[3], summed over the ranks (world size 1: the pass's own counts)
+
+    Rows of a block that no pass has written since the block's last reduction are zero, so a partial last batch reduces
+    zeros there, never the sums of an earlier use.
     """
 
     def __init__(self, ctx, device, batch=8, stream=None):
@@ -58,16 +61,23 @@ class CountsReducer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.blocks = [torch.zeros((self.B, 3), dtype=torch.int64, device=device) for _ in range(2)]
         self.pending = [None, None]
+        # the rows' addresses, marshalled once: before_pass runs once per pass, and a pass is ~30 us
+        import ctypes
+        from ._lib import lib
+        self._sink = lib.nv_set_counts_sink
+        self._rows = [[ctypes.c_void_p(self.blocks[k][r].data_ptr()) for r in range(self.B)] for k in range(2)]
 
     def before_pass(self, i):
-        if self.world == 1:
-            return
         blk, row = (i // self.B) % 2, i % self.B
-        if row == 0 and self.pending[blk] is not None:
+        if self.world == 1:  # nothing to sum: the scatter launch still leaves the pass's counts in its row, so last() holds for any world size
+            self._sink(self.ctx.h, self._rows[blk][row])
+            return
+        if row == 0:
             with self._on():
-                self.pending[blk].wait()  # the block's previous reduction (issued 2 B passes ago)
-            self.pending[blk] = None
-        self.ctx.set_counts_sink(self.blocks[blk][row])
+                if self.pending[blk] is not None:
+                    self.pending[blk].wait()  # the block's previous reduction (issued 2 B passes ago)
+                    self.pending[blk] = None
+        self._sink(self.ctx.h, self._rows[blk][row])
 
     def after_pass(self, i):
         if self.world > 1 and i % self.B == self.B - 1:
@@ -82,6 +92,7 @@ class CountsReducer:
         with self._on():
             if n_steps % self.B:
                 blk = (n_steps // self.B) % 2
+                self.blocks[blk][n_steps % self.B:].zero_()  # rows this partial batch did not write still hold an earlier use's sums
                 self.pending[blk] = self.dist.all_reduce(self.blocks[blk], async_op=True)
             for k in range(2):
                 if self.pending[k] is not None:

@@ -46,6 +46,7 @@ class GpuScene:
         dccb = torch.full((4,), 12345 if self.fused else 0, dtype=torch.int32, device=dev)
         dvb = torch.from_numpy(dvb_host.view(np.int32).copy()).to(dev)
         pd = cd.copy()
+        pd["clusterBackfaceEnabled"] = 1 if post_pass == 0 else 0  # cull(): src/niagara.cpp:1549
         pd["postPass"] = post_pass
         self.ctx.drawcull(pd, late, task, self.db, self.mb, dcb, dccb, dvb, self.pyramid.desc if with_pyramid else None)
         return dcb, dccb, dvb
@@ -81,14 +82,15 @@ def run_frames(ctx, scene, flags, frames=2, use_soa=True, fused=False):
     out = []
     for f in range(frames):
         rec = {}
-        for phase, late in (("early", 0), ("late", 1)):
-            if late:
+        phases = [("early", 0, 0), ("late", 1, 0)] + ([("post", 1, 1)] if int(scene.get("post_mask", 0)) >> 1 else [])
+        for phase, late, post in phases:
+            if phase == "late":
                 depth = scene["depth"] if f > 0 else np.zeros_like(scene["depth"])
                 rec["pyramid"] = g.depthreduce(depth).copy()
-            dcb, dccb, dvb = g.drawcull(cd, late, 1, dvb_host)
+            dcb, dccb, dvb = g.drawcull(cd, late, 1, dvb_host, post_pass=post)
             if not fused:
                 ctx.tasksubmit(dccb, dcb)
-            cib, ccb = g.clustercull(cd, late, dcb, dccb, mvb)
+            cib, ccb = g.clustercull(cd, late, dcb, dccb, mvb, post_pass=post)
             dvb_host = host_u32(dvb).copy()
             c4, cc4 = host_u32(dccb), host_u32(ccb)
             rec[phase] = dict(commands=P.from_device(dcb, L.TASKCMD)[:int(c4[1]) * 64].copy(), count4=c4.copy(),

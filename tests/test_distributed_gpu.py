@@ -24,10 +24,12 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("batch, streams", [(8, 2), (1, 2), (3, 2), (8, 1), (3, 3)])
-def test_bench_two_ranks_on_one_device(batch, streams):
+@pytest.mark.parametrize("batch, streams, total", [(8, 2, 0), (1, 2, 0), (3, 2, 0), (8, 1, 0), (3, 3, 0), (8, 1, 3_000_000 + 64 * 7)])
+def test_bench_two_ranks_on_one_device(batch, streams, total):
     """python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --backend gloo --shared-device: rc 0, one JSON
-    line, and the all-reduced visible count of the last pass = the sum of what the oracle sees in the two shards"""
+    line, and the all-reduced visible count of the last pass = the sum of what the oracle sees in the two shards.  total > 0:
+    the strong-scaling mode (--total-meshlets), with a shard boundary in the middle of a draw's commands."""
+    import argparse
     import oracle
     sys.path.insert(0, ROOT)
     import bench
@@ -36,23 +38,43 @@ def test_bench_two_ranks_on_one_device(batch, streams):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
            str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--shared-device", "--steps", str(steps), "--warmup", "3",
-           "--counts-batch", str(batch), "--streams", str(streams), "--draws", str(draws_per_rank), "--no-cpu-baseline"]
+           "--counts-batch", str(batch), "--streams", str(streams), "--draws", str(draws_per_rank), "--no-cpu-baseline"] + (["--total-meshlets", str(total)] if total else [])
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["steps"] == steps and rec["scaling"] == "weak" and rec["config"]["streams"] == streams
+    assert rec["n_gpus"] == 2 and rec["steps"] == steps and rec["scaling"] == ("strong" if total else "weak") and rec["config"]["streams"] == streams
+    assert rec["config"]["meshlets_total"] == (total if total else 2 * draws_per_rank * cpd * 64)
+    assert "collective_wait_ms" in rec and rec["throughput_overlapped"] is None
     assert len(set(rec["config"]["visible_per_stream"])) == 1  # every stream's last pass saw the same scene
     want = []
+    args = argparse.Namespace(draws=draws_per_rank, commands_per_draw=cpd, total_meshlets=total)
     for rank in range(2):
-        draws, meshlets, cd, c4 = bench.make_inputs(draws_per_rank, cpd, rank, 2)
-        commands = synth.make_task_commands(draws_per_rank, cpd)
+        draws, meshlets, cd, (b, e), _ = bench.make_inputs(args, rank, 2)
+        commands = bench.make_commands(b, e, cpd)
         cib, cc4 = np.zeros(len(commands) * 64, np.uint32), np.zeros(4, np.uint32)
-        oracle.clustercull(cd, 0, commands, c4, draws, meshlets, None, None, cib, cc4, threads=oracle.max_threads())
+        oracle.clustercull(cd, 0, commands, synth.count4_for(e - b), draws, meshlets, None, None, cib, cc4, threads=oracle.max_threads())
         want.append(int(cc4[0]))
-    assert rec["config"]["visible_per_gpu"] == want[0]
+    if total:
+        assert (total // 64 // 2) % cpd != 0  # the boundary splits a draw's commands
+    assert rec["config"]["visible_rank0"] == want[0]
     assert rec["config"]["visible_total"] == want[0] + want[1] and want[1] > 0
+
+
+def test_bench_single_gpu_line_is_one_regime():
+    """the default line's value / ms_per_step are one pass after the other on one stream, the dominant kernel's
+    event time fits inside a step, and the several-passes-in-flight figure is a side field"""
+    sys.path.insert(0, ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--draws", "6000", "--cpu-seconds", "0.2"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["config"]["streams"] == 1 and "note" not in rec
+    assert rec["roofline"]["kernel_avg_us"] * 1e-3 <= rec["ms_per_step"] * 1.02
+    assert abs(rec["roofline"]["ms_per_pass_single_stream"] - rec["ms_per_step"]) < 1e-9
+    assert rec["throughput_overlapped"]["streams"] == 3 and rec["throughput_overlapped"]["value"] > 0
+    assert rec["cpu_baseline"]["visible_list"].startswith("bit-identical") and rec["config"]["visible_total"] == rec["config"]["visible_rank0"]
 
 
 def _worker(rank, world, port, out_dir):

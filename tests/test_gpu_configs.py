@@ -9,6 +9,8 @@ functions with a handful of iterations, so the numbers in profiles/ and the pari
     config 4   4096^2 depth -> 2048^2 x 12 pyramid, then clustercull<1> over 10 M meshlets with random visibility bits and
                lateDrawVisibility: IDs and the rewritten meshletVisibility words
     dense      config 3A's 10 M meshlets as a cloud of radius 40 seen from outside (87 % of the commands have survivors), cone on / off
+    frame      niagara's dependent frame (early cull -> pyramid -> late cull) at BASELINE scale: 1 M draws, ~10 M meshlets tested per
+               cluster pass, 4096^2 depth, three rotated scene copies, both launch forms; every buffer of a frame's two phases
 """
 import importlib.util
 import os
@@ -61,3 +63,19 @@ def test_config4_pyramid_and_late_pass(bc, ctx):
 def test_dense_visibility(bc, ctx, backface):
     r = bc.cluster_config(ctx, 3, "dense", 15625, 10, scene_radius=40.0, backface=backface, cam_pos=(0, 0, 60))
     assert r["parity"] == "bit-identical" and r["commands_with_survivors"] > 0.3
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_frame_at_baseline_scale(bc, fused):
+    """the frame chain at 1 M draws / 4096^2 / ~10 M meshlets per cluster pass, 3 timed frames over 3 rotated scene
+    copies, frame N's visibility feeding frame N + 1; the buffers of both phases of one more frame against the oracle"""
+    from niagara_amd import pipeline as P
+    c = P.Context()
+    try:
+        r = bc.config_frame(c, 3, fused=fused)
+    finally:
+        c.close()
+    assert r["parity"] == "bit-identical" and r["draws"] == 1_000_000
+    assert r["early"]["meshlets_tested"] > 8_000_000 and r["late"]["meshlets_tested"] > 8_000_000
+    assert r["early"]["visible"] > 1_000_000 and r["late"]["draws_visible"] > 10_000
+    assert r["frames_on_checked_copy"] >= 3

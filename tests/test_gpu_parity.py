@@ -136,17 +136,20 @@ def test_submit_kernels(ctx):
 @pytest.mark.parametrize("use_soa", [True, False])
 @pytest.mark.parametrize("seed", [21, 22])
 def test_two_frame_protocol(ctx, seed, use_soa, fused):
-    """early -> pyramid -> late over three frames, every intermediate buffer bit-identical to the oracle"""
-    scene = make_scene(seed=seed, n_draws=1500, meshlets_lod0=130, zero_radius_fraction=0.02)
+    """early -> pyramid -> late (-> post: seed 22's scene has postPass draws, src/niagara.cpp:1781-1787) over three frames, every
+    intermediate buffer bit-identical to the oracle"""
+    scene = make_scene(seed=seed, n_draws=1500, meshlets_lod0=130, zero_radius_fraction=0.02, post_pass_fraction=0.15 if seed == 22 else 0.0)
     for flags in [(1, 1, 1, 1, 1), (1, 1, 1, 0, 1), (1, 0, 0, 0, 0), (0, 1, 1, 1, 0), (1, 1, 0, 1, 1)]:
         fo = passes.run_frames(oracle, scene, flags, frames=3)
         fg = G.run_frames(ctx, scene, flags, frames=3, use_soa=use_soa, fused=fused)
         for a, b in zip(fo, fg):
             assert a["pyramid"].tobytes() == b["pyramid"].tobytes()
-            for phase in ("early", "late"):
+            for phase in [p for p in ("early", "late", "post") if p in a]:
                 for key in ("count4", "commands", "cc4", "cib", "dvb", "mvb"):
                     assert a[phase][key].tobytes() == b[phase][key].tobytes(), (flags, phase, key)
         assert fo[0]["late"]["cc4"][0] > 0
+        if seed == 22:
+            assert fo[0]["post"]["cc4"][0] > 0 and fo[1]["post"]["count4"][0] > 0
 
 
 def test_randomised_scenes(ctx):
@@ -160,7 +163,8 @@ def test_randomised_scenes(ctx):
         fg = G.run_frames(ctx, scene, flags, frames=3, use_soa=use_soa, fused=fused)
         for a, b in zip(fo, fg):
             assert a["pyramid"].tobytes() == b["pyramid"].tobytes(), (seed, kw)
-            for phase in ("early", "late"):
+            assert ("post" in a) == ("post" in b) == bool(int(scene["post_mask"]) >> 1)
+            for phase in [p for p in ("early", "late", "post") if p in a]:
                 for key in ("count4", "commands", "cc4", "cib", "dvb", "mvb"):
                     assert a[phase][key].tobytes() == b[phase][key].tobytes(), (seed, kw, flags, use_soa, fused, phase, key)
 
@@ -395,6 +399,120 @@ def test_graph_replay_is_safe(ctx):
             assert total == int(cc4_o[0])
             assert (G.host_u32(cib)[:total] == cib_o[:total]).all()
     ctx.status()
+
+
+def test_capture_of_a_growing_draw_count(ctx):
+    """no pass entry point allocates, frees or synchronises, so a sequence of frame phases over a GROWING
+    number of draws (up to what nv_reserve was given) records into one HIP graph; the replay leaves the oracle's buffers."""
+    meshes, total = synth.make_meshes(2, 2, 70)
+    meshlets = synth.make_meshlets(total)
+    sizes = [40_000, 700_000, 1_500_000, 2_600_000]  # the last is above the 2 097 088 draws nv_create's scratch holds
+    draws = host.synth_draws(sizes[-1], 2, 300.0)
+    host.assign_visibility_offsets(draws, meshes)
+    dev = ctx.device
+    ctx.reserve(sizes[-1], 1 << 19)
+    db, mb, mlb = P.to_device(draws, dev), P.to_device(meshes, dev), P.to_device(meshlets, dev)
+    ctx.upload_meshes(mb, len(meshes))
+    ctx.upload_meshlets(mlb, len(meshlets))
+    ctx.upload_draws(db, len(draws), mb)
+    cap = 1 << 19
+    T = oracle.max_threads()
+    bufs = []
+    for n in sizes:
+        cd = host.build_cull_data(draw_count=n, cullingEnabled=1, lodEnabled=1, clusterBackfaceEnabled=1)
+        co, c4o = np.zeros(cap, dtype=L.TASKCMD), np.zeros(4, np.uint32)
+        oracle.drawcull(cd, 0, 1, draws[:n], meshes, co, c4o, np.ones(n, np.uint32), None, threads=T)
+        oracle.tasksubmit(c4o, co)
+        ncmd = int(c4o[1]) * 64
+        assert ncmd < cap
+        cib_o, cc4_o = np.zeros(ncmd * 64 + 256, np.uint32), np.zeros(4, np.uint32)
+        oracle.clustercull(cd, 0, co, c4o, draws[:n], meshlets, None, None, cib_o, cc4_o, threads=T)
+        oracle.clustersubmit(cc4_o, cib_o)
+        bufs.append(dict(n=n, cd=cd, want=(co, c4o, ncmd, cib_o, cc4_o),
+                         dcb=torch.zeros(cap * 20, dtype=torch.uint8, device=dev), dccb=torch.zeros(4, dtype=torch.int32, device=dev),
+                         ccb=torch.zeros(4, dtype=torch.int32, device=dev), cib=torch.zeros(ncmd * 64 + 256, dtype=torch.int32, device=dev),
+                         dvb=torch.ones(n, dtype=torch.int32, device=dev)))
+
+    def record():
+        for b in bufs:
+            ctx.reset_count(b["dccb"], b["ccb"])
+            ctx.drawcull(b["cd"], 0, 1, db, mb, b["dcb"], b["dccb"], b["dvb"], None)
+            ctx.tasksubmit(b["dccb"], b["dcb"])
+            ctx.clustercull(b["cd"], 0, b["dcb"], b["dccb"], db, mlb, None, None, b["cib"], b["ccb"])
+            ctx.clustersubmit(b["ccb"], b["cib"])
+
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        record()  # warm-up outside the capture
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            record()
+        for b in bufs:
+            b["cib"].zero_()
+            b["dcb"].zero_()
+        for _ in range(2):
+            graph.replay()
+        torch.cuda.synchronize()
+    ctx.status()
+    for b in bufs:
+        n = b["n"]
+        co, c4o, ncmd, cib_o, cc4_o = b["want"]
+        assert (G.host_u32(b["dccb"]) == c4o).all(), n
+        assert P.from_device(b["dcb"], L.TASKCMD)[:ncmd].tobytes() == co[:ncmd].tobytes(), n
+        assert (G.host_u32(b["ccb"]) == cc4_o).all(), n
+        nv = (int(cc4_o[0]) + 255) // 256 * 256
+        assert (G.host_u32(b["cib"])[:nv] == cib_o[:nv]).all(), n
+    ctx.upload_draws(None, 0)
+
+
+def test_three_contexts_share_one_scene_mirror():
+    """contexts on three streams (three views in flight) use ONE set of SoA mirrors after nv_share_scene —
+    device memory grows by one mirror, not three — and each produces the oracle's list for its own view."""
+    draws, meshlets, commands, n, cd = _cluster_inputs(40_000, 10)  # 25.6 M meshlets: a 307 MB mirror
+    c4 = synth.count4_for(n)
+    ctxs = [P.Context() for _ in range(3)]
+    try:
+        dev = ctxs[0].device
+        db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+        dccb = torch.from_numpy(c4.view(np.int32).copy()).to(dev)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        ctxs[0].upload_meshlets(mlb, len(meshlets))
+        torch.cuda.synchronize()
+        one_mirror = free0 - torch.cuda.mem_get_info()[0]
+        assert one_mirror >= len(meshlets) * 12
+        for c in ctxs[1:]:
+            c.share_scene(ctxs[0])
+        torch.cuda.synchronize()
+        assert free0 - torch.cuda.mem_get_info()[0] <= one_mirror + (8 << 20)  # still one mirror
+        streams = [torch.cuda.Stream() for _ in ctxs]
+        cams = [(0, 0, 0), (50, 0, 0), (0, -80, 20)]
+        outs = []
+        for c, s, cam in zip(ctxs, streams, cams):
+            cdv = host.build_cull_data(cam_pos=cam, draw_count=len(draws), cullingEnabled=1, clusterBackfaceEnabled=1)
+            cib = torch.zeros(n * 64 + 256, dtype=torch.int32, device=dev)
+            ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+            with torch.cuda.stream(s):
+                c.clustercull(cdv, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
+            outs.append((cdv, cib, ccb))
+        torch.cuda.synchronize()
+        # a context that goes away leaves the others' mirror alone
+        ctxs[0].close()
+        for (cdv, cib, ccb), c, s in zip(outs[1:], ctxs[1:], streams[1:]):
+            with torch.cuda.stream(s):
+                ccb.zero_()
+                c.clustercull(cdv, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
+        torch.cuda.synchronize()
+        T = oracle.max_threads()
+        for cdv, cib, ccb in outs:
+            cib_o, cc4_o = np.zeros(n * 64, np.uint32), np.zeros(4, np.uint32)
+            oracle.clustercull(cdv, 0, commands, c4, draws, meshlets, None, None, cib_o, cc4_o, threads=T)
+            total = int(ccb[0].item())
+            assert total == int(cc4_o[0]) and (G.host_u32(cib)[:total] == cib_o[:total]).all()
+    finally:
+        for c in ctxs:
+            c.close()
 
 
 def _compare_cluster_pass(ctx, draws, meshlets, commands, n, cd, late, mvb0, pyr, gp, soa=True):
@@ -709,8 +827,9 @@ def test_frustum_coefficients_outside_the_unit_range(ctx, scale):
 
 
 def test_three_million_draws_then_clustercull(ctx):
-    """ADVICE r1 (high) / VERDICT r1 item 4a: a drawcull above the initial result-scratch capacity (2 097 088 draws) grows
-    the scratch; the cluster pass behind it must still find its mapped hint word (it was freed with the old scratch)."""
+    """ADVICE r1 (high) / VERDICT r1 item 4a + r2 item 8: a drawcull above the initial result-scratch capacity (2 097 088
+    draws) is refused with NV_ENOMEM — a pass entry point never allocates or synchronises — until nv_reserve raised the
+    scratch; the cluster pass behind it must still find its mapped hint word (it was once freed with the old scratch)."""
     n_draws = 3_000_000
     meshes, total = synth.make_meshes(2, 2, 70)
     meshlets = synth.make_meshlets(total)
@@ -735,6 +854,9 @@ def test_three_million_draws_then_clustercull(ctx):
         dccb, ccb = torch.zeros(4, dtype=torch.int32, device=dev), torch.zeros(4, dtype=torch.int32, device=dev)
         dvb = torch.ones(n_draws, dtype=torch.int32, device=dev)
         cib = torch.zeros(ncmd * 64 + 256, dtype=torch.int32, device=dev)
+        with pytest.raises(P.NvError, match="NV_ENOMEM"):
+            c.drawcull(cd, 0, 1, db, mb, dcb, dccb, dvb, None)
+        c.reserve(n_draws, cap)
         for _ in range(2):
             dccb.zero_()
             ccb.zero_()

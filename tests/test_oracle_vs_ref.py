@@ -217,13 +217,15 @@ def test_tasksubmit_and_clustersubmit_padding_and_clamps():
 
 @pytest.mark.parametrize("seed", [21, 22, 23])
 def test_two_frame_protocol_all_cluster_flags(seed):
-    scene = make_scene(seed=seed, n_draws=250, meshlets_lod0=130, zero_radius_fraction=0.02)
+    # seed 23: a quarter of the draws are postPass draws, so every frame has the third phase (src/niagara.cpp:1781-1787)
+    scene = make_scene(seed=seed, n_draws=250, meshlets_lod0=130, zero_radius_fraction=0.02, post_pass_fraction=0.25 if seed == 23 else 0.0)
     for flags in [(1, 1, 1, 1, 1), (1, 1, 1, 0, 1), (1, 0, 0, 0, 0), (0, 1, 1, 1, 0), (1, 1, 0, 1, 1)]:
         fo = passes.run_frames(oracle, scene, flags, frames=2)
         fr = passes.run_frames(R, scene, flags, frames=2)
         for a, b in zip(fo, fr):
             assert a["pyramid"].tobytes() == b["pyramid"].tobytes()
-            for phase in ("early", "late"):
+            assert ("post" in a) == (seed == 23)
+            for phase in [p for p in ("early", "late", "post") if p in a]:
                 for key in ("commands", "count4", "cib", "cc4", "dvb", "mvb"):
                     assert a[phase][key].tobytes() == b[phase][key].tobytes(), (flags, phase, key)
         # the protocol does something: frame 0 early emits nothing, frame 0 late establishes the visible set

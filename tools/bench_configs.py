@@ -255,6 +255,238 @@ def config4(ctx, iters, size=4096, n_draws=15625, cpd=10):
                 late_pass_frac=algo / pass_us / 1e3 / HBM, meshlets_per_s=m / (pass_us * 1e-6))
 
 
+def frame_scene(n_draws, lod0, size):
+    """the frame benchmark's scene: niagara's draw generator over 64 meshes x 4 LODs, a seeded meshlet pool, a synthetic depth
+    target; flags as niagara ships them with every culling feature on"""
+    meshes, total = synth.make_meshes(64, 4, lod0)
+    meshlets = synth.make_meshlets(total)
+    draws = host.synth_draws(n_draws, 64, 300.0)
+    slots, _ = host.assign_visibility_offsets(draws, meshes)
+    depth = synth.make_depth(size, size)
+    pw = host.previous_pow2(size)
+    cd = host.build_cull_data(draw_count=n_draws, viewport=(size, size), pyramid=(pw, pw), cullingEnabled=1, lodEnabled=1, occlusionEnabled=1,
+                              clusterOcclusionEnabled=1, clusterBackfaceEnabled=1)
+    return meshes, meshlets, draws, slots, depth, cd
+
+
+def oracle_frames(meshes, meshlets, draws, slots, depth, cd, size, frames, first_cleared=False):
+    """the reference's frame order (src/niagara.cpp:1765-1788) on the CPU oracle; returns the last frame's buffers per phase and
+    the per-phase counts; stops early once a frame reproduces the previous frame's state AND outputs (a static camera reaches
+    that fixed point with frame 1: every later frame is identical).  first_cleared: frame 0 reduces a cleared depth target, like
+    examples/frame_driver and the reference's first frame (its visibility bits outlive the frame: history matters)"""
+    T = oracle.max_threads()
+    n = len(draws)
+    dvb, mvb = np.zeros(n, np.uint32), np.zeros((slots + 31) // 32 + 2, np.uint32)
+    pyr = oracle.Pyramid(size, size)
+    cap = L.TASK_WGLIMIT + 64
+    prev = None
+    for f in range(frames):
+        rec = {}
+        for phase, late in (("early", 0), ("late", 1)):
+            if late:
+                oracle.depthreduce(np.zeros_like(depth) if first_cleared and f == 0 else depth, pyr)
+            co, c4 = np.zeros(cap, dtype=L.TASKCMD), np.zeros(4, np.uint32)
+            pd = cd.copy()
+            pd["clusterBackfaceEnabled"] = 1
+            oracle.drawcull(pd, late, 1, draws, meshes, co, c4, dvb, pyr, threads=T)
+            oracle.tasksubmit(c4, co)
+            ncmd = int(c4[1]) * 64
+            cib, cc4 = np.zeros(min(ncmd * 64, L.CLUSTER_LIMIT) + 256, np.uint32), np.zeros(4, np.uint32)
+            oracle.clustercull(cd, late, co, c4, draws, meshlets, mvb, pyr, cib, cc4, threads=T)
+            oracle.clustersubmit(cc4, cib)
+            nv = (min(int(cc4[0]), L.CLUSTER_LIMIT) + 255) // 256 * 256
+            rec[phase] = dict(count4=c4, commands=co[:ncmd].copy(), cc4=cc4, cib=cib[:nv].copy(), dvb=dvb.copy(), mvb=mvb.copy(),
+                              tested=int(co[:min(int(c4[0]), L.TASK_WGLIMIT)]["taskCount"].sum()))
+        rec["pyramid"] = pyr.data.copy()
+        if prev is not None and all(prev[ph][k].tobytes() == rec[ph][k].tobytes() for ph in ("early", "late") for k in ("count4", "commands", "cc4", "cib", "dvb", "mvb")):
+            return rec, f + 1
+        prev = rec
+    return prev, frames
+
+
+def config_frame(ctx, iters, n_draws=1_000_000, lod0=2200, size=4096, copies=3, fused=True, cpp_driver=False):
+    """VERDICT r2 item 2 — the drop-in number: niagara's dependent frame at BASELINE scale, one frame after the other on one
+    stream (src/niagara.cpp:1765-1788):
+
+        drawcull<0,TASK> -> tasksubmit -> clustercull<0> -> clustersubmit -> depthreduce (4096^2 -> 2048^2 x 12)
+        -> drawcull<1,TASK> -> tasksubmit -> clustercull<1> -> clustersubmit
+
+    1 M draws over 64 meshes x 4 LODs (LOD 0 = `lod0` meshlets: ~10 M meshlets tested per cluster pass), every culling flag on,
+    frame N's late visibility (drawVisibility, meshletVisibility) feeding frame N + 1's early pass.  `copies` complete scene copies
+    (draws + mirror, visibility buffers, depth target, pyramid) are rotated so that no frame finds its 48 MB of draws, its
+    visibility words or its depth target in the 256 MiB Infinity Cache.  fused = NV_OPT_FUSED_COUNT_RESET + NV_OPT_FUSED_SUBMIT
+    (11 launches per frame); otherwise the reference's dispatch sequence one to one (19 launches)."""
+    dev = ctx.device
+    meshes, meshlets, draws, slots, depth_h, cd = frame_scene(n_draws, lod0, size)
+    ctx.set_option(P.NV_OPT_FUSED_COUNT_RESET, int(fused))
+    ctx.set_option(P.NV_OPT_FUSED_SUBMIT, int(fused))
+    ctx.reserve(n_draws, L.TASK_WGLIMIT)
+    mb, mlb = P.to_device(meshes, dev), P.to_device(meshlets, dev)
+    ctx.upload_meshes(mb, len(meshes))
+    ctx.upload_meshlets(mlb, len(meshlets))
+    one = P.to_device(draws, dev)
+    db_all = torch.cat([one] * copies)
+    dbs = [db_all[c * one.numel():(c + 1) * one.numel()] for c in range(copies)]
+    ctx.upload_draws(db_all, copies * n_draws, mb)
+    mvb_words = (slots + 31) // 32 + 2
+    dvbs = [torch.zeros(n_draws, dtype=torch.int32, device=dev) for _ in range(copies)]
+    mvbs = [torch.zeros(mvb_words, dtype=torch.int32, device=dev) for _ in range(copies)]
+    depths = [torch.from_numpy(depth_h).to(dev) for _ in range(copies)]
+    pyrs = [P.DepthPyramid(dev, size, size) for _ in range(copies)]
+    dcb = torch.zeros((L.TASK_WGLIMIT + 64) * L.TASKCMD.itemsize, dtype=torch.uint8, device=dev)
+    dccb = torch.zeros(4, dtype=torch.int32, device=dev)
+    cib = torch.zeros(L.CLUSTER_LIMIT + 256, dtype=torch.int32, device=dev)
+    ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+    pd = cd.copy()
+    pd["clusterBackfaceEnabled"] = 1  # cull(): src/niagara.cpp:1549, postPass 0
+    frames_of = [0] * copies
+
+    def phase(c, late):
+        if not fused:
+            ctx.reset_count(dccb)
+        ctx.drawcull(pd, late, 1, dbs[c], mb, dcb, dccb, dvbs[c], pyrs[c].desc)
+        if not fused:
+            ctx.tasksubmit(dccb, dcb)
+            ctx.reset_count(ccb)
+        ctx.clustercull(cd, late, dcb, dccb, dbs[c], mlb, mvbs[c], pyrs[c].desc, cib, ccb)
+        if not fused:
+            ctx.clustersubmit(ccb, cib)
+
+    def frame(i):
+        c = i % copies
+        phase(c, 0)
+        ctx.depthreduce(depths[c], size, size, pyrs[c].desc)
+        phase(c, 1)
+        frames_of[c] += 1
+
+    k = 0
+    for _ in range(2 * copies):  # every copy reaches the steady state (frame 0 establishes the visible set, frame 1 is the first real one)
+        frame(k)
+        k += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        frame(k)
+        k += 1
+    torch.cuda.synchronize()
+    frame_us = (time.perf_counter() - t0) / iters * 1e6
+
+    # per-pass breakdown: the library's event pairs, read (and thereby synchronised) after every phase
+    names = ("early_drawcull", "early_cluster_cull", "early_cluster_scatter", "pyramid", "late_drawcull", "late_cluster_cull", "late_cluster_hiz", "late_cluster_scatter")
+    acc = dict.fromkeys(names, 0.0)
+    ctx.profile(True)
+    n_b = max(3, min(iters, 10))
+    for _ in range(n_b):
+        c = k % copies
+        phase(c, 0)
+        pr = ctx.profile_read()
+        acc["early_drawcull"] += pr["drawcull"][0]
+        acc["early_cluster_cull"] += pr["cluster_cull"][0]
+        acc["early_cluster_scatter"] += pr["cluster_scatter"][0]
+        ctx.depthreduce(depths[c], size, size, pyrs[c].desc)
+        acc["pyramid"] += ctx.profile_read()["depthreduce"][0]
+        phase(c, 1)
+        pr = ctx.profile_read()
+        acc["late_drawcull"] += pr["drawcull"][0]
+        acc["late_cluster_cull"] += pr["cluster_cull"][0]
+        acc["late_cluster_hiz"] += pr["cluster_hiz"][0]
+        acc["late_cluster_scatter"] += pr["cluster_scatter"][0]
+        frames_of[c] += 1
+        k += 1
+    ctx.profile(False)
+    breakdown = {n + "_us": acc[n] / n_b * 1e3 for n in names}
+
+    # ---- parity: one more frame on the next copy with every buffer of both phases read back, against the oracle after the same
+    # number of frames on that copy (errors of the timed frames would sit in its visibility state)
+    c = k % copies
+    got = {}
+    for name, late in (("early", 0), ("late", 1)):
+        if late:
+            ctx.depthreduce(depths[c], size, size, pyrs[c].desc)
+        phase(c, late)
+        if fused:  # the fused passes leave what the submit launches would; nothing else to run
+            pass
+        torch.cuda.synchronize()
+        c4, cc4 = dccb.cpu().numpy().view(np.uint32).copy(), ccb.cpu().numpy().view(np.uint32).copy()
+        ncmd = int(c4[1]) * 64
+        nv = (min(int(cc4[0]), L.CLUSTER_LIMIT) + 255) // 256 * 256
+        got[name] = dict(count4=c4, commands=P.from_device(dcb, L.TASKCMD)[:ncmd].copy(), cc4=cc4, cib=cib[:nv].cpu().numpy().view(np.uint32).copy(),
+                         dvb=dvbs[c].cpu().numpy().view(np.uint32).copy(), mvb=mvbs[c].cpu().numpy().view(np.uint32).copy())
+    got["pyramid"] = pyrs[c].data.cpu().numpy()
+    frames_of[c] += 1
+    want, simulated = oracle_frames(meshes, meshlets, draws, slots, depth_h, cd, size, frames_of[c])
+    same = got["pyramid"].tobytes() == want["pyramid"].tobytes()
+    for ph in ("early", "late"):
+        for key in ("count4", "commands", "cc4", "cib", "dvb", "mvb"):
+            same = same and got[ph][key].tobytes() == want[ph][key].tobytes()
+
+    # ---- algorithmic bytes of the frame (what the reference's shaders read and write, SURVEY.md §8d per pass): early drawcull
+    # reads postPass + the visibility word of every draw and the rest of the record only for last frame's visible draws; the late one
+    # reads every record and rewrites every visibility word; a cluster pass reads 12 cull bytes + 1 visibility bit per meshlet and
+    # command + draw per command (the late pass also writes the bit); the pyramid reads the depth target once and writes its levels.
+    e, l = want["early"], want["late"]
+    vis_prev = int(e["dvb"].sum())  # (the early pass leaves drawVisibility alone: these are last frame's visible draws)
+
+    def cluster_bytes(r, late):
+        m, ncmd = r["tested"], int(r["count4"][0])
+        return m * 12 + ncmd * 68 + m // 8 * (2 if late else 1) + int(r["cc4"][0]) * 4 + 4
+
+    bytes_ = dict(early_drawcull=n_draws * 8 + vis_prev * 44 + int(e["count4"][0]) * 20 + 4 + 208 * len(meshes), early_cluster=cluster_bytes(e, 0),
+                  pyramid=4 * size * size + pyrs[0].desc.totalTexels * 4,
+                  late_drawcull=n_draws * 56 + int(l["count4"][0]) * 20 + 4 + 208 * len(meshes), late_cluster=cluster_bytes(l, 1))
+    algo = sum(bytes_.values())
+    tested = e["tested"] + l["tested"]
+    out = dict(config="frame: 1M draws, early cull -> pyramid -> late cull at BASELINE scale" + (" (fused: 11 launches)" if fused else " (reference dispatch sequence: 19 launches)"),
+               draws=n_draws, lod0_meshlets=lod0, depth=size, scene_copies_rotated=copies, frames_timed=iters, frame_us=frame_us, **breakdown,
+               sum_of_kernels_us=sum(breakdown.values()),
+               early=dict(task_commands=int(e["count4"][0]), meshlets_tested=e["tested"], visible=int(e["cc4"][0])),
+               late=dict(task_commands=int(l["count4"][0]), meshlets_tested=l["tested"], visible=int(l["cc4"][0]), draws_visible=int(l["dvb"].sum())),
+               algorithmic_bytes=algo, algorithmic_bytes_by_pass=bytes_, achieved_GBs=algo / frame_us / 1e3, frac=algo / frame_us / 1e3 / HBM,
+               meshlets_tested_per_frame=tested, meshlets_per_s=tested / (frame_us * 1e-6), draws_per_s=2 * n_draws / (frame_us * 1e-6),
+               frames_per_s=1e6 / frame_us, oracle_frames_simulated=simulated, frames_on_checked_copy=frames_of[c], parity=verdict(same))
+    if cpp_driver:
+        out["cpp_driver"] = frame_driver_timed(meshes, meshlets, draws, slots, depth_h, cd, size, fused, iters)
+    ctx.set_option(P.NV_OPT_FUSED_COUNT_RESET, 0)
+    ctx.set_option(P.NV_OPT_FUSED_SUBMIT, 0)
+    ctx.upload_draws(None, 0)
+    return out
+
+
+def frame_driver_timed(meshes, meshlets, draws, slots, depth, cd, size, fused, iters):
+    """the same scene through examples/frame_driver (C++ on the C ABI, no Python or torch in that process) in its timed mode (one
+    scene copy, not rotated; frame 0 reduces a cleared depth target); the frame it records after the timed ones is held against the
+    oracle after the same history"""
+    import struct
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        scene, outp = os.path.join(tmp, "scene.bin"), os.path.join(tmp, "out.bin")
+        with open(scene, "wb") as f:
+            f.write(struct.pack("<6I", 0x4353564E, len(meshes), len(meshlets), len(draws), size, size))
+            f.write(cd.tobytes())
+            for a in (meshes, meshlets, draws):
+                f.write(np.ascontiguousarray(a).tobytes())
+            f.write(np.ascontiguousarray(depth, dtype=np.float32).tobytes())
+        p = subprocess.run([os.path.join(root, "examples", "frame_driver"), scene, outp, "0"] + (["fused"] if fused else []) + ["time", str(iters)],
+                           capture_output=True, text=True, timeout=1800)
+        if p.returncode != 0:
+            raise SystemExit("frame_driver failed: " + p.stderr[-2000:])
+        line = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][0])
+        blob = open(outp, "rb").read()
+    want, _ = oracle_frames(meshes, meshlets, draws, slots, depth, cd, size, 3 + iters + 1, first_cleared=True)
+    # records of the one frame written after the timed ones: early {count4, commands, cc4, cib, dvb, mvb}, pyramid, late {...}
+    pos, recs = 0, []
+    while pos < len(blob):
+        tag, nbytes = struct.unpack_from("<2I", blob, pos)
+        recs.append((tag, blob[pos + 8:pos + 8 + nbytes]))
+        pos += 8 + nbytes
+    keys = ("count4", "commands", "cc4", "cib", "dvb", "mvb")
+    expect = [want["early"][k].tobytes() for k in keys] + [want["pyramid"].tobytes()] + [want["late"][k].tobytes() for k in keys]
+    same = len(recs) == len(expect) and all(r[1] == w for r, w in zip(recs, expect))
+    return dict(frame_us=line["frame_us"], frames=line["frames"], parity=verdict(same))
+
+
 def config_n4(ctx, iters, n_draws=2048, cpd=1):
     """the mesh stage's triangle cull (meshlet.mesh.glsl with MESH_CULL = 1) over a cluster list that
     names every meshlet of a 131 k-meshlet pool once (the list a fully visible scene would produce)"""
@@ -392,6 +624,7 @@ if __name__ == "__main__":
     ctx = P.Context(0)
     runs = {"2": lambda: config2(ctx, a.iters), "2_aos": lambda: config2(P.Context(0), a.iters, soa=False), "2l": lambda: config2_late(ctx, a.iters), "3b": lambda: config3b(ctx, a.iters), "3b_fused": lambda: config3b(P.Context(0), a.iters, fused=True), "4": lambda: config4(ctx, a.iters),
             "4b": lambda: config4(ctx, a.iters, size=1024), "n4": lambda: config_n4(ctx, a.iters),
+            "frame": lambda: config_frame(P.Context(0), a.iters, cpp_driver=True), "frame_contract": lambda: config_frame(P.Context(0), a.iters, fused=False),
             "task": lambda: config_task(ctx, a.iters),
             "big": lambda: cluster_config(ctx, max(5, a.iters // 3), "3A x10 (SoA mirror)"),
             "big_aos": lambda: cluster_config(P.Context(0), max(5, a.iters // 3), "3A x10 (AoS in place)", aos=True),

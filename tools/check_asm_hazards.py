@@ -16,7 +16,11 @@ kernel in the file:
      as `; nv_ready all`).  Any other instruction that reads or writes an in-flight VGPR (a v_mov the allocator inserted
      to split a live range, a spill, a compiler-scheduled use) is reported, and so is an in-flight register at s_endpgm.
 
-    python tools/check_asm_hazards.py [-D MACRO ...]     # exit code 1 and a listing if anything is found
+The rings were validated on ONE compiler (VALIDATED_HIPCC below: register allocation and scheduling around the asm
+statements are what the scan certifies, and they change with the compiler); the scan refuses any other unless
+NV_ALLOW_UNVALIDATED_HIPCC=1, in which case it still scans and says so.
+
+    python tools/check_asm_hazards.py [--hipcc PATH] [-D MACRO ...]     # exit code 1 and a listing if anything is found
 """
 import os
 import re
@@ -29,6 +33,24 @@ SRC = os.path.join(ROOT, "niagara_amd", "csrc", "clustercull.hip")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
          "--cuda-device-only", "-S"]
 LOOKBACK = 6  # instructions
+VALIDATED_HIPCC = "roc-7.2.0"  # substring of `hipcc --version` (AMD clang 22.0.0git, ROCm 7.2.0)
+
+
+def compiler_is_validated(hipcc):
+    try:
+        text = subprocess.run([hipcc, "--version"], capture_output=True, text=True, timeout=120).stdout
+    except OSError as e:
+        print("cannot run %s: %s" % (hipcc, e))
+        return False
+    if VALIDATED_HIPCC in text:
+        return True
+    print("clustercull.hip's inline-asm load rings were validated with hipcc %s; this is:\n%s" % (VALIDATED_HIPCC, text.strip()))
+    if os.environ.get("NV_ALLOW_UNVALIDATED_HIPCC") == "1":
+        print("NV_ALLOW_UNVALIDATED_HIPCC=1: scanning anyway — re-run tests/test_plain_loads.py and the soak tools before trusting this build")
+        return True
+    print("refusing to build the asm rings with an unvalidated compiler (set NV_ALLOW_UNVALIDATED_HIPCC=1 to scan and build anyway, or "
+          "build with -DNV_PLAIN_LOADS)")
+    return False
 
 
 def sgprs(text):
@@ -194,13 +216,19 @@ def scan_inflight(name, lines):
 
 def main():
     defines = []
+    hipcc = "/opt/rocm/bin/hipcc"
     args = sys.argv[1:]
-    while args and args[0] == "-D":
-        defines.append("-D" + args[1])
+    while args and args[0] in ("-D", "--hipcc"):
+        if args[0] == "-D":
+            defines.append("-D" + args[1])
+        else:
+            hipcc = args[1]
         args = args[2:]
+    if not compiler_is_validated(hipcc):
+        return 1
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "cc.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + defines + [SRC, "-o", out], cwd=os.path.dirname(SRC), stderr=subprocess.DEVNULL)
+        subprocess.check_call([hipcc] + FLAGS + defines + [SRC, "-o", out], cwd=os.path.dirname(SRC), stderr=subprocess.DEVNULL)
         isa = open(out).read()
     blocks, guarded, problems = scan_nops(isa)
     print("inline-asm blocks: %d, of which fed by a VALU-written SGPR and guarded by s_nop: %d, unguarded: %d" % (blocks, guarded, len(problems)))
