@@ -18,7 +18,7 @@ def pytest_configure(config):
     lib = os.path.join(ROOT, "niagara_amd", "libniagara_vis.so")
     if not os.path.exists(lib):
         subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "niagara_amd", "csrc")])
-    if not os.path.exists(os.path.join(ROOT, "examples", "frame_driver")):
+    if not os.path.exists(os.path.join(ROOT, "examples", "frame_driver")) or not os.path.exists(os.path.join(ROOT, "examples", "shard_driver")):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples")])
 
 
