@@ -199,7 +199,8 @@ def test_taskcull_payloads(ctx):
         assert (G.host_u32(d_mvb) == mvb_o).all()
 
 
-@pytest.mark.parametrize("size", [(64, 64), (128, 32), (100, 75), (257, 130), (33, 2), (5, 3), (1024, 768), (4096, 4096), (2048, 1024), (1024, 512), (8192, 2048)])
+@pytest.mark.parametrize("size", [(64, 64), (128, 32), (100, 75), (257, 130), (33, 2), (5, 3), (1024, 768), (4096, 4096), (2048, 1024), (1024, 512), (8192, 2048),
+                                  (2048, 2048), (4096, 2048), (512, 256), (2048, 4096), (8192, 8192)])
 def test_depthreduce_sizes(ctx, size):
     w, h = size
     rng = np.random.default_rng(w * 1000 + h)
@@ -210,6 +211,47 @@ def test_depthreduce_sizes(ctx, size):
     ctx.depthreduce(torch.from_numpy(depth).to(ctx.device), w, h, pg.desc)
     assert (pg.width, pg.height, pg.levels) == (po.width, po.height, po.levels)
     assert pg.data.cpu().numpy().tobytes() == po.data.tobytes()
+
+
+def test_depthreduce_in_launch_tail_is_stable(ctx):
+    """the pyramid's last levels are computed by one extra workgroup of the first launch, which waits for the other workgroups'
+    flags and reads their level-4 texels past the L2 (depthreduce.hip, reduce_rows_kernel<true>): 40 builds of fresh 4096^2 and
+    2048^2 targets back to back, alternating sizes on one context (the flags' epoch advances per launch), all byte-identical;
+    special values (NaN, -0, inf) included in every other target"""
+    rng = np.random.default_rng(99)
+    dev = ctx.device
+    cases = []
+    for size in (4096, 2048):
+        for k in range(2):
+            depth = rng.random((size, size), dtype=np.float32)
+            if k:
+                sp = rng.random((size, size)) < 1e-3
+                depth[sp] = rng.choice(np.array([np.nan, -0.0, np.inf, 0.0, -np.inf, 1e-42], np.float32), int(sp.sum()))
+            po = oracle.Pyramid(size, size)
+            oracle.depthreduce(depth, po)
+            cases.append((size, torch.from_numpy(depth).to(dev), po.data.tobytes(), P.DepthPyramid(dev, size, size)))
+    for i in range(40):
+        size, d, want, pg = cases[i % len(cases)]
+        pg.data.fill_(-1.0)
+        ctx.depthreduce(d, size, size, pg.desc)
+        if i % 4 == 3:
+            for size, d, want, pg in cases:
+                assert pg.data.cpu().numpy().tobytes() == want, (i, size)
+    # ... and captured into a graph (the epoch lives in device memory and is advanced by the kernel)
+    size, d, want, pg = cases[0]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ctx.depthreduce(d, size, size, pg.desc)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            ctx.depthreduce(d, size, size, pg.desc)
+        for _ in range(5):
+            pg.data.fill_(-1.0)
+            g.replay()
+            torch.cuda.synchronize()
+            assert pg.data.cpu().numpy().tobytes() == want
+    ctx.status()
 
 
 def _cluster_inputs(draw_count, commands_per_draw, seed=2):

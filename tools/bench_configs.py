@@ -194,34 +194,50 @@ def config3b(ctx, iters, n_draws=15625 * 4, fused=False):
                 drawcull_us=prof["drawcull"][0] / max(1, prof["drawcull"][1]) * 1e3, meshlets_per_s=tested / (wall_plain * 1e-6), parity=verdict(same))
 
 
-def config4(ctx, iters, size=4096, n_draws=15625, cpd=10):
-    """two-phase HiZ: 4096^2 depth -> 2048^2 x 12 pyramid, then clustercull<LATE=1> with cluster occlusion over 10 M meshlets"""
+def config4(ctx, iters, size=4096, n_draws=15625, cpd=10, copies=4):
+    """two-phase HiZ: 4096^2 depth -> 2048^2 x 12 pyramid, then clustercull<LATE=1> with cluster occlusion over 10 M meshlets.
+    Cache-cold like configs 2 and 3A: `copies` depth targets (64 MiB each) with their own pyramids, and `copies` meshlet
+    pools + command lists + visibility words, are rotated, so that neither the 64 MiB depth image nor the 120 MB of cull bytes is
+    found in the 256 MiB Infinity Cache."""
     dev = ctx.device
-    depth = torch.from_numpy(synth.make_depth(size, size)).to(dev)
-    pyr = P.DepthPyramid(dev, size, size)
+    depth_h = synth.make_depth(size, size)
+    depths = [torch.from_numpy(depth_h).to(dev) for _ in range(copies)]
+    pyrs = [P.DepthPyramid(dev, size, size) for _ in range(copies)]
 
     def build(i):
-        ctx.depthreduce(depth, size, size, pyr.desc)
+        ctx.depthreduce(depths[i % copies], size, size, pyrs[i % copies].desc)
 
     wall_p, k_p, _ = timed(ctx, build, iters, "depthreduce")
+    for i in range(copies):  # (every pyramid complete, whatever `iters` was)
+        build(i)
+    pyr = pyrs[0]
     pyr_bytes = 4 * size * size + pyr.desc.totalTexels * 4
     draws, meshlets, commands, n = synth.cluster_scene(n_draws, cpd)
     cd = host.build_cull_data(draw_count=n_draws, viewport=(size, size), pyramid=(pyr.width, pyr.height), cullingEnabled=1, clusterBackfaceEnabled=1,
                               clusterOcclusionEnabled=1, occlusionEnabled=1)
     rng = np.random.default_rng(7)
-    commands["lateDrawVisibility"][:n] = rng.integers(0, 2, n)
-    db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
-    ctx.upload_meshlets(mlb, len(meshlets))
+    ldv = rng.integers(0, 2, n)
+    commands["lateDrawVisibility"][:n] = ldv
+    m = n * 64
+    db = P.to_device(draws, dev)
+    mlb = torch.cat([P.to_device(meshlets, dev) for _ in range(copies)])
+    dcbs = []
+    for c in range(copies):
+        cc = synth.make_task_commands(n_draws, cpd, meshlet_base=c * m)
+        cc["lateDrawVisibility"][:n] = ldv
+        dcbs.append(P.to_device(cc, dev))
+    ctx.upload_meshlets(mlb, copies * m)
     dccb = torch.from_numpy(synth.count4_for(n).view(np.int32).copy()).to(dev)
     mvb0 = torch.from_numpy(rng.integers(0, 2 ** 32, n * 2 + 4, dtype=np.uint64).astype(np.uint32).view(np.int32)).to(dev)
-    mvb = mvb0.clone()
+    mvbs = [mvb0.clone() for _ in range(copies)]
     cib = torch.zeros(n * 64 + 256, dtype=torch.int32, device=dev)
     ccb = torch.zeros(4, dtype=torch.int32, device=dev)
 
     def late(i):
-        mvb.copy_(mvb0)
+        c = i % copies
+        mvbs[c].copy_(mvb0)
         ctx.reset_count(ccb)
-        ctx.clustercull(cd, 1, dcb, dccb, db, mlb, mvb, pyr.desc, cib, ccb)
+        ctx.clustercull(cd, 1, dcbs[c], dccb, db, mlb, mvbs[c], pyrs[c].desc, cib, ccb)
 
     # the whole late pass back to back (count reset + cull + occlusion stage + scatter), no event brackets between the kernels;
     # the visibility words are not restored in this loop (same work per pass: every command is tested either way)
@@ -230,25 +246,26 @@ def config4(ctx, iters, size=4096, n_draws=15625, cpd=10):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(iters):
+        c = i % copies
         ctx.reset_count(ccb)
-        ctx.clustercull(cd, 1, dcb, dccb, db, mlb, mvb, pyr.desc, cib, ccb)
+        ctx.clustercull(cd, 1, dcbs[c], dccb, db, mlb, mvbs[c], pyrs[c].desc, cib, ccb)
     torch.cuda.synchronize()
     pass_us = (time.perf_counter() - t0) / iters * 1e6
     wall_c, k_c, prof = timed(ctx, late, iters, "cluster_cull")
     k_h = prof["cluster_hiz"][0] / max(1, prof["cluster_hiz"][1]) * 1e3
     k_s = prof["cluster_scatter"][0] / max(1, prof["cluster_scatter"][1]) * 1e3
-    m = n * 64
     algo = m * 12 + n * 68 + n * 8 + m // 4
-    # parity: the pyramid, the visible IDs and the rewritten visibility words against the oracle
+    # parity: every pyramid, and the visible IDs + the rewritten visibility words of the last timed pass, against the oracle
     po = oracle.Pyramid(size, size)
-    oracle.depthreduce(depth.cpu().numpy(), po)
+    oracle.depthreduce(depth_h, po)
     mvo = mvb0.cpu().numpy().view(np.uint32).copy()
     cib_o, cc4_o = np.zeros(m, np.uint32), np.zeros(4, np.uint32)
     oracle.clustercull(cd, 1, commands, synth.count4_for(n), draws, meshlets, mvo, po, cib_o, cc4_o, threads=oracle.max_threads())
     total = int(ccb[0].item())
-    same = ((pyr.data.cpu().numpy() == po.data).all() and total == int(cc4_o[0]) and (cib[:total].cpu().numpy().view(np.uint32) == cib_o[:total]).all()
-            and (mvb.cpu().numpy().view(np.uint32) == mvo).all())
-    return dict(config="4: 4096^2 depth pyramid + 10M-meshlet late clustercull with HiZ", parity=verdict(same), pyramid_us=k_p, pyramid_bytes=pyr_bytes,
+    last = (iters - 1) % copies
+    same = (all((p.data.cpu().numpy() == po.data).all() for p in pyrs) and total == int(cc4_o[0]) and (cib[:total].cpu().numpy().view(np.uint32) == cib_o[:total]).all()
+            and (mvbs[last].cpu().numpy().view(np.uint32) == mvo).all())
+    return dict(config="4: 4096^2 depth pyramid + 10M-meshlet late clustercull with HiZ", input_copies_rotated=copies, parity=verdict(same), pyramid_us=k_p, pyramid_wall_us=wall_p, pyramid_bytes=pyr_bytes,
                 pyramid_GBs=pyr_bytes / k_p / 1e3, pyramid_frac=pyr_bytes / k_p / 1e3 / HBM, texels_per_s=size * size / (k_p * 1e-6),
                 late_cull_us=k_c, late_hiz_us=k_h, late_scatter_us=k_s, late_pass_us=pass_us, late_visible=int(ccb[0].item()),
                 late_algorithmic_bytes=algo, late_frac=algo / k_c / 1e3 / HBM, late_cull_plus_hiz_frac=algo / (k_c + k_h) / 1e3 / HBM,
@@ -574,21 +591,24 @@ def cluster_config(ctx, iters, label, n_draws=156250, cpd=10, aos=False, scene_r
                 meshlets_per_s=m / (wall * 1e-6), parity=verdict(same))
 
 
-def config_task(ctx, iters, n_draws=15625, cpd=10, late=0):
+def config_task(ctx, iters, n_draws=15625, cpd=10, late=0, copies=4):
     """the task-shader form of the cluster cull (meshlet.task.glsl:53-149, nv_taskcull): per command a compacted 64-entry payload
-    + count instead of the global ordered list; config 3A's 10 M meshlets"""
+    + count instead of the global ordered list; config 3A's 10 M meshlets, `copies` meshlet pools rotated (cache-cold)"""
     dev = ctx.device
     draws, meshlets, commands, n = synth.cluster_scene(n_draws, cpd)
     cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, clusterBackfaceEnabled=1)
-    db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
-    ctx.upload_meshlets(mlb, len(meshlets))
+    m = n * 64
+    db = P.to_device(draws, dev)
+    mlb = torch.cat([P.to_device(meshlets, dev) for _ in range(copies)])
+    dcbs = [P.to_device(synth.make_task_commands(n_draws, cpd, meshlet_base=c * m), dev) for c in range(copies)]
+    ctx.upload_meshlets(mlb, copies * m)
     dccb = torch.from_numpy(synth.count4_for(n).view(np.int32).copy()).to(dev)
     ncmd = len(commands)
     payloads = torch.zeros(ncmd * 64, dtype=torch.int32, device=dev)
     counts = torch.zeros(ncmd, dtype=torch.int32, device=dev)
 
     def step(i):
-        ctx.taskcull(cd, late, dcb, dccb, db, mlb, None, None, payloads, counts)
+        ctx.taskcull(cd, late, dcbs[i % copies], dccb, db, mlb, None, None, payloads, counts)
 
     for i in range(3):
         step(i)
@@ -604,9 +624,8 @@ def config_task(ctx, iters, n_draws=15625, cpd=10, late=0):
     oracle.taskcull(cd, late, commands, synth.count4_for(n), draws, meshlets, None, None, po, co)
     cg, pg = counts.cpu().numpy().view(np.uint32), payloads.cpu().numpy().view(np.uint32).reshape(ncmd, 64)
     same = (cg == co).all() and all((pg[i, :co[i]] == po.reshape(ncmd, 64)[i, :co[i]]).all() for i in np.nonzero(co)[0][:20000])
-    m = n * 64
     algo = m * 12 + n * 68 + int(co.sum()) * 4 + ncmd * 4
-    return dict(config="T: task-shader form (nv_taskcull), %d meshlets" % m, visible=int(co.sum()), call_us=us, algorithmic_bytes=algo,
+    return dict(config="T: task-shader form (nv_taskcull), %d meshlets" % m, input_copies_rotated=copies, visible=int(co.sum()), call_us=us, algorithmic_bytes=algo,
                 achieved_GBs=algo / us / 1e3, frac=algo / us / 1e3 / HBM, meshlets_per_s=m / (us * 1e-6), parity=verdict(same))
 
 
