@@ -500,6 +500,10 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 	__shared__ __attribute__((aligned(16))) uint32_t s_meshTable[MESH_LDS ? DC_MESH_LDS * sizeof(NvMesh) / 4 : 4];
 	__shared__ uint32_t s_part[DC_WAVES];
 	__shared__ uint32_t s_sum[DC_WAVES];
+	// TASK: the step's emitting draws in draw order, {first command of the draw relative to the step's first command,
+	// draw within the step | lod << 12 | previous visibility << 15}, + one sentinel (round 3: one LANE per output command)
+	__shared__ uint2 s_emit[TASK ? DC_STEP + 1 : 1];
+	__shared__ uint32_t s_partE[DC_WAVES];
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
@@ -643,80 +647,104 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 			mine += cnt[j];
 		}
 		const uint32_t incl = wave_inclusive_scan(mine, lane);
+		uint32_t mineE = 0, inclE = 0;
+		if (TASK)
+		{
+#pragma unroll
+			for (uint32_t j = 0; j < DC_PER_LANE; ++j)
+				mineE += cnt[j] != 0 ? 1u : 0u;
+			inclE = wave_inclusive_scan(mineE, lane);
+		}
 		__syncthreads(); // s_part free (base reduction / previous step's readers are done)
 		if (lane == 63)
+		{
 			s_part[wave] = incl;
+			if (TASK)
+				s_partE[wave] = inclE;
+		}
 		__syncthreads();
+		const uint32_t stepBase = running; // append index of the step's first command
 		uint32_t dci = running + incl - mine;
+		uint32_t eIdx = inclE - mineE, stepEmitters = 0;
 #pragma unroll
 		for (int w = 0; w < DC_WAVES; ++w)
 		{
 			const uint32_t p = s_part[w];
 			dci += w < (int)wave ? p : 0u;
 			running += p;
+			if (TASK)
+			{
+				const uint32_t pe = s_partE[w];
+				eIdx += w < (int)wave ? pe : 0u;
+				stepEmitters += pe;
+			}
+		}
+
+		if (TASK)
+		{
+			// ---- drawcull.comp.glsl:120-139, one LANE per output command (round 3).  Through round 2 a draw's commands were
+			// written by its owning lane (<= 4 task groups) or wave-cooperatively, one owning draw at a time; with one scatter
+			// workgroup per CU that is one wave per SIMD walking ~25 owners at single-wave latency — 18.5 us for the 175 k commands
+			// of a 1 M-draw frame against 11 us for the decision itself.  Now the step's emitting draws go into an LDS list in draw
+			// order and every output command finds its draw by binary search over the list's (sorted) first-command column: all
+			// lanes busy whatever the draws' sizes, consecutive lanes write consecutive 20-B commands.
+			const uint32_t stepTotal = running - stepBase;
+#pragma unroll
+			for (uint32_t j = 0; j < DC_PER_LANE; ++j)
+			{
+				if (cnt[j])
+				{
+					s_emit[eIdx] = make_uint2(dci - stepBase, (tid * DC_PER_LANE + j) | (res[j] & 7u) << 12 | (res[j] >> 4 & 1u) << 15);
+					++eIdx;
+				}
+				dci += cnt[j];
+			}
+			if (tid == 0)
+				s_emit[stepEmitters] = make_uint2(stepTotal, 0u);
+			__syncthreads();
+			NvMeshTaskCommand* tc = static_cast<NvMeshTaskCommand*>(a.commands);
+			for (uint32_t k = tid; k < stepTotal; k += DC_THREADS)
+			{
+				// largest e with s_emit[e].x <= k (s_emit[0].x == 0; draws emit >= 1 command, so the column is strictly increasing)
+				uint32_t lo = 0, hi = stepEmitters; // invariant: s_emit[lo].x <= k < s_emit[hi].x
+				while (hi - lo > 1u)
+				{
+					const uint32_t mid = (lo + hi) >> 1;
+					if (s_emit[mid].x <= k)
+						lo = mid;
+					else
+						hi = mid;
+				}
+				const uint2 e = s_emit[lo];
+				const uint32_t groups = s_emit[lo + 1u].x - e.x;
+				const uint32_t i = k - e.x;
+				const uint32_t di = first + c0 + (e.y & 0xfffu);
+				const uint32_t lod = e.y >> 12 & 7u;
+				// the draw's meshIndex / meshletVisibilityOffset (8 B of its record; one request per draw and wave) and its LOD's range
+				const uint2 d2 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.draws + di) + 32);
+				const char* mesh = meshBase + (size_t)d2.x * sizeof(NvMesh);
+				const uint32_t meshletOffset = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * lod + 8);
+				const uint32_t meshletCount = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * lod + 12);
+				if (stepBase + e.x + groups <= NV_TASK_WGLIMIT) // drop the whole draw on overflow (:128)
+				{
+					NvMeshTaskCommand cmd;
+					cmd.drawId = di;
+					cmd.taskOffset = meshletOffset + i * NV_TASK_WGSIZE;
+					const uint32_t rest = meshletCount - i * NV_TASK_WGSIZE;
+					cmd.taskCount = rest < NV_TASK_WGSIZE ? rest : NV_TASK_WGSIZE;
+					cmd.lateDrawVisibility = e.y >> 15 & 1u;
+					cmd.meshletVisibilityOffset = d2.y + i * NV_TASK_WGSIZE;
+					tc[stepBase + k] = cmd;
+				}
+			}
+			continue; // (the next step's first barrier orders the list's reuse)
 		}
 
 #pragma unroll
 		for (uint32_t j = 0; j < DC_PER_LANE; ++j)
 		{
 			const uint32_t lodIndex = res[j] & 7u;
-			if (TASK)
-			{
-				// drawcull.comp.glsl:120-139.  Draws with a handful of task groups write their own commands (all lanes
-				// in parallel); larger ones are expanded wave-cooperatively, one owning lane at a time, so that no lane
-				// loops over hundreds of commands while 63 others wait.
-				constexpr uint32_t DC_SMALL = 4;
-				uint64_t owners = __ballot(cnt[j] > DC_SMALL);
-				const uint32_t oldVis = res[j] >> 4 & 1u;
-				NvMeshTaskCommand* tc = static_cast<NvMeshTaskCommand*>(a.commands);
-				if (cnt[j] != 0 && cnt[j] <= DC_SMALL && dci + cnt[j] <= NV_TASK_WGLIMIT) // drop the whole draw on overflow (:128)
-				{
-					const char* mesh = meshBase + (size_t)meshIndex[j] * sizeof(NvMesh);
-					const uint32_t meshletOffset = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * lodIndex + 8);
-					const uint32_t meshletCount = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * lodIndex + 12);
-					for (uint32_t i = 0; i < cnt[j]; ++i)
-					{
-						NvMeshTaskCommand cmd;
-						cmd.drawId = first + c + j;
-						cmd.taskOffset = meshletOffset + i * NV_TASK_WGSIZE;
-						const uint32_t rest = meshletCount - i * NV_TASK_WGSIZE;
-						cmd.taskCount = rest < NV_TASK_WGSIZE ? rest : NV_TASK_WGSIZE;
-						cmd.lateDrawVisibility = oldVis;
-						cmd.meshletVisibilityOffset = mvo[j] + i * NV_TASK_WGSIZE;
-						tc[dci + i] = cmd;
-					}
-				}
-				while (owners)
-				{
-					const int src = __builtin_ctzll(owners);
-					owners &= owners - 1;
-					const uint32_t oDraw = first + c0 + (wave * 64 + src) * DC_PER_LANE + j;
-					const uint32_t oDci = __builtin_amdgcn_readlane(dci, src);
-					const uint32_t oGroups = __builtin_amdgcn_readlane(cnt[j], src);
-					const uint32_t oLod = __builtin_amdgcn_readlane(lodIndex, src);
-					const uint32_t oVis = __builtin_amdgcn_readlane(oldVis, src);
-					const uint32_t oMesh = __builtin_amdgcn_readlane(meshIndex[j], src);
-					const uint32_t oMvo = __builtin_amdgcn_readlane(mvo[j], src);
-					if (oDci + oGroups <= NV_TASK_WGLIMIT) // drop the whole draw on overflow (:128)
-					{
-						const char* mesh = meshBase + (size_t)oMesh * sizeof(NvMesh);
-						const uint32_t meshletOffset = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * oLod + 8);
-						const uint32_t meshletCount = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * oLod + 12);
-						for (uint32_t i = lane; i < oGroups; i += 64)
-						{
-							NvMeshTaskCommand cmd;
-							cmd.drawId = oDraw;
-							cmd.taskOffset = meshletOffset + i * NV_TASK_WGSIZE;
-							uint32_t rest = meshletCount - i * NV_TASK_WGSIZE;
-							cmd.taskCount = rest < NV_TASK_WGSIZE ? rest : NV_TASK_WGSIZE;
-							cmd.lateDrawVisibility = oVis;
-							cmd.meshletVisibilityOffset = oMvo + i * NV_TASK_WGSIZE;
-							tc[oDci + i] = cmd;
-						}
-					}
-				}
-			}
-			else if (cnt[j])
+			if (!TASK && cnt[j])
 			{
 				// drawcull.comp.glsl:141-150
 				const char* mesh = meshBase + (size_t)meshIndex[j] * sizeof(NvMesh);

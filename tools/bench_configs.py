@@ -643,7 +643,7 @@ if __name__ == "__main__":
     ctx = P.Context(0)
     runs = {"2": lambda: config2(ctx, a.iters), "2_aos": lambda: config2(P.Context(0), a.iters, soa=False), "2l": lambda: config2_late(ctx, a.iters), "3b": lambda: config3b(ctx, a.iters), "3b_fused": lambda: config3b(P.Context(0), a.iters, fused=True), "4": lambda: config4(ctx, a.iters),
             "4b": lambda: config4(ctx, a.iters, size=1024), "n4": lambda: config_n4(ctx, a.iters),
-            "frame": lambda: config_frame(P.Context(0), a.iters, cpp_driver=True), "frame_contract": lambda: config_frame(P.Context(0), a.iters, fused=False),
+            "frame": lambda: config_frame(P.Context(0), a.iters, cpp_driver=True), "frame_py": lambda: config_frame(P.Context(0), a.iters), "frame_contract": lambda: config_frame(P.Context(0), a.iters, fused=False),
             "task": lambda: config_task(ctx, a.iters),
             "big": lambda: cluster_config(ctx, max(5, a.iters // 3), "3A x10 (SoA mirror)"),
             "big_aos": lambda: cluster_config(P.Context(0), max(5, a.iters // 3), "3A x10 (AoS in place)", aos=True),
