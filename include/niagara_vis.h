@@ -212,10 +212,6 @@ int nv_profile_read(nv_context* ctx, float out_ms[NV_PROF_SLOTS], uint32_t out_c
  * passes are in flight (10 M meshlets, three passes in flight: 23.3 instead of 24.8 us per pass; a single pass: 31.5
  * instead of 30.1 us).  Speed only. */
 #define NV_OPT_SCATTER_WAVES 4
-/* NV_OPT_RIDING_SCATTER (default 0): when 1, the ordered scatter of an early nv_clustercull pass in its sparse (filter) form runs
- * inside the cull launch — its workgroups wait for the cull workgroups' completion counts instead of for a launch boundary — and
- * the pass is one launch instead of two.  Speed only: the results do not depend on it. */
-#define NV_OPT_RIDING_SCATTER 5
 int nv_set_option(nv_context* ctx, int option, int value);
 
 /* ---- capacities ----

@@ -57,7 +57,6 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 constexpr uint32_t CC_MAX_SCATTER_TILES = 512;
 constexpr uint32_t CC_COUNT_STRIDE = 16; // words between two tile counters
 constexpr uint32_t CC_LISTS = 256;       // sub-lists of the late pass's survivor-command list (cluster_hiz_kernel)
-constexpr uint32_t CC_DONE_SLOTS = 16;   // completion counters of a launch whose scatter rides in the cull launch (cluster_mask_kernel<.., FUSE>)
 struct ClusterCounts
 {
 	uint32_t parity;   // read by the cull kernel; flipped by one thread of the scatter kernel
@@ -68,7 +67,6 @@ struct ClusterCounts
 	uint32_t listOverflow[2]; // late pass with HiZ, banked like `counts`: a sub-list of ClusterArgs::candList ran out of room
 	uint32_t pad2[30];
 	uint32_t listCount[2][CC_LISTS * CC_COUNT_STRIDE]; // entries per sub-list, one counter per 64-byte line
-	uint32_t done[2][CC_DONE_SLOTS * CC_COUNT_STRIDE]; // FUSE: cull workgroups that have finished (workgroup index % CC_DONE_SLOTS), banked like `counts`
 	uint32_t counts[2][CC_MAX_SCATTER_TILES * CC_COUNT_STRIDE];
 };
 
@@ -103,7 +101,6 @@ struct ClusterArgs
 	ClusterCounts* __restrict__ tileCounts;
 	uint32_t scatterTiles; // grid of the scatter kernel (<= CC_MAX_SCATTER_TILES)
 	uint32_t generations;  // workgroups of the cull kernel per CU (its grid = generations x CUs)
-	uint32_t cullBlocks;   // != 0: the scatter rides in the cull launch (FUSE) behind this many cull workgroups
 	uint32_t dealScale;    // percent of the nominal start-delay compensation of the dealing (tuning; 100)
 	float filterK;         // 4 K u S of the conservative filter / certified test (clustercull.hip make_filter); 0 = both off
 	uint32_t* hostHint;    // mapped host word: the cull kernel leaves its command count here for the next launch's tuning

@@ -895,16 +895,16 @@ NV_DEV bool __all_quad_same(uint32_t v, uint32_t ref)
 // of the six resident workgroups per CU.  Returns the number of chunks of this wave; *chunkOf = index of its lane-th
 // chunk, or the plain round-robin when the pass is not weighted (other grid shapes, tiny passes, or more than 64
 // chunks per wave — where a start-up delay of a few commands no longer matters).
-NV_DEV uint32_t make_dealing(uint32_t gridBlocks, uint32_t numChunks, uint32_t wave, uint32_t lane, uint32_t generations, uint32_t gen, bool weighted, uint32_t scalePercent,
+NV_DEV uint32_t make_dealing(uint32_t numChunks, uint32_t wave, uint32_t lane, uint32_t generations, uint32_t gen, bool weighted, uint32_t scalePercent,
                              uint32_t* chunkOf, bool* isWeighted)
 {
-	const uint32_t W = gridBlocks * CC_WAVES; // (the cull workgroups of the launch: a FUSE launch has scatter workgroups behind them)
+	const uint32_t W = gridDim.x * CC_WAVES;
 	const uint32_t w = blockIdx.x * CC_WAVES + wave;
 	*chunkOf = lane * W + w;
 	*isWeighted = false;
 	const uint32_t perWaveChunks = numChunks / W;
 	const uint32_t even = perWaveChunks + (w < numChunks - perWaveChunks * W ? 1u : 0u);
-	if (!weighted || generations != 6u || gridBlocks % 6u != 0u || perWaveChunks < 4u || perWaveChunks >= 60u)
+	if (!weighted || generations != 6u || gridDim.x % 6u != 0u || perWaveChunks < 4u || perWaveChunks >= 60u)
 		return even;
 	const uint32_t genWaves = W / 6u;
 	// delays in 1/16 command: { 0, 0.5, 2.4, 4.2, 7.1, 13.1 }, mean 4.55
@@ -946,54 +946,12 @@ NV_DEV uint32_t make_dealing(uint32_t gridBlocks, uint32_t numChunks, uint32_t w
 // DEFER (late pass with HiZ: the early form, LATE = BITS = false): frustum / cone ballots only, no tile counts — the occlusion
 // stage (cluster_hiz_kernel) finishes the commands that have survivors; the visibility bits of the commands without any are
 // cleared here (clustercull.comp.glsl:125-131 with visible == false), so that the stage touches 3 % of the commands, not all.
-// Words another workgroup of the SAME launch wrote (the riding scatter of cluster_mask_kernel<.., FUSE>, below): read at
-// system scope, i.e. past this XCD's L2 — within a launch the XCDs' L2s are not coherent with each other; the memory side is.
-NV_DEV uint32_t load_through_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-NV_DEV uint64_t load_through_u64(const uint64_t* p)
-{
-	return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-template <int SC_WAVES, bool RIDING>
-NV_DEV void scatter_tile(const ClusterArgs& a, uint32_t tile, uint32_t gridTiles);
-
-// FUSE (round 3; early passes in the filter form): the ordered scatter RIDES in this launch.  The grid is a.cullBlocks cull
-// workgroups followed by a.scatterTiles scatter workgroups (4 waves: what a CU has left next to six cull workgroups).  A
-// cull workgroup stores its ballots write-through, waits for its stores and tile-count adds (s_waitcnt vmcnt(0)), and adds 1
-// to one of CC_DONE_SLOTS completion counters; a scatter workgroup polls the counters (wave 0, system-scope loads), then runs
-// scatter_tile<4, RIDING> on data it reads past the L2.  What that saves is a launch: the boundary (~1 us), the second
-// launch's ramp and its dependent first loads — a third of the 6 us the scatter launch takes behind a 23 us cull launch.
-// The wait cannot deadlock: cull workgroups wait for nothing, and they are dispatched first.  Round 2 tried this with an
-// agent-scope acquire in the waiting workgroups (42 us per pass: the acquire drops the XCD's L2 under the cull kernel's
-// tail) — here nothing is invalidated, the few KB in question are simply read and written at system scope.
-// Only the sparse (filter-form) passes ride: a dense pass has ~600 owning commands per tile, and 4 waves walk them 3x slower
-// than the 16 waves of the separate scatter launch.
-template <bool LATE, bool SOA, bool BITS, int CC_DA, bool DIRECT = false, bool DEFER = false, bool FUSE = false>
+template <bool LATE, bool SOA, bool BITS, int CC_DA, bool DIRECT = false, bool DEFER = false>
 __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs a)
 {
-	static_assert(!FUSE || (!LATE && !DIRECT && !DEFER), "the scatter rides only in early filter-form launches");
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t w = blockIdx.x * CC_WAVES + wave;
-	const uint32_t cullGrid = FUSE ? a.cullBlocks : gridDim.x;
-	if (FUSE && blockIdx.x >= cullGrid)
-	{
-		if (wave == 0)
-		{
-			const uint32_t rbank = load_uniform_u32(&a.tileCounts->parity) & 1u;
-			const uint32_t expected = cullGrid / CC_DONE_SLOTS + (lane < cullGrid % CC_DONE_SLOTS ? 1u : 0u);
-			for (;;)
-			{
-				const uint32_t v = lane < CC_DONE_SLOTS ? load_through_u32(&a.tileCounts->done[rbank][lane * CC_COUNT_STRIDE]) : expected;
-				if (__ballot(v != expected) == 0ull)
-					break;
-				__builtin_amdgcn_s_sleep(2);
-			}
-		}
-		__syncthreads();
-		scatter_tile<CC_WAVES, true>(a, blockIdx.x - cullGrid, gridDim.x - cullGrid);
-		return;
-	}
 
 	// late pass: the pyramid's level offsets in LDS, one copy per wave (written and read by the same wave: no barrier).
 	// Built from the scalar kernel arguments with constant indices — a per-lane index into the argument array would be
@@ -1015,7 +973,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 	// a CU got its first data 11 k cycles after the first one)
 	if (!NV_DBG(a, 262144u)) // bit 18 (experiments)
 		__builtin_amdgcn_s_setprio(3);
-	const uint32_t gen = blockIdx.x / (cullGrid / 6u ? cullGrid / 6u : 1u);
+	const uint32_t gen = blockIdx.x / (gridDim.x / 6u ? gridDim.x / 6u : 1u);
 	const uint32_t numCmds = indirect_command_count(a);
 	if (a.hostHint && blockIdx.x == 0 && threadIdx.x == 0)
 		__hip_atomic_store(a.hostHint, numCmds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1023,7 +981,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 	const uint32_t numChunks = (numCmds + CH - 1) / CH;
 	uint32_t chunkOf;
 	bool dealtWeighted;
-	const uint32_t myChunks = make_dealing(cullGrid, numChunks, wave, lane, a.generations, gen, !LATE && !NV_DBG(a, 32768u), a.dealScale, &chunkOf, &dealtWeighted); // (late pass: even — the weights are calibrated on the early pass, and the extra state costs the late variants two resident workgroups per CU) // bit 15 (experiments): even dealing
+	const uint32_t myChunks = make_dealing(numChunks, wave, lane, a.generations, gen, !LATE && !NV_DBG(a, 32768u), a.dealScale, &chunkOf, &dealtWeighted); // (late pass: even — the weights are calibrated on the early pass, and the extra state costs the late variants two resident workgroups per CU) // bit 15 (experiments): even dealing
 	const uint32_t myCmds = myChunks * CH; // the last chunk of the pass may run past numCmds: guarded below
 	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles);
 	const uint32_t bank = load_uniform_u32(&a.tileCounts->parity) & 1u;
@@ -1048,7 +1006,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 
 		// lane l holds the wave's (seg + l)-th command and (below) the MeshDraw it points at
 		const uint32_t cidx = (seg + lane) / CH;
-		const uint32_t chunk = dealtWeighted ? (uint32_t)__shfl(chunkOf, cidx & 63u, 64) : cidx * (cullGrid * CC_WAVES) + w;
+		const uint32_t chunk = dealtWeighted ? (uint32_t)__shfl(chunkOf, cidx & 63u, 64) : cidx * (gridDim.x * CC_WAVES) + w;
 		const uint32_t myIdx = chunk * CH + (seg + lane) % CH;
 		SegmentRegs r = {};
 		if (lane < cnt && myIdx < numCmds)
@@ -1533,10 +1491,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 		if (lane < cnt && myIdx < numCmds)
 		{
 			const uint64_t m = ((uint64_t)maskHi << 32) | maskLo;
-			if (FUSE) // read by the riding scatter workgroups of this launch: write-through
-				__hip_atomic_store(reinterpret_cast<unsigned long long*>(a.masks + myIdx), m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			else
-				a.masks[myIdx] = m;
+			a.masks[myIdx] = m;
 		}
 		// survivors per scatter tile: fire-and-forget adds.  The four commands of a chunk sit in four neighbouring lanes
 		// and nearly always in one tile: their counts are summed across the quad first (3x fewer atomics).
@@ -1569,14 +1524,6 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 	if (dbgTime && lane == 0)
 		stamps[7] = wall_clock64();
 #undef NV_STAMP
-	if (FUSE)
-	{
-		// this wave's ballots and adds have left for the memory side (vmcnt counts stores and atomics on gfx9) ...
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		__syncthreads(); // ... and so have the other three waves'
-		if (threadIdx.x == 0)
-			__hip_atomic_fetch_add(&a.tileCounts->done[bank][(blockIdx.x % CC_DONE_SLOTS) * CC_COUNT_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-	}
 }
 
 // K2: contiguous ranges, ordered scatter.  Tile t's append base = count word + survivors of tiles < t, which the cull
@@ -1584,11 +1531,8 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 // one scan and the stores.  A step covers 1024 commands: 16 waves with one command per lane (the usual shape: the stores
 // are emitted one owning command at a time per wave, so with one wave per SIMD — 4 waves x 4 commands per lane — a
 // workgroup spent 3.7 of its 8 us walking ~25 owners per wave at single-wave issue latency), or 4 waves with four.
-// One scatter tile.  RIDING = the tile's workgroup is part of the cull launch itself (FUSE): it has waited for the cull
-// workgroups' completion counts, reads their ballots / tile counts with load_through, and derives the bank and the base from
-// the words the cull workgroups derive them from (k2parity / base are messages to a SEPARATE scatter launch).
-template <int SC_WAVES, bool RIDING>
-NV_DEV void scatter_tile(const ClusterArgs& a, const uint32_t tile, const uint32_t gridTiles)
+template <int SC_WAVES>
+__global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterArgs a)
 {
 	constexpr uint32_t SC_THREADS = SC_WAVES * 64;
 	__shared__ uint32_t s_part[SC_WAVES];
@@ -1602,13 +1546,14 @@ NV_DEV void scatter_tile(const ClusterArgs& a, const uint32_t tile, const uint32
 
 	const uint32_t numCmds = indirect_command_count(a);
 	const uint32_t T = scatter_tile_commands(numCmds, a.scatterTiles);
-	const uint32_t numTiles = (numCmds + T - 1) / T; // <= gridTiles
+	const uint32_t numTiles = (numCmds + T - 1) / T; // <= gridDim.x
+	const uint32_t tile = blockIdx.x;
 	const bool dbgNoScatter = NV_DBG(a, 4u); // experiments only
 
-	// Separate launch: everything below was written by the cull kernel, i.e. before this launch: plain loads, all issued
-	// together; both banks of tile counts are read speculatively so that no load waits for the parity word.
-	const uint32_t k2parity = RIDING ? load_uniform_u32(&a.tileCounts->parity) : load_uniform_u32(&a.tileCounts->k2parity);
-	const uint32_t base0 = RIDING ? (a.fusedReset ? 0u : load_uniform_u32(a.clusterCount4)) : load_uniform_u32(&a.tileCounts->base);
+	// Everything below was written by the cull kernel, i.e. before this launch: plain loads, all issued together.
+	// Both banks of tile counts are read speculatively so that no load waits for the parity word.
+	const uint32_t k2parity = load_uniform_u32(&a.tileCounts->k2parity);
+	const uint32_t base0 = load_uniform_u32(&a.tileCounts->base);
 	uint32_t cnt0[TILE_LOADS] = {}, cnt1[TILE_LOADS] = {}; // this thread's tiles tid, tid + SC_THREADS, ..., per bank
 	uint32_t pf0[TILE_LOADS] = {}, pf1[TILE_LOADS] = {};   // likewise the cull kernel's filter statistic (word 1 of the line)
 #pragma unroll
@@ -1617,18 +1562,10 @@ NV_DEV void scatter_tile(const ClusterArgs& a, const uint32_t tile, const uint32
 		const uint32_t i = j * SC_THREADS + tid;
 		if (i < numTiles)
 		{
-			if (RIDING) // (the bank is known: the parity word was written by an earlier launch)
-			{
-				cnt0[j] = cnt1[j] = load_through_u32(&a.tileCounts->counts[k2parity & 1u][i * CC_COUNT_STRIDE]);
-				pf0[j] = pf1[j] = load_through_u32(&a.tileCounts->counts[k2parity & 1u][i * CC_COUNT_STRIDE + 1]);
-			}
-			else
-			{
-				cnt0[j] = a.tileCounts->counts[0][i * CC_COUNT_STRIDE];
-				cnt1[j] = a.tileCounts->counts[1][i * CC_COUNT_STRIDE];
-				pf0[j] = a.tileCounts->counts[0][i * CC_COUNT_STRIDE + 1];
-				pf1[j] = a.tileCounts->counts[1][i * CC_COUNT_STRIDE + 1];
-			}
+			cnt0[j] = a.tileCounts->counts[0][i * CC_COUNT_STRIDE];
+			cnt1[j] = a.tileCounts->counts[1][i * CC_COUNT_STRIDE];
+			pf0[j] = a.tileCounts->counts[0][i * CC_COUNT_STRIDE + 1];
+			pf1[j] = a.tileCounts->counts[1][i * CC_COUNT_STRIDE + 1];
 		}
 	}
 	const uint32_t first = tile * T;
@@ -1636,13 +1573,7 @@ NV_DEV void scatter_tile(const ClusterArgs& a, const uint32_t tile, const uint32
 	// first step's ballots (the only step for the usual T <= 1024); the ballot array is padded, so the 16-B loads of
 	// a partially valid quad stay in range and are masked afterwards
 	uint64_t m4[PER_LANE];
-	if (RIDING)
-	{
-#pragma unroll
-		for (uint32_t j = 0; j < PER_LANE; ++j)
-			m4[j] = tid * PER_LANE + j < n ? load_through_u64(a.masks + first + tid * PER_LANE + j) : 0ull;
-	}
-	else if (PER_LANE == 4)
+	if (PER_LANE == 4)
 	{
 		const uint32_t c = tid * PER_LANE;
 		const ulonglong2* src = reinterpret_cast<const ulonglong2*>(a.masks + first + c);
@@ -1667,14 +1598,12 @@ NV_DEV void scatter_tile(const ClusterArgs& a, const uint32_t tile, const uint32
 	const uint32_t bank = k2parity & 1u;
 	// every workgroup clears its entries of the other bank for the next pass; one thread flips the parity the next
 	// cull kernel will read (this pass reads k2parity only)
-	for (uint32_t i = tile * SC_THREADS + tid; i < CC_MAX_SCATTER_TILES; i += gridTiles * SC_THREADS)
+	for (uint32_t i = tile * SC_THREADS + tid; i < CC_MAX_SCATTER_TILES; i += gridDim.x * SC_THREADS)
 	{
 		a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE] = 0;
 		a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE + 1] = 0;
 		if (i < CC_LISTS)
 			a.tileCounts->listCount[bank ^ 1u][i * CC_COUNT_STRIDE] = 0;
-		if (i < CC_DONE_SLOTS)
-			a.tileCounts->done[bank ^ 1u][i * CC_COUNT_STRIDE] = 0; // (completion counts of a FUSE launch)
 	}
 	if (tile == 0 && tid == 0)
 	{
@@ -1781,7 +1710,7 @@ NV_DEV void scatter_tile(const ClusterArgs& a, const uint32_t tile, const uint32
 			const uint32_t c = c0 + tid * PER_LANE;
 #pragma unroll
 			for (uint32_t j = 0; j < PER_LANE; ++j)
-				m4[j] = c + j < n ? (RIDING ? load_through_u64(a.masks + first + c + j) : a.masks[first + c + j]) : 0ull;
+				m4[j] = c + j < n ? a.masks[first + c + j] : 0ull;
 		}
 		uint32_t pc[PER_LANE], mine = 0;
 #pragma unroll
@@ -1834,12 +1763,6 @@ NV_DEV void scatter_tile(const ClusterArgs& a, const uint32_t tile, const uint32
 			excl += pc[j];
 		}
 	}
-}
-
-template <int SC_WAVES>
-__global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterArgs a)
-{
-	scatter_tile<SC_WAVES, false>(a, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2272,18 +2195,6 @@ template <bool LATE, bool SOA, int DEPTH, bool DIRECT = false>
 static void launch_cc(hipStream_t stream, const ClusterArgs& a, uint32_t gridBlocks)
 {
 	dim3 grid(gridBlocks), block(CC_THREADS);
-	if (a.cullBlocks) // FUSE: the scatter workgroups ride behind the cull workgroups (context.hip asks for it only where a variant exists)
-	{
-		if constexpr (!LATE && !DIRECT)
-		{
-			const dim3 fgrid(a.cullBlocks + a.scatterTiles);
-			if (a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0)
-				hipLaunchKernelGGL((cluster_mask_kernel<false, SOA, true, DEPTH, false, false, true>), fgrid, block, 0, stream, a);
-			else
-				hipLaunchKernelGGL((cluster_mask_kernel<false, SOA, false, DEPTH, false, false, true>), fgrid, block, 0, stream, a);
-			return;
-		}
-	}
 	if (!LATE && a.deferHiz)
 		hipLaunchKernelGGL((cluster_mask_kernel<false, SOA, false, DEPTH, DIRECT, true>), grid, block, 0, stream, a);
 	else if (a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0)

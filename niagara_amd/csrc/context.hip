@@ -101,7 +101,6 @@ struct nv_context
 	uint32_t dealScale;
 	uint32_t scatterTilesPerCU;
 	uint32_t scatterWaves; // NV_OPT_SCATTER_WAVES: waves per workgroup of the cluster scatter launch (16; 4 / 8)
-	uint32_t ridingScatter; // NV_OPT_RIDING_SCATTER
 	uint32_t scatterTilesAbs; // experiments: absolute number of scatter tiles (0 = per CU)
 	uint32_t hizLds; // stage the coarse pyramid levels in LDS for drawcull's late pass (experiments: measured slower)
 	uint32_t directPercent; // share of commands passing the filter above which the next launch skips the filter pass
@@ -290,8 +289,6 @@ int nv_create(nv_context** out_ctx, int device)
 	ctx->listSharers = 4;
 	ctx->listMinPer = 8;
 #ifdef NV_EXPERIMENTS
-	if (const char* v = getenv("NV_RIDING_SCATTER"))
-		ctx->ridingScatter = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_PYRAMID_MODE"))
 		ctx->pyramidMode = atoi(v);
 	if (const char* v = getenv("NV_HIZ_LDS"))
@@ -407,9 +404,6 @@ int nv_set_option(nv_context* ctx, int option, int value)
 		if (value != 4 && value != 8 && value != 16)
 			return NV_EINVAL;
 		ctx->scatterWaves = (uint32_t)value;
-		return NV_OK;
-	case NV_OPT_RIDING_SCATTER:
-		ctx->ridingScatter = value ? 1u : 0u;
 		return NV_OK;
 	case NV_OPT_CULL_WORKGROUPS_PER_CU:
 		if (value < 1 || value > 8)
@@ -763,9 +757,6 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	// with one lane per survivor (clustercull.hip cluster_hiz_kernel: visibility bits, skip, tile counts), the scatter.
 	const bool twoStage = late && cull->clusterOcclusionEnabled == 1 && !(ctx->debugMode & 2097152u); // bit 21 (experiments): the probe inside the cull kernel (r1 form)
 	a.deferHiz = twoStage ? 1u : 0u;
-	// NV_OPT_RIDING_SCATTER: the scatter workgroups ride in the cull launch (early passes in the filter form: see clustercull.hip)
-	const bool riding = ctx->ridingScatter && !late && !twoStage && !(direct && a.soaBounds && a.filterK > 0.0f) && !(ctx->debugMode & 16u);
-	a.cullBlocks = riding ? persistent_grid(ctx, ctx->ccBlocksPerCU) : 0u;
 	rc = nv::launch_cluster_mask(s, a, twoStage ? 0 : late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), shallow, direct);
 	hipEvent_t e1 = prof_mark(ctx, s);
 	hipEvent_t eh = e1;
@@ -775,7 +766,7 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 		rc = nv::launch_cluster_hiz(s, a, a.soaBounds != nullptr, blocks);
 		eh = prof_mark(ctx, s);
 	}
-	if (rc == 0 && !riding && !(ctx->debugMode & 16u)) // bit 4 (experiments): ballots only
+	if (rc == 0 && !(ctx->debugMode & 16u)) // bit 4 (experiments): ballots only
 		rc = nv::launch_cluster_scatter(s, a, a.scatterTiles, ctx->scatterWaves);
 	hipEvent_t e2 = prof_mark(ctx, s);
 	prof_push(ctx, NV_PROF_CLUSTER_CULL, e0, e1);

@@ -39,7 +39,6 @@ NV_OPT_FUSED_COUNT_RESET = 1
 NV_OPT_FUSED_SUBMIT = 2
 NV_OPT_CULL_WORKGROUPS_PER_CU = 3
 NV_OPT_SCATTER_WAVES = 4
-NV_OPT_RIDING_SCATTER = 5
 
 
 class Context:
