@@ -38,8 +38,7 @@ int launch_cluster_expand(hipStream_t, const NvMeshTaskCommand*, const NvMeshlet
                           NvClusterRecord* records, uint32_t capacity, uint64_t* totals, unsigned long long* partials, uint32_t gridBlocks);
 int launch_clustersubmit(hipStream_t, uint32_t* cc4, uint32_t* clusterIndices);
 int launch_pack_counts(hipStream_t, const uint32_t*, const uint32_t*, const uint32_t*, uint64_t*);
-int launch_depthreduce(hipStream_t, const float* depth, uint32_t w, uint32_t h, const NvPyramidDesc& pyr, uint32_t* scratch, uint32_t scratchWords, int mode);
-uint32_t depthreduce_scratch_words();
+int launch_depthreduce(hipStream_t, const float* depth, uint32_t w, uint32_t h, const NvPyramidDesc& pyr);
 int launch_trianglecull(hipStream_t, const TriangleArgs& a, uint32_t gridBlocks);
 int launch_meshlet_bounds(hipStream_t, const NvVertex* vertices, const uint32_t* data, NvMeshlet* meshlets, uint32_t count, float* out8, uint32_t gridBlocks);
 
@@ -91,8 +90,6 @@ struct nv_context
 	size_t drawResultsCapacity;
 	nv::ClusterCounts* drawTileCounts;
 	unsigned long long* totalsPartials; // nv_trianglecull / nv_cluster_expand: per-workgroup partial totals (3 x u64 x grid)
-	uint32_t* pyramidFlags; // nv_depthreduce: epoch word + one flag per first-stage workgroup (depthreduce.hip, the in-launch tail)
-	int pyramidMode;        // 0 = tail levels inside the first launch where possible; 1 = always a launch per stage (experiments)
 	nv_scene* scene; // mirrors + registrations (shared between contexts by nv_share_scene)
 	// launch shape of the cull kernel (workgroups per CU) and the dealing's start-delay compensation in percent; constants
 	// in the product, environment-tunable (with the NV_DEBUG_MODE bit mask) only in the NV_EXPERIMENTS build
@@ -289,8 +286,6 @@ int nv_create(nv_context** out_ctx, int device)
 	ctx->listSharers = 4;
 	ctx->listMinPer = 8;
 #ifdef NV_EXPERIMENTS
-	if (const char* v = getenv("NV_PYRAMID_MODE"))
-		ctx->pyramidMode = atoi(v);
 	if (const char* v = getenv("NV_HIZ_LDS"))
 		ctx->hizLds = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_DIRECT"))
@@ -321,9 +316,7 @@ int nv_create(nv_context** out_ctx, int device)
 	    hipMemset(ctx->tileCounts, 0, sizeof(nv::ClusterCounts)) != hipSuccess ||
 	    hipMalloc(&ctx->drawTileCounts, sizeof(nv::ClusterCounts)) != hipSuccess ||
 	    hipMemset(ctx->drawTileCounts, 0, sizeof(nv::ClusterCounts)) != hipSuccess || reserve_draw_results(ctx, 1u << 20) != NV_OK ||
-	    hipMalloc(&ctx->totalsPartials, (size_t)persistent_grid(ctx, 8) * 3 * sizeof(unsigned long long)) != hipSuccess ||
-	    hipMalloc(&ctx->pyramidFlags, (size_t)nv::depthreduce_scratch_words() * sizeof(uint32_t)) != hipSuccess ||
-	    hipMemset(ctx->pyramidFlags, 0, (size_t)nv::depthreduce_scratch_words() * sizeof(uint32_t)) != hipSuccess)
+	    hipMalloc(&ctx->totalsPartials, (size_t)persistent_grid(ctx, 8) * 3 * sizeof(unsigned long long)) != hipSuccess)
 	{
 		nv_destroy(ctx);
 		return NV_ENOMEM;
@@ -362,8 +355,6 @@ void nv_destroy(nv_context* ctx)
 		(void)hipFree(ctx->drawTileCounts);
 	if (ctx->totalsPartials)
 		(void)hipFree(ctx->totalsPartials);
-	if (ctx->pyramidFlags)
-		(void)hipFree(ctx->pyramidFlags);
 	if (ctx->masks)
 		(void)hipFree(ctx->masks);
 	if (ctx->tileCounts)
@@ -859,7 +850,7 @@ int nv_depthreduce(nv_context* ctx, void* stream, const float* d_depth, uint32_t
 		return NV_EINVAL;
 	DeviceGuard guard(ctx->device);
 	hipEvent_t e0 = prof_mark(ctx, (hipStream_t)stream);
-	int rc = nv::launch_depthreduce((hipStream_t)stream, d_depth, width, height, *pyramid, ctx->pyramidFlags, nv::depthreduce_scratch_words(), ctx->pyramidMode);
+	int rc = nv::launch_depthreduce((hipStream_t)stream, d_depth, width, height, *pyramid);
 	prof_push(ctx, NV_PROF_DEPTHREDUCE, e0, prof_mark(ctx, (hipStream_t)stream));
 	return rc;
 }

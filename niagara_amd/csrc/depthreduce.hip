@@ -12,7 +12,6 @@
 // Level 0 from a depth target that is not exactly 2x the pyramid (e.g. 1024x768 -> 512x512) goes through the
 // generic sampler kernel first.
 #include "cullmath.h"
-#include "args.h"
 
 namespace nv
 {
@@ -45,34 +44,19 @@ struct ChainArgs
 // be bit-identical for those too (tests/test_special_values.py)
 NV_DEV float min4(float a, float b, float c, float d) { return gl_min(gl_min(gl_min(a, b), c), d); }
 
-// Loads that see what OTHER workgroups of the SAME launch stored with store_through(): system scope, i.e. past the XCD's L2
-// (which is not coherent with the other XCDs' L2s inside a launch) to the memory side.  Relaxed atomics, so that hipcc emits
-// the sc0 sc1 forms and counts its own waits: all of a lane's loads are in flight together.
-NV_DEV float2 load_through2(const float* p)
+__global__ __launch_bounds__(256) void reduce_chain_kernel(ChainArgs a)
 {
-	const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-	return make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
-}
-NV_DEV float load_through(const float* p)
-{
-	return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-}
-NV_DEV void store_through(float* p, float v)
-{
-	__hip_atomic_store(reinterpret_cast<uint32_t*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
+	__shared__ float s_l2[16][17];
+	__shared__ float s_l3[8][9];
+	__shared__ float s_l4[4][5];
+	__shared__ float s_l5[2][3];
 
-// One 128 x 128 source tile -> up to seven levels.
-NV_DEV void chain_finish(const ChainArgs& a, uint32_t L, uint32_t numLevels, uint32_t bx, uint32_t by, float t2);
-
-NV_DEV void chain_tile(const ChainArgs& a, const uint32_t bx, const uint32_t by)
-{
 	const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
 	const uint32_t L = a.firstLevel;
 
 	// ---- 8x8 source patch -> registers
-	const uint32_t sx = (bx * 64 + tx * 4) * 2;
-	const uint32_t sy = (by * 64 + ty * 4) * 2;
+	const uint32_t sx = (blockIdx.x * 64 + tx * 4) * 2;
+	const uint32_t sy = (blockIdx.y * 64 + ty * 4) * 2;
 	float p[8][8];
 	if (sx + 7 < a.sw && sy + 7 < a.sh)
 	{
@@ -110,7 +94,7 @@ NV_DEV void chain_tile(const ChainArgs& a, const uint32_t bx, const uint32_t by)
 			q[r][c] = min4(p[2 * r][2 * c], p[2 * r][2 * c + 1], p[2 * r + 1][2 * c], p[2 * r + 1][2 * c + 1]);
 	{
 		const uint32_t lw = mip_dim(a.pw, L), lh = mip_dim(a.ph, L);
-		const uint32_t x0 = bx * 64 + tx * 4, y0 = by * 64 + ty * 4;
+		const uint32_t x0 = blockIdx.x * 64 + tx * 4, y0 = blockIdx.y * 64 + ty * 4;
 		float* dst = a.base + a.mipOffset[L];
 		if (x0 + 3 < lw && y0 + 3 < lh)
 		{
@@ -140,7 +124,7 @@ NV_DEV void chain_tile(const ChainArgs& a, const uint32_t bx, const uint32_t by)
 			h[r][c] = min4(q[2 * r][2 * c], q[2 * r][2 * c + 1], q[2 * r + 1][2 * c], q[2 * r + 1][2 * c + 1]);
 	{
 		const uint32_t lw = mip_dim(a.pw, L + 1), lh = mip_dim(a.ph, L + 1);
-		const uint32_t x0 = bx * 32 + tx * 2, y0 = by * 32 + ty * 2;
+		const uint32_t x0 = blockIdx.x * 32 + tx * 2, y0 = blockIdx.y * 32 + ty * 2;
 		float* dst = a.base + a.mipOffset[L + 1];
 		if (x0 + 1 < lw && y0 + 1 < lh)
 		{
@@ -164,37 +148,27 @@ NV_DEV void chain_tile(const ChainArgs& a, const uint32_t bx, const uint32_t by)
 	const float t2 = min4(h[0][0], h[0][1], h[1][0], h[1][1]);
 	{
 		const uint32_t lw = mip_dim(a.pw, L + 2), lh = mip_dim(a.ph, L + 2);
-		const uint32_t x = bx * 16 + tx, y = by * 16 + ty;
+		const uint32_t x = blockIdx.x * 16 + tx, y = blockIdx.y * 16 + ty;
 		if (x < lw && y < lh)
 			a.base[a.mipOffset[L + 2] + (size_t)y * lw + x] = t2;
 	}
-	chain_finish(a, a.firstLevel, a.numLevels, bx, by, t2);
-}
-
-// levels L+3 .. L+6 of a tile from its 16 x 16 texels of level L+2 (one per lane), through LDS: 8x8, 4x4, 2x2, 1x1 per workgroup
-NV_DEV void chain_finish(const ChainArgs& a, const uint32_t L, const uint32_t numLevels, const uint32_t bx, const uint32_t by, const float t2)
-{
-	__shared__ float s_l2[16][17];
-	__shared__ float s_l3[8][9];
-	__shared__ float s_l4[4][5];
-	__shared__ float s_l5[2][3];
-	const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
-	if (numLevels < 4)
+	if (a.numLevels < 4)
 		return;
 	s_l2[ty][tx] = t2;
 	__syncthreads();
 
+	// ---- levels L+3 .. L+6 from LDS (8x8, 4x4, 2x2, 1x1 per workgroup)
 	if (threadIdx.x < 64)
 	{
 		const uint32_t x = threadIdx.x & 7u, y = threadIdx.x >> 3;
 		const float t = min4(s_l2[2 * y][2 * x], s_l2[2 * y][2 * x + 1], s_l2[2 * y + 1][2 * x], s_l2[2 * y + 1][2 * x + 1]);
 		s_l3[y][x] = t;
 		const uint32_t lw = mip_dim(a.pw, L + 3), lh = mip_dim(a.ph, L + 3);
-		const uint32_t gx = bx * 8 + x, gy = by * 8 + y;
+		const uint32_t gx = blockIdx.x * 8 + x, gy = blockIdx.y * 8 + y;
 		if (gx < lw && gy < lh)
 			a.base[a.mipOffset[L + 3] + (size_t)gy * lw + gx] = t;
 	}
-	if (numLevels < 5)
+	if (a.numLevels < 5)
 		return;
 	__syncthreads();
 	if (threadIdx.x < 16)
@@ -203,11 +177,11 @@ NV_DEV void chain_finish(const ChainArgs& a, const uint32_t L, const uint32_t nu
 		const float t = min4(s_l3[2 * y][2 * x], s_l3[2 * y][2 * x + 1], s_l3[2 * y + 1][2 * x], s_l3[2 * y + 1][2 * x + 1]);
 		s_l4[y][x] = t;
 		const uint32_t lw = mip_dim(a.pw, L + 4), lh = mip_dim(a.ph, L + 4);
-		const uint32_t gx = bx * 4 + x, gy = by * 4 + y;
+		const uint32_t gx = blockIdx.x * 4 + x, gy = blockIdx.y * 4 + y;
 		if (gx < lw && gy < lh)
 			a.base[a.mipOffset[L + 4] + (size_t)gy * lw + gx] = t;
 	}
-	if (numLevels < 6)
+	if (a.numLevels < 6)
 		return;
 	__syncthreads();
 	if (threadIdx.x < 4)
@@ -216,95 +190,20 @@ NV_DEV void chain_finish(const ChainArgs& a, const uint32_t L, const uint32_t nu
 		const float t = min4(s_l4[2 * y][2 * x], s_l4[2 * y][2 * x + 1], s_l4[2 * y + 1][2 * x], s_l4[2 * y + 1][2 * x + 1]);
 		s_l5[y][x] = t;
 		const uint32_t lw = mip_dim(a.pw, L + 5), lh = mip_dim(a.ph, L + 5);
-		const uint32_t gx = bx * 2 + x, gy = by * 2 + y;
+		const uint32_t gx = blockIdx.x * 2 + x, gy = blockIdx.y * 2 + y;
 		if (gx < lw && gy < lh)
 			a.base[a.mipOffset[L + 5] + (size_t)gy * lw + gx] = t;
 	}
-	if (numLevels < 7)
+	if (a.numLevels < 7)
 		return;
 	__syncthreads();
 	if (threadIdx.x == 0)
 	{
 		const float t = min4(s_l5[0][0], s_l5[0][1], s_l5[1][0], s_l5[1][1]);
 		const uint32_t lw = mip_dim(a.pw, L + 6), lh = mip_dim(a.ph, L + 6);
-		if (bx < lw && by < lh)
-			a.base[a.mipOffset[L + 6] + (size_t)by * lw + bx] = t;
+		if (blockIdx.x < lw && blockIdx.y < lh)
+			a.base[a.mipOffset[L + 6] + (size_t)blockIdx.y * lw + blockIdx.x] = t;
 	}
-}
-
-// The tail workgroup's version of chain_tile: its source (<= 128 x 128, level L - 1) was written by the other
-// workgroups of this launch, so it is read with load_through; and it must fit the producers' register budget (the launch's
-// VGPR count is the maximum over both paths, and the producers stream best at 8 waves per SIMD = 64 VGPRs), so a lane walks
-// its 8 x 8 patch as four 4 x 4 sub-patches — 2 x 2 texels of level L and one of level L+1 each — instead of holding 64
-// texels.  Same 2 x 2 footprints in the same texel order, hence the same bits.
-NV_DEV void tail_tile(const ChainArgs& a, const uint32_t L, const uint32_t numLevels, const float* src, const uint32_t sw, const uint32_t sh)
-{
-	const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
-	const uint32_t lw0 = mip_dim(a.pw, L), lh0 = mip_dim(a.ph, L);
-	const uint32_t lw1 = mip_dim(a.pw, L + 1), lh1 = mip_dim(a.ph, L + 1);
-	// Two sub-patches (32 texels) in flight at a time, two round trips in all: the loads are relaxed atomics, which hipcc keeps in
-	// program order, so the order written here is the order issued.  Branch-free: clamp-to-edge addresses (duplicates do not
-	// change a min; only lanes outside a source smaller than 128 x 128 clamp at all).
-	auto fetch = [&](float (&p)[4][4], const int sub)
-	{
-		const uint32_t sx = tx * 8 + (sub & 1) * 4, sy = ty * 8 + (sub >> 1) * 4;
-#pragma unroll
-		for (int r = 0; r < 4; ++r)
-		{
-			const uint32_t yy = sy + r < sh ? sy + r : sh - 1;
-#pragma unroll
-			for (int c = 0; c < 4; ++c)
-			{
-				const uint32_t xx = sx + c < sw ? sx + c : sw - 1;
-				p[r][c] = load_through(src + (size_t)yy * sw + xx);
-			}
-		}
-	};
-	float t2 = 0.0f;
-	auto reduce = [&](const float (&p)[4][4], const int sub)
-	{
-		float q[2][2];
-#pragma unroll
-		for (int r = 0; r < 2; ++r)
-#pragma unroll
-			for (int c = 0; c < 2; ++c)
-			{
-				q[r][c] = min4(p[2 * r][2 * c], p[2 * r][2 * c + 1], p[2 * r + 1][2 * c], p[2 * r + 1][2 * c + 1]);
-				const uint32_t x = tx * 4 + (sub & 1) * 2 + c, y = ty * 4 + (sub >> 1) * 2 + r;
-				if (x < lw0 && y < lh0)
-					a.base[a.mipOffset[L] + (size_t)y * lw0 + x] = q[r][c];
-			}
-		const float h = min4(q[0][0], q[0][1], q[1][0], q[1][1]);
-		if (numLevels >= 2)
-		{
-			const uint32_t x = tx * 2 + (sub & 1), y = ty * 2 + (sub >> 1);
-			if (x < lw1 && y < lh1)
-				a.base[a.mipOffset[L + 1] + (size_t)y * lw1 + x] = h;
-		}
-		t2 = sub == 0 ? h : gl_min(t2, h); // min4(h0, h1, h2, h3) is this chain
-	};
-	float pa[4][4], pb[4][4];
-	fetch(pa, 0);
-	fetch(pb, 1);
-	reduce(pa, 0);
-	reduce(pb, 1);
-	fetch(pa, 2); // (interleaving these with the reductions above needs more than the 64 VGPRs the producers leave)
-	fetch(pb, 3);
-	reduce(pa, 2);
-	reduce(pb, 3);
-	if (numLevels < 3)
-		return;
-	{
-		const uint32_t lw = mip_dim(a.pw, L + 2), lh = mip_dim(a.ph, L + 2);
-		if (tx < lw && ty < lh)
-			a.base[a.mipOffset[L + 2] + (size_t)ty * lw + tx] = t2;
-	}
-	chain_finish(a, L, numLevels, 0, 0, t2);
-}
-
-__global__ __launch_bounds__(256) void reduce_chain_kernel(ChainArgs a)
-{
-	chain_tile(a, blockIdx.x, blockIdx.y);
 }
 
 
@@ -312,60 +211,14 @@ __global__ __launch_bounds__(256) void reduce_chain_kernel(ChainArgs a)
 // one 16-B load per lane and row (1 KiB contiguous per wave-instruction), and reduces 4 x 8 -> 2 x 4 -> 1 x 2 in
 // registers; level +2 pairs neighbouring lanes with a DPP shuffle, levels +3 and +4 pair the workgroup's four waves
 // (32 source rows) through 512 B of LDS.  Five levels per launch, every store a contiguous run.
-//
-// TAIL (round 3): the remaining levels in the SAME launch.  A second launch for them — one workgroup, 64 KiB in, 22 KiB
-// out — took 9.4 us of the pyramid's 25.8: a dependent launch with a cold load is launch + two memory round trips + drain,
-// whatever it computes.  Here the grid has ONE extra workgroup, the last one (index nx * ny): every producer stores its 8
-// texels of level +4 write-through (store_through: past its XCD's L2), waits for those stores, and raises its flag; the
-// tail workgroup polls the nx * ny flags (load_through), then runs the 128 x 128 chain on level +4 read the same way.
-// It is the only wait in the library, and it cannot deadlock: the tail waits for producers, producers wait for nothing,
-// and the dispatcher hands workgroups out in index order, so every producer holds its slot before the tail gets one.
-// Flags carry the launch's epoch (a device word the tail advances), so nothing is reset between launches and a captured
-// graph replays.  Measured in round 2 without this structure (tickets / fences): each agent-scope release fence writes
-// back the whole L2 (224 us), 2048 returning atomics on one line serialise (45 us) — hence plain write-through stores and
-// one flag word per producer, no atomics, no fences.
-struct TailArgs
-{
-	uint32_t* epoch; // scratch[0]
-	uint32_t* flags; // one per producer workgroup
-	uint32_t nx, ny; // producer grid
-};
-
-template <bool TAIL>
-__global__ __launch_bounds__(256, 8) void reduce_rows_kernel(ChainArgs a, TailArgs t)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(ChainArgs a)
 {
 	__shared__ float s_l2[4][32];
 
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint32_t L = a.firstLevel;
-	uint32_t bx = blockIdx.x, by = blockIdx.y;
-	uint32_t want = 0;
-	if (TAIL)
-	{
-		want = load_uniform_u32(t.epoch) + 1u;
-		bx = blockIdx.x % t.nx;
-		by = blockIdx.x / t.nx;
-		if (blockIdx.x == t.nx * t.ny)
-		{
-			// ---- the tail workgroup: wait for every producer's flag, then levels L+5 .. from level L+4
-			const uint32_t producers = t.nx * t.ny;
-			for (;;)
-			{
-				int ok = 1;
-				for (uint32_t i = threadIdx.x; i < producers; i += 256u)
-					ok &= __hip_atomic_load(t.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == want;
-				if (__syncthreads_and(ok))
-					break;
-				__builtin_amdgcn_s_sleep(4);
-			}
-			tail_tile(a, L + 5, a.numLevels - 5, a.base + a.mipOffset[L + 4], mip_dim(a.pw, L + 4), mip_dim(a.ph, L + 4));
-			if (threadIdx.x == 0)
-				*t.epoch = want; // read by the next launch (kernel boundary)
-			return;
-		}
-	}
-	const uint32_t col0 = bx * 256u + lane * 4u; // source column of this lane
-	const uint32_t row0 = by * 32u + wave * 8u;  // first source row of this wave
+	const uint32_t col0 = blockIdx.x * 256u + lane * 4u; // source column of this lane
+	const uint32_t row0 = blockIdx.y * 32u + wave * 8u;  // first source row of this wave
 
 	float4 v[8];
 #pragma unroll
@@ -387,7 +240,7 @@ __global__ __launch_bounds__(256, 8) void reduce_rows_kernel(ChainArgs a, TailAr
 		for (int i = 0; i < 4; ++i)
 			*reinterpret_cast<float2*>(dst + (size_t)i * lw) = make_float2(q[i][0], q[i][1]);
 	}
-	if (!TAIL && a.numLevels < 2)
+	if (a.numLevels < 2)
 		return;
 
 	// level L+1: 1 x 2 per lane
@@ -400,18 +253,18 @@ __global__ __launch_bounds__(256, 8) void reduce_rows_kernel(ChainArgs a, TailAr
 		dst[0] = h[0];
 		dst[lw] = h[1];
 	}
-	if (!TAIL && a.numLevels < 3)
+	if (a.numLevels < 3)
 		return;
 
 	// level L+2: lane pairs; (x0,y0) = even lane's h[0], (x1,y0) = odd lane's h[0], (x0,y1) = even h[1], (x1,y1) = odd h[1]
-	const float t2 = min4(h[0], __shfl_xor(h[0], 1, 64), h[1], __shfl_xor(h[1], 1, 64)); // meaningful on even lanes
+	const float t = min4(h[0], __shfl_xor(h[0], 1, 64), h[1], __shfl_xor(h[1], 1, 64)); // meaningful on even lanes
 	if ((lane & 1u) == 0)
 	{
 		const uint32_t lw = a.sw / 8;
-		a.base[a.mipOffset[L + 2] + (size_t)(row0 / 8) * lw + col0 / 8] = t2;
-		s_l2[wave][lane >> 1] = t2;
+		a.base[a.mipOffset[L + 2] + (size_t)(row0 / 8) * lw + col0 / 8] = t;
+		s_l2[wave][lane >> 1] = t;
 	}
-	if (!TAIL && a.numLevels < 4)
+	if (a.numLevels < 4)
 		return;
 	__syncthreads();
 
@@ -422,37 +275,23 @@ __global__ __launch_bounds__(256, 8) void reduce_rows_kernel(ChainArgs a, TailAr
 		float m = min4(s_l2[2 * y][2 * x], s_l2[2 * y][2 * x + 1], s_l2[2 * y + 1][2 * x], s_l2[2 * y + 1][2 * x + 1]);
 		{
 			const uint32_t lw = a.sw / 16;
-			a.base[a.mipOffset[L + 3] + (size_t)(by * 2 + y) * lw + bx * 16 + x] = m;
+			a.base[a.mipOffset[L + 3] + (size_t)(blockIdx.y * 2 + y) * lw + blockIdx.x * 16 + x] = m;
 		}
-		if (TAIL || a.numLevels >= 5)
+		if (a.numLevels >= 5)
 		{
 			m = min4(m, __shfl_xor(m, 1, 64), __shfl_xor(m, 16, 64), __shfl_xor(m, 17, 64)); // meaningful on lanes y == 0, x even
 			if (y == 0 && (x & 1u) == 0)
 			{
 				const uint32_t lw = a.sw / 32;
-				float* dst = a.base + a.mipOffset[L + 4] + (size_t)by * lw + bx * 8 + x / 2;
-				if (TAIL)
-					store_through(dst, m);
-				else
-					*dst = m;
+				a.base[a.mipOffset[L + 4] + (size_t)blockIdx.y * lw + blockIdx.x * 8 + x / 2] = m;
 			}
 		}
 	}
-	if (TAIL && wave == 0)
-	{
-		// the wave's level-(L+4) stores have left for the memory side before the flag does (vmcnt counts stores on gfx9)
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		if (lane == 0)
-			__hip_atomic_store(t.flags + (by * t.nx + bx), want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-	}
 }
-
-// words of the flag scratch launch_depthreduce wants (16 for the epoch's line + one flag per producer: 16 384 cover an 8192 x 8192 target)
-uint32_t depthreduce_scratch_words() { return 16u + 16384u; }
 
 static bool halves(uint32_t s, uint32_t d) { return s == 2 * d || (s == 1 && d == 1); }
 
-int launch_depthreduce(hipStream_t stream, const float* depth, uint32_t w, uint32_t h, const NvPyramidDesc& pyr, uint32_t* scratch, uint32_t scratchWords, int mode)
+int launch_depthreduce(hipStream_t stream, const float* depth, uint32_t w, uint32_t h, const NvPyramidDesc& pyr)
 {
 	const float* src = depth;
 	uint32_t sw = w, sh = h;
@@ -487,25 +326,10 @@ int launch_depthreduce(hipStream_t stream, const float* depth, uint32_t w, uint3
 		// big sources: row-coalesced five-level stage (needs whole 256 x 32 source tiles and exact halving down to its
 		// last level); everything else: the seven-level 128 x 128 tile chain
 		const bool rows = sw % 256 == 0 && sh % 32 == 0 && sw == 2 * lw && sh == 2 * lh && sw >= 512 && sh >= 64 && pyr.levels - L >= 5;
-		// ... and the rest of the chain from the same launch when it is one 128 x 128 tile's worth (levels L+5 ..: <= 7 of them)
-		const uint32_t nx = sw / 256, ny = sh / 32;
-		const bool tail = rows && mode != 1 && scratch && (uint64_t)nx * ny + 16 <= scratchWords && pyr.levels - L > 5 && pyr.levels - L <= 12 &&
-		                  (pyr.width >> (L + 4)) <= 128 && (pyr.height >> (L + 4)) <= 128;
-		if (tail)
-		{
-			TailArgs t;
-			t.epoch = scratch;
-			t.flags = scratch + 16;
-			t.nx = nx;
-			t.ny = ny;
-			a.numLevels = pyr.levels - L;
-			hipLaunchKernelGGL(reduce_rows_kernel<true>, dim3(nx * ny + 1), dim3(256), 0, stream, a, t);
-		}
-		else if (rows)
+		if (rows)
 		{
 			a.numLevels = 5;
-			TailArgs t = {};
-			hipLaunchKernelGGL(reduce_rows_kernel<false>, dim3(nx, ny), dim3(256), 0, stream, a, t);
+			hipLaunchKernelGGL(reduce_rows_kernel, dim3(sw / 256, sh / 32), dim3(256), 0, stream, a);
 		}
 		else
 		{
