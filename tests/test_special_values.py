@@ -114,6 +114,50 @@ def test_hip_equals_oracle_on_special_values(seed, late, soa, post_pass):
         ctx.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("soa", [True, False])
+@pytest.mark.parametrize("bits", [0, 1])
+def test_taskcull_hip_equals_oracle_on_special_values(seed, soa, bits):
+    """nv_taskcull's early pass over the SoA mirror walks 64-command segments through the conservative frustum filter (round 3):
+    NaN / inf / denormal bounds and draw fields, dummy commands and partial commands must leave the oracle's payloads"""
+    import torch
+    from niagara_amd import pipeline as P
+    s = special_scene(950 + seed)
+    pyr = oracle.Pyramid(256, 192)
+    oracle.depthreduce(s["depth"], pyr)
+    cd = s["cull"].copy()
+    cd["pyramidWidth"], cd["pyramidHeight"] = pyr.width, pyr.height
+    cd["clusterOcclusionEnabled"] = bits
+    ncmd = len(s["commands"])
+    pay_o, cnt_o = np.zeros((ncmd, 64), np.uint32), np.zeros(ncmd, np.uint32)
+    mvb_o = s["mvb"].copy()
+    oracle.taskcull(cd, 0, s["commands"], s["count4"], s["draws"], s["meshlets"], mvb_o, pyr, pay_o, cnt_o)
+    ctx = P.Context()
+    try:
+        dev = ctx.device
+        gp = P.DepthPyramid(dev, 256, 192)
+        ctx.depthreduce(torch.from_numpy(s["depth"]).to(dev), 256, 192, gp.desc)
+        db, mlb, dcb = P.to_device(s["draws"], dev), P.to_device(s["meshlets"], dev), P.to_device(s["commands"], dev)
+        if soa:
+            ctx.upload_meshlets(mlb, len(s["meshlets"]))
+        dccb = torch.from_numpy(s["count4"].view(np.int32).copy()).to(dev)
+        mvb = torch.from_numpy(s["mvb"].view(np.int32).copy()).to(dev)
+        d_pay = torch.full((ncmd * 64,), -1, dtype=torch.int32, device=dev)
+        d_cnt = torch.full((ncmd,), -1, dtype=torch.int32, device=dev)
+        ctx.taskcull(cd, 0, dcb, dccb, db, mlb, mvb, gp.desc, d_pay, d_cnt)
+        n = int(s["count4"][1]) * 64
+        cnt_g = d_cnt.cpu().numpy().view(np.uint32)
+        assert (cnt_g[:n] == cnt_o[:n]).all()
+        pay_g = d_pay.cpu().numpy().view(np.uint32).reshape(ncmd, 64)
+        for c in range(n):
+            assert (pay_g[c, :cnt_o[c]] == pay_o[c, :cnt_o[c]]).all(), c
+        assert (mvb.cpu().numpy().view(np.uint32) == mvb_o).all()
+        assert cnt_o[:n].sum() > 0
+    finally:
+        ctx.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------- drawcull
 def special_draw_scene(seed):
     from scenes import make_scene

@@ -75,9 +75,11 @@ def graph_wall(fn, iters):
     return us
 
 
-def config2(ctx, iters, n_draws=1_000_000, copies=6, soa=True):
-    """1 M MeshDraw spheres, frustum cull + LOD + ordered compaction: drawcull<LATE=0,TASK=0>"""
+def config2(ctx, iters, n_draws=1_000_000, copies=6, soa=True, fused_reset=False):
+    """1 M MeshDraw spheres, frustum cull + LOD + ordered compaction: drawcull<LATE=0,TASK=0>.  fused_reset: the pass absorbs the
+    caller's vkCmdFillBuffer(dccb, 0, 4, 0) (NV_OPT_FUSED_COUNT_RESET) instead of nv_reset_count as its own launch"""
     dev = ctx.device
+    ctx.set_option(P.NV_OPT_FUSED_COUNT_RESET, int(fused_reset))
     meshes, _ = synth.make_meshes(1, 8, 1 << 12)
     meshes["center"] = (-0.016, -0.028, -0.034)
     meshes["radius"] = 0.598  # kitten sphere (tests/golden/kitten_bounds.json)
@@ -96,10 +98,12 @@ def config2(ctx, iters, n_draws=1_000_000, copies=6, soa=True):
     dccb = torch.zeros(4, dtype=torch.int32, device=dev)
 
     def step(i):
-        ctx.reset_count(dccb)
+        if not fused_reset:
+            ctx.reset_count(dccb)
         ctx.drawcull(cd, 0, 0, dbs[i % copies], mb, dcb, dccb, dvbs[i % copies], None)
 
     wall, k_us, prof = timed(ctx, step, iters, "drawcull")
+    ctx.set_option(P.NV_OPT_FUSED_COUNT_RESET, 0)
     v = int(dccb[0].item())
     # parity: commands, count and (untouched by the early pass) drawVisibility against the oracle
     co, c4o, dvo = np.zeros(n_draws + 1, dtype=L.DRAWCMD), np.zeros(4, np.uint32), np.ones(n_draws, np.uint32)
@@ -107,7 +111,7 @@ def config2(ctx, iters, n_draws=1_000_000, copies=6, soa=True):
     same = (v == int(c4o[0]) and dcb[:v * 24].cpu().numpy().tobytes() == co[:v].tobytes()
             and (dvbs[(iters - 1) % copies].cpu().numpy().view(np.uint32) == dvo).all())
     algo = n_draws * 52 + v * 24 + 208 + 4
-    return dict(config="2: 1M draws, drawcull<0,0>" + ("" if soa else " (AoS records in place)"), draws=n_draws, visible=v, kernel_us=k_us, step_us=wall, step_us_with_events=prof["wall_with_events_us"], draws_per_s=n_draws / (k_us * 1e-6),
+    return dict(config="2: 1M draws, drawcull<0,0>" + ("" if soa else " (AoS records in place)") + (" (count reset fused)" if fused_reset else ""), draws=n_draws, visible=v, kernel_us=k_us, step_us=wall, step_us_with_events=prof["wall_with_events_us"], draws_per_s=n_draws / (k_us * 1e-6),
                 algorithmic_bytes=algo, achieved_GBs=algo / k_us / 1e3, frac=algo / k_us / 1e3 / HBM, parity=verdict(same))
 
 
@@ -641,7 +645,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     ctx = P.Context(0)
-    runs = {"2": lambda: config2(ctx, a.iters), "2_aos": lambda: config2(P.Context(0), a.iters, soa=False), "2l": lambda: config2_late(ctx, a.iters), "3b": lambda: config3b(ctx, a.iters), "3b_fused": lambda: config3b(P.Context(0), a.iters, fused=True), "4": lambda: config4(ctx, a.iters),
+    runs = {"2": lambda: config2(ctx, a.iters), "2_fused": lambda: config2(P.Context(0), a.iters, fused_reset=True), "2_aos": lambda: config2(P.Context(0), a.iters, soa=False), "2l": lambda: config2_late(ctx, a.iters), "3b": lambda: config3b(ctx, a.iters), "3b_fused": lambda: config3b(P.Context(0), a.iters, fused=True), "4": lambda: config4(ctx, a.iters),
             "4b": lambda: config4(ctx, a.iters, size=1024), "n4": lambda: config_n4(ctx, a.iters),
             "frame": lambda: config_frame(P.Context(0), a.iters, cpp_driver=True), "frame_py": lambda: config_frame(P.Context(0), a.iters), "frame_contract": lambda: config_frame(P.Context(0), a.iters, fused=False),
             "task": lambda: config_task(ctx, a.iters),
