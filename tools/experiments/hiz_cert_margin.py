@@ -180,11 +180,102 @@ def fast(c, r, znear, P00, P11, pw, ph, width, height, levels, rng, K=8.0):
     return dict(active=active, certain=ok | ~active, level=l, x0=x0, x1=x1, y0=y0, y1=y1, depth=depth, depth_margin=np.abs(depth) * kE)
 
 
+def fast_lean(c, r, znear, P00, P11, pw, ph, width, height, levels, rng, K=8.0):
+    """the lean variant: ONE bound E_A for all four aabb coordinates instead of one per quantity.
+        |q_fast - q_ref| <= 3 eps Q (2 + K'),   Q = (|c_a| + r c_z / v_a) / (c_z - r) >= |q|,   K' = (c_z + r) / (c_z - r)
+    (D = v_a c_z +- c_a r >= v_a (c_z - r) because |c_a| <= v_a), E_A = 0.5 max|P| max_a E_q + rounding of the affine map."""
+    cx, cy, cz = c
+    active = ~(cz < r + znear)
+    crz = cz * r
+    czr2 = cz * cz - r * r
+    kE = f32(K) * EPS
+    with np.errstate(all="ignore"):
+        rd = perturb((1.0 / (cz - r).astype(np.float64)).astype(f32), rng)
+        Kp = (cz + r) * rd
+
+        def axis(ca):
+            cra = ca * r
+            va = perturb(np.sqrt((ca * ca + czr2).astype(np.float64)).astype(f32), rng)
+            rva = perturb((1.0 / va.astype(np.float64)).astype(f32), rng)
+            p, g = va * ca, va * cz
+            qmin = (p - crz) * perturb((1.0 / (g + cra).astype(np.float64)).astype(f32), rng)
+            qmax = (p + crz) * perturb((1.0 / (g - cra).astype(np.float64)).astype(f32), rng)
+            Q = (np.abs(ca) + crz * rva) * rd
+            return qmin, qmax, Q
+
+        minx, maxx, Qx = axis(cx)
+        miny, maxy, Qy = axis(cy)
+        Pm = np.maximum(np.abs(P00), np.abs(P11)) * f32(0.5)
+        A0 = minx * P00 * f32(0.5) + f32(0.5)
+        A1 = maxy * P11 * f32(-0.5) + f32(0.5)
+        A2 = maxx * P00 * f32(0.5) + f32(0.5)
+        A3 = miny * P11 * f32(-0.5) + f32(0.5)
+        Amax = np.maximum(np.maximum(np.abs(A0), np.abs(A1)), np.maximum(np.abs(A2), np.abs(A3)))
+        EA = (np.maximum(Qx, Qy) * (f32(2) + Kp) * Pm + Amax + f32(0.5)) * kE
+        sx, sy = A2 - A0, A3 - A1
+        mx, my = sx * pw, sy * ph
+        m = np.maximum(mx, my)
+        pmax = np.maximum(pw, ph)
+        Em = f32(2) * EA * pmax + np.abs(m) * kE
+        lo, hi = m - Em, m + Em
+        pos_lo = lo > f32(2.0 ** -100)
+        pos_hi = hi > f32(2.0 ** -100)
+        l_lo = np.where(pos_lo, ceil_log2_exact(np.where(pos_lo, lo, f32(1))), -1000)
+        l_hi = np.where(pos_hi, ceil_log2_exact(np.where(pos_hi, hi, f32(1))), -1000)
+        ok = np.isfinite(m) & np.isfinite(Em) & ((pos_lo & (l_lo == l_hi)) | (hi <= 0))
+        lvl = np.clip(np.where(pos_lo, l_lo, 0), None, 32)
+        has = lvl > 0
+        scale = np.exp2((1 - np.where(has, lvl, 1)).astype(np.float64)).astype(f32)
+        fx, fy = pw * scale, ph * scale
+        fmax = np.maximum(fx, fy)
+        Ef = EA * fmax  # bound of any aabb coordinate in texels of the `fits` grid
+
+        def fit(A, s, f):
+            u = A * f
+            fl = np.floor(u)
+            fr = u - fl
+            T = fr + s * f
+            Eu = Ef + np.abs(u) * kE
+            ET = f32(3) * Ef + (np.abs(u) + np.abs(T) + f32(2)) * kE
+            good = (fr > Eu) & (fr < f32(1) - Eu) & (np.abs(T - f32(2)) > ET)
+            return T <= f32(2.0), good
+
+        fit0, g0 = fit(A0, sx, fx)
+        fit1, g1 = fit(A1, sy, fy)
+        ok &= ~has | (g0 & g1)
+        lvl = np.where(has, lvl - (fit0 & fit1), 0)
+        l = np.clip(lvl, 0, levels - 1)
+        w = np.maximum(1, width >> l).astype(np.int64)
+        h = np.maximum(1, height >> l).astype(np.int64)
+        u = (A0 + A2) * f32(0.5)
+        v = (A1 + A3) * f32(0.5)
+
+        def foot(uv, size):
+            sf = size.astype(f32)
+            t = uv * sf - f32(0.5)
+            Et = EA * sf + (np.abs(t) + f32(1)) * kE
+            f0 = np.floor(t)
+            fr = t - f0
+            good = (fr > Et) & (fr < f32(1) - Et)
+            f0 = np.where(f0 >= -1, f0, f32(-1))
+            f0 = np.where(f0 > sf, sf, f0)
+            a = f0.astype(np.int64)
+            hi_ = size - 1
+            return np.clip(a, 0, hi_), np.clip(a + 1, 0, hi_), good
+
+        x0, x1, gx = foot(u, w)
+        y0, y1, gy = foot(v, h)
+        ok &= gx & gy
+        depth = znear * rd
+    return dict(active=active, certain=ok | ~active, level=l, x0=x0, x1=x1, y0=y0, y1=y1, depth=depth, depth_margin=np.abs(depth) * kE)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=2_000_000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--K", type=float, default=8.0)
+    ap.add_argument("--lean", action="store_true", help="the one-bound variant")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     worst = 0.0
@@ -202,7 +293,7 @@ def main():
         cy = (rng.uniform(-1.3, 1.3, n) * cz / P11).astype(f32)
         r = np.exp(rng.uniform(np.log(rr[0]), np.log(rr[1]), n)).astype(f32)
         ref = reference((cx, cy, cz), r, znear, P00, P11, pw, ph, width, height, levels)
-        fa = fast((cx, cy, cz), r, znear, P00, P11, pw, ph, width, height, levels, rng, a.K)
+        fa = (fast_lean if a.lean else fast)((cx, cy, cz), r, znear, P00, P11, pw, ph, width, height, levels, rng, a.K)
         act = ref["active"]
         assert (act == fa["active"]).all()
         cert = fa["certain"] & act

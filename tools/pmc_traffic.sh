@@ -9,7 +9,7 @@ rocprofv3 -L 2>/dev/null | grep -o "TCC_EA0_[A-Z0-9_]*\|TCC_HIT[A-Z_]*\|TCC_MISS
 i=0
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   i=$((i+1))
-  env "$@" rocprofv3 --kernel-trace --pmc $pmc -f csv -d $out/pmc$i -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/pmc$i.log 2>&1
+  env "$@" rocprofv3 --kernel-trace --pmc $pmc -f csv -d $out/pmc$i -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --overlap-streams 0 > $out/pmc$i.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, os, json
@@ -37,7 +37,7 @@ def kern(sub):
     return best
 def mean(v, c):
     return v.get(c, {}).get("mean_per_launch")
-summary = {"command": "python bench.py --steps 20 --warmup 3 --no-cpu-baseline", "meshlets_per_gpu": 10000000, "meshlet_layout": "SoA12",
+summary = {"command": "python bench.py --steps 20 --warmup 3 --no-cpu-baseline --overlap-streams 0 (one pass after the other on one stream: the mode the bench line's value is measured in)", "meshlets_per_gpu": 10000000, "meshlet_layout": "SoA12",
            "units": "bytes per launch (mean over the profiled launches)"}
 cal = kern("soa_split_kernel")
 if cal:
