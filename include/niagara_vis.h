@@ -212,6 +212,17 @@ int nv_profile_read(nv_context* ctx, float out_ms[NV_PROF_SLOTS], uint32_t out_c
  * passes are in flight (10 M meshlets, three passes in flight: 23.3 instead of 24.8 us per pass; a single pass: 31.5
  * instead of 30.1 us).  Speed only. */
 #define NV_OPT_SCATTER_WAVES 4
+/* NV_OPT_CULL_FORM (default 0) and NV_OPT_CULL_RING (default 0): pin what nv_clustercull otherwise chooses per launch from two
+ * words the PREVIOUS launches of the context left in mapped host memory (frame coherence; read unsynchronised — possibly a launch
+ * or two behind).  Results never depend on the choice, speed does, and a captured HIP graph freezes whatever the capture saw;
+ * a caller that replays graphs, or wants run-to-run identical timing, pins it:
+ *   NV_OPT_CULL_FORM  0 = by statistic (direct form when more than 35 % of the last launch's commands passed the frustum filter),
+ *                     1 = always the filter form (sparse passes: few commands have survivors),
+ *                     2 = always the direct form (dense passes: the commands of draws drawcull already found visible);
+ *   NV_OPT_CULL_RING  0 = by the last launch's command count, 4 = the 4-deep load ring (passes of a few hundred thousand commands),
+ *                     8 = the 8-deep ring (long streams, late passes). */
+#define NV_OPT_CULL_FORM 5
+#define NV_OPT_CULL_RING 6
 int nv_set_option(nv_context* ctx, int option, int value);
 
 /* ---- capacities ----

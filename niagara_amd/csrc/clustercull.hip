@@ -1365,8 +1365,11 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 									else if (cmd.lateDrawVisibility == 1)
 										skipM = bitM;
 								}
-								bool rejects = false;
-								decided = certified_visible(a.cd, cf, cur.b0, cur.b1, cur.cone, need, &vis, &rejects);
+								bool rejects = true;
+								if (need == 0) // early pass: none of the command's clusters was visible last frame (clustercull.comp.glsl:91-92) — nothing to test
+									decided = true;
+								else
+									decided = certified_visible(a.cd, cf, cur.b0, cur.b1, cur.cone, need, &vis, &rejects);
 								m = vis & ~skipM;
 								if (DIRECT && !rejects)
 									++passedFilter;

@@ -101,7 +101,8 @@ struct nv_context
 	uint32_t scatterTilesAbs; // experiments: absolute number of scatter tiles (0 = per CU)
 	uint32_t hizLds; // stage the coarse pyramid levels in LDS for drawcull's late pass (experiments: measured slower)
 	uint32_t directPercent; // share of commands passing the filter above which the next launch skips the filter pass
-	int forceDirect;        // experiments build: -1 = by statistic, 0 / 1 = always filter / always direct
+	int forceDirect;        // NV_OPT_CULL_FORM: -1 = by the previous launch's statistic, 0 / 1 = always filter / always direct
+	int forceShallow;       // NV_OPT_CULL_RING: -1 = by the previous launch's command count, 0 / 1 = always the 8-deep / the 4-deep ring
 	// command count of the previous clustercull launch, written by its kernel into mapped host memory (tuning hint)
 	volatile uint32_t* hintHost;
 	uint32_t* hintDevice;
@@ -282,6 +283,7 @@ int nv_create(nv_context** out_ctx, int device)
 	ctx->scatterWaves = 16;
 	ctx->directPercent = 35; // measured crossover (config 3A geometry at several densities): ~36 % of the commands passing the filter
 	ctx->forceDirect = -1;
+	ctx->forceShallow = -1;
 	ctx->listStride = nv::clustercull_list_stride();
 	ctx->listSharers = 4;
 	ctx->listMinPer = 8;
@@ -395,6 +397,16 @@ int nv_set_option(nv_context* ctx, int option, int value)
 		if (value != 4 && value != 8 && value != 16)
 			return NV_EINVAL;
 		ctx->scatterWaves = (uint32_t)value;
+		return NV_OK;
+	case NV_OPT_CULL_FORM:
+		if (value < 0 || value > 2)
+			return NV_EINVAL;
+		ctx->forceDirect = value - 1; // 0 -> -1 (by statistic), 1 -> 0 (filter form), 2 -> 1 (direct form)
+		return NV_OK;
+	case NV_OPT_CULL_RING:
+		if (value != 0 && value != 4 && value != 8)
+			return NV_EINVAL;
+		ctx->forceShallow = value == 0 ? -1 : (value == 4 ? 1 : 0);
 		return NV_OK;
 	case NV_OPT_CULL_WORKGROUPS_PER_CU:
 		if (value < 1 || value > 8)
@@ -738,7 +750,9 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	// two pure maps: the cull kernel also accumulates survivors per scatter tile, so no workgroup waits on another
 	hipStream_t s = (hipStream_t)stream;
 	hipEvent_t e0 = prof_mark(ctx, s);
-	const bool shallow = ctx->hintHost && nv::clustercull_prefers_shallow(*ctx->hintHost) && !(ctx->debugMode & 65536u); // bit 16 (experiments): always deep
+	bool shallow = ctx->hintHost && nv::clustercull_prefers_shallow(*ctx->hintHost) && !(ctx->debugMode & 65536u); // bit 16 (experiments): always deep
+	if (ctx->forceShallow >= 0)
+		shallow = ctx->forceShallow != 0;
 	// mapped host words the previous launches left: [0] command count, [1] commands their filter did not (or would not
 	// have) finished — possibly a launch or two behind, which only matters for speed
 	bool direct = ctx->hintHost && nv::clustercull_prefers_direct(ctx->hintHost[0], ctx->hintHost[1], ctx->directPercent);

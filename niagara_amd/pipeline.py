@@ -39,6 +39,8 @@ NV_OPT_FUSED_COUNT_RESET = 1
 NV_OPT_FUSED_SUBMIT = 2
 NV_OPT_CULL_WORKGROUPS_PER_CU = 3
 NV_OPT_SCATTER_WAVES = 4
+NV_OPT_CULL_FORM = 5
+NV_OPT_CULL_RING = 6
 
 
 class Context:

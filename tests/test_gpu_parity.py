@@ -507,6 +507,40 @@ def test_capture_of_a_growing_draw_count(ctx):
     ctx.upload_draws(None, 0)
 
 
+def test_pinned_kernel_variants_equal_the_oracle(ctx):
+    """NV_OPT_CULL_FORM / NV_OPT_CULL_RING pin what nv_clustercull otherwise chooses from the previous launches' statistics (VERDICT
+    r2): every pinned combination, on a sparse and on a dense view of one pool, leaves the oracle's list; bad values are refused"""
+    draws, meshlets, commands, n, _ = _cluster_inputs(3000, 10)
+    dev = ctx.device
+    c4 = synth.count4_for(n)
+    db, mlb, dcb = P.to_device(draws, dev), P.to_device(meshlets, dev), P.to_device(commands, dev)
+    ctx.upload_meshlets(mlb, len(meshlets))
+    dccb = torch.from_numpy(c4.view(np.int32).copy()).to(dev)
+    cib = torch.zeros(n * 64 + 256, dtype=torch.int32, device=dev)
+    ccb = torch.zeros(4, dtype=torch.int32, device=dev)
+    try:
+        for cam, radius_note in (((0, 0, 0), "sparse"), ((0, 0, 400), "whole cloud in view")):
+            cd = host.build_cull_data(cam_pos=cam, draw_count=len(draws), draw_distance=2000.0, cullingEnabled=1, clusterBackfaceEnabled=1)
+            cib_o, cc4_o = np.zeros(n * 64, np.uint32), np.zeros(4, np.uint32)
+            oracle.clustercull(cd, 0, commands, c4, draws, meshlets, None, None, cib_o, cc4_o, threads=oracle.max_threads())
+            total = int(cc4_o[0])
+            for form in (0, 1, 2):
+                for ring in (0, 4, 8):
+                    ctx.set_option(P.NV_OPT_CULL_FORM, form)
+                    ctx.set_option(P.NV_OPT_CULL_RING, ring)
+                    ccb.zero_()
+                    ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
+                    assert int(ccb[0].item()) == total, (radius_note, form, ring)
+                    assert (G.host_u32(cib)[:total] == cib_o[:total]).all(), (radius_note, form, ring)
+        for opt, bad in ((P.NV_OPT_CULL_FORM, 3), (P.NV_OPT_CULL_RING, 5)):
+            with pytest.raises(P.NvError):
+                ctx.set_option(opt, bad)
+    finally:
+        ctx.set_option(P.NV_OPT_CULL_FORM, 0)
+        ctx.set_option(P.NV_OPT_CULL_RING, 0)
+    ctx.status()
+
+
 def test_three_contexts_share_one_scene_mirror():
     """contexts on three streams (three views in flight) use ONE set of SoA mirrors after nv_share_scene —
     device memory grows by one mirror, not three — and each produces the oracle's list for its own view."""
