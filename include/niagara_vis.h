@@ -223,6 +223,11 @@ int nv_profile_read(nv_context* ctx, float out_ms[NV_PROF_SLOTS], uint32_t out_c
  *                     8 = the 8-deep ring (long streams, late passes). */
 #define NV_OPT_CULL_FORM 5
 #define NV_OPT_CULL_RING 6
+/* NV_OPT_TASK_EMIT (default 0): likewise the form in which nv_drawcull (task = 1) writes its MeshTaskCommands — 0 = by the statistic
+ * of earlier task passes (list form once a pass emitted more than 4 commands per emitting draw), 1 = always per draw (every lane
+ * writes its own draws' commands; fastest for meshes of one or two task groups), 2 = always the list form (one lane per output
+ * command; fastest for meshes of many task groups).  Speed only. */
+#define NV_OPT_TASK_EMIT 7
 int nv_set_option(nv_context* ctx, int option, int value);
 
 /* ---- capacities ----

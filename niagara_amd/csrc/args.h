@@ -134,6 +134,8 @@ struct DrawArgs
 	uint32_t fusedReset; // NV_OPT_FUSED_COUNT_RESET
 	uint32_t fusedSubmit; // NV_OPT_FUSED_SUBMIT
 	uint32_t meshCount;  // > 0 when nv_upload_meshes registered `meshes`: the table may be staged in LDS
+	uint32_t* hostHint;  // mapped host words (context.hip): [2], [3] = emitting draws / commands of the last TASK pass, written by its scatter launch
+	uint32_t taskList;   // TASK scatter in the list form (one lane per output command) instead of the per-draw form
 	uint32_t stagedBase; // late pass: first texel (offset from the pyramid base) of the coarse levels the decide kernel stages in LDS; ~0u = none
 #ifdef NV_EXPERIMENTS
 	uint32_t debugMode; // NV_DEBUG_MODE of the experiments build

@@ -102,6 +102,7 @@ struct nv_context
 	uint32_t hizLds; // stage the coarse pyramid levels in LDS for drawcull's late pass (experiments: measured slower)
 	uint32_t directPercent; // share of commands passing the filter above which the next launch skips the filter pass
 	int forceDirect;        // NV_OPT_CULL_FORM: -1 = by the previous launch's statistic, 0 / 1 = always filter / always direct
+	int forceTaskList;      // NV_OPT_TASK_EMIT: -1 = by the statistic of earlier TASK passes, 0 / 1 = per-draw / list form of drawcull's TASK scatter
 	int forceShallow;       // NV_OPT_CULL_RING: -1 = by the previous launch's command count, 0 / 1 = always the 8-deep / the 4-deep ring
 	// command count of the previous clustercull launch, written by its kernel into mapped host memory (tuning hint)
 	volatile uint32_t* hintHost;
@@ -284,6 +285,7 @@ int nv_create(nv_context** out_ctx, int device)
 	ctx->directPercent = 35; // measured crossover (config 3A geometry at several densities): ~36 % of the commands passing the filter
 	ctx->forceDirect = -1;
 	ctx->forceShallow = -1;
+	ctx->forceTaskList = -1;
 	ctx->listStride = nv::clustercull_list_stride();
 	ctx->listSharers = 4;
 	ctx->listMinPer = 8;
@@ -402,6 +404,11 @@ int nv_set_option(nv_context* ctx, int option, int value)
 		if (value < 0 || value > 2)
 			return NV_EINVAL;
 		ctx->forceDirect = value - 1; // 0 -> -1 (by statistic), 1 -> 0 (filter form), 2 -> 1 (direct form)
+		return NV_OK;
+	case NV_OPT_TASK_EMIT:
+		if (value < 0 || value > 2)
+			return NV_EINVAL;
+		ctx->forceTaskList = value - 1;
 		return NV_OK;
 	case NV_OPT_CULL_RING:
 		if (value != 0 && value != 4 && value != 8)
@@ -641,6 +648,10 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 	a.fusedReset = ctx->fusedReset;
 	a.fusedSubmit = ctx->fusedSubmit;
 	a.meshCount = ctx->scene->meshesFrom == d_meshes ? ctx->scene->meshCount : 0u;
+	a.hostHint = ctx->hintDevice;
+	// TASK scatter form: the list form (one lane per output command) when an earlier TASK pass emitted more than 4 commands per
+	// emitting draw, the per-draw form otherwise (and until a pass has been seen); NV_OPT_TASK_EMIT pins it
+	a.taskList = ctx->forceTaskList >= 0 ? (uint32_t)ctx->forceTaskList : (ctx->hintHost && ctx->hintHost[3] > 4u * ctx->hintHost[2] ? 1u : 0u);
 	// LDS-staged coarse pyramid levels for the late pass's HiZ probes: measured slower than reading them through L2 (a
 	// workgroup of 512 draws stages 22 KiB to serve the ~20 probes of its visible draws) — off unless asked for
 	a.stagedBase = ~0u;

@@ -366,6 +366,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 
 	// per wave-batch command counts -> LDS; merged per scatter tile below
 	__shared__ uint32_t s_waveCount[DC_BATCH * DC_WAVES];
+	__shared__ uint32_t s_waveEmit[DC_BATCH * DC_WAVES]; // TASK: draws of the wave-batch that emit commands (the host's statistic)
 	DrawPre pre[DC_BATCH];
 	bool visible[DC_BATCH];
 #pragma unroll
@@ -444,8 +445,12 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 			count = res.count;
 		}
 		const uint32_t waveCount = wave_sum_u32(count);
+		const uint32_t waveEmit = TASK ? (uint32_t)__builtin_popcountll(__ballot(count != 0)) : 0u;
 		if (lane == 0)
+		{
 			s_waveCount[j * DC_WAVES + wave] = waveCount;
+			s_waveEmit[j * DC_WAVES + wave] = waveEmit;
+		}
 	}
 	__syncthreads();
 	// One thread adds the workgroup's counts to the scatter tiles they fall in (tiles are whole multiples of 64 draws, so
@@ -453,7 +458,8 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 	// workgroup instead of one per wave-batch — atomics into one line serialise in its L2 channel (args.h).
 	if (tid == 0 && !NV_DBG(a, 4u))
 	{
-		uint32_t runTile = first / T2, runSum = 0;
+		// (TASK: the tile's emitting draws go into word 1 of the same line — the scatter launch's last tile sums them for the host)
+		uint32_t runTile = first / T2, runSum = 0, runEmit = 0;
 #pragma unroll
 		for (uint32_t i = 0; i < DC_BATCH * DC_WAVES; ++i)
 		{
@@ -462,13 +468,19 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 			{
 				if (runSum)
 					atomicAdd(&a.tileCounts->counts[bank][runTile * CC_COUNT_STRIDE], runSum);
+				if (TASK && runEmit)
+					atomicAdd(&a.tileCounts->counts[bank][runTile * CC_COUNT_STRIDE + 1], runEmit);
 				runTile = t;
 				runSum = 0;
+				runEmit = 0;
 			}
 			runSum += s_waveCount[i];
+			runEmit += s_waveEmit[i];
 		}
 		if (runSum)
 			atomicAdd(&a.tileCounts->counts[bank][runTile * CC_COUNT_STRIDE], runSum);
+		if (TASK && runEmit)
+			atomicAdd(&a.tileCounts->counts[bank][runTile * CC_COUNT_STRIDE + 1], runEmit);
 	}
 }
 
@@ -493,7 +505,7 @@ NV_DEV void load_result_bytes(const uint8_t* p, uint32_t (&w)[4])
 
 // K2.  DC_PER_LANE = consecutive draws per lane (1, 4 or 16, chosen by the launcher so that a tile is one step and all
 // lanes have work: 16 for >= 1 M draws, 1 for the few thousand draws of a small scene).
-template <bool TASK, bool MESH_LDS, uint32_t DC_PER_LANE>
+template <bool TASK, bool MESH_LDS, uint32_t DC_PER_LANE, bool LIST = false>
 __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 {
 	constexpr uint32_t DC_STEP = DC_THREADS * DC_PER_LANE;
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 	__shared__ uint32_t s_sum[DC_WAVES];
 	// TASK: the step's emitting draws in draw order, {first command of the draw relative to the step's first command,
 	// draw within the step | lod << 12 | previous visibility << 15}, + one sentinel (round 3: one LANE per output command)
-	__shared__ uint2 s_emit[TASK ? DC_STEP + 1 : 1];
+	__shared__ uint2 s_emit[TASK && LIST ? DC_STEP + 1 : 1];
 	__shared__ uint32_t s_partE[DC_WAVES];
 
 	const uint32_t tid = threadIdx.x;
@@ -519,6 +531,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 	const uint32_t k2parity = load_uniform_u32(&a.tileCounts->k2parity);
 	const uint32_t base0 = load_uniform_u32(&a.tileCounts->base);
 	uint32_t cnt0[2] = { 0, 0 }, cnt1[2] = { 0, 0 }; // this thread's tiles tid and tid + 256, per bank
+	uint32_t em0[2] = { 0, 0 }, em1[2] = { 0, 0 };   // TASK, last tile: likewise the tiles' emitting draws (word 1 of the line)
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
 	{
@@ -527,6 +540,11 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 		{
 			cnt0[j] = a.tileCounts->counts[0][i * CC_COUNT_STRIDE];
 			cnt1[j] = a.tileCounts->counts[1][i * CC_COUNT_STRIDE];
+			if (TASK && tile == numTiles - 1)
+			{
+				em0[j] = a.tileCounts->counts[0][i * CC_COUNT_STRIDE + 1];
+				em1[j] = a.tileCounts->counts[1][i * CC_COUNT_STRIDE + 1];
+			}
 		}
 	}
 	const uint32_t first = tile * T;
@@ -539,7 +557,10 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 	// every workgroup clears its entries of the other bank for the next pass; one thread flips the parity the next
 	// decide kernel will read (this pass reads k2parity only)
 	for (uint32_t i = tile * DC_THREADS + tid; i < CC_MAX_SCATTER_TILES; i += gridDim.x * DC_THREADS)
+	{
 		a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE] = 0;
+		a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE + 1] = 0; // (a TASK pass's emitting draws: cleared by whatever pass comes next)
+	}
 	if (tile == 0 && tid == 0)
 	{
 		a.tileCounts->parity = bank ^ 1u;
@@ -587,6 +608,23 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 	}
 	if (tid == 0 && tile == numTiles - 1)
 		a.count4[0] = total; // what the chain of atomicAdds leaves in the count word
+	if (TASK && tile == numTiles - 1 && a.hostHint)
+	{
+		// the pass's emitting draws and commands for the host's choice of a later launch's form (mapped words; speed only)
+		__shared__ uint32_t s_emitters;
+		if (tid == 0)
+			s_emitters = 0;
+		__syncthreads();
+		const uint32_t we = wave_sum_u32(bank ? em1[0] + em1[1] : em0[0] + em0[1]);
+		if (lane == 0 && we)
+			atomicAdd(&s_emitters, we);
+		__syncthreads();
+		if (tid == 0)
+		{
+			__hip_atomic_store(a.hostHint + 2, s_emitters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(a.hostHint + 3, total - base0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
 	if (TASK && a.fusedSubmit && tile == numTiles - 1)
 	{
 		// NV_OPT_FUSED_SUBMIT: tasksubmit.comp.glsl:27-47 from the workgroup that knows the final count.  The dummy commands
@@ -680,7 +718,13 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 			}
 		}
 
-		if (TASK)
+		// TASK, two forms (LIST, chosen per launch by the host from the previous launches' statistic: frame coherence, speed only).
+		// Passes whose emitting draws have many task groups (a 1 M-draw frame over meshes of thousands of meshlets: 7 commands per
+		// emitting draw) take the list form below; passes of small draws (one or two commands each: the synthetic contract scene,
+		// most real meshes) keep round 2's form further down — every lane writes its own draws' commands, the few large ones are
+		// expanded owner by owner — which is 1.5 us faster for them (config 3B: 13.1 against 14.6 us).  One kernel with a per-step
+		// choice between the two measured 14.2 us where the list form alone takes 9.4 (151 VGPRs, both paths' state live).
+		if constexpr (TASK && LIST)
 		{
 			// ---- drawcull.comp.glsl:120-139, one LANE per output command (round 3).  Through round 2 a draw's commands were
 			// written by its owning lane (<= 4 task groups) or wave-cooperatively, one owning draw at a time; with one scatter
@@ -744,7 +788,63 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 		for (uint32_t j = 0; j < DC_PER_LANE; ++j)
 		{
 			const uint32_t lodIndex = res[j] & 7u;
-			if (!TASK && cnt[j])
+			if (TASK) // (!LIST: the list form left the step above)
+			{
+				// drawcull.comp.glsl:120-139.  Draws with a handful of task groups write their own commands (all lanes
+				// in parallel); larger ones are expanded wave-cooperatively, one owning lane at a time, so that no lane
+				// loops over hundreds of commands while 63 others wait.
+				constexpr uint32_t DC_SMALL = 4;
+				uint64_t owners = __ballot(cnt[j] > DC_SMALL);
+				const uint32_t oldVis = res[j] >> 4 & 1u;
+				NvMeshTaskCommand* tc = static_cast<NvMeshTaskCommand*>(a.commands);
+				if (cnt[j] != 0 && cnt[j] <= DC_SMALL && dci + cnt[j] <= NV_TASK_WGLIMIT) // drop the whole draw on overflow (:128)
+				{
+					const char* mesh = meshBase + (size_t)meshIndex[j] * sizeof(NvMesh);
+					const uint32_t meshletOffset = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * lodIndex + 8);
+					const uint32_t meshletCount = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * lodIndex + 12);
+					for (uint32_t i = 0; i < cnt[j]; ++i)
+					{
+						NvMeshTaskCommand cmd;
+						cmd.drawId = first + c + j;
+						cmd.taskOffset = meshletOffset + i * NV_TASK_WGSIZE;
+						const uint32_t rest = meshletCount - i * NV_TASK_WGSIZE;
+						cmd.taskCount = rest < NV_TASK_WGSIZE ? rest : NV_TASK_WGSIZE;
+						cmd.lateDrawVisibility = oldVis;
+						cmd.meshletVisibilityOffset = mvo[j] + i * NV_TASK_WGSIZE;
+						tc[dci + i] = cmd;
+					}
+				}
+				while (owners)
+				{
+					const int src = __builtin_ctzll(owners);
+					owners &= owners - 1;
+					const uint32_t oDraw = first + c0 + (wave * 64 + src) * DC_PER_LANE + j;
+					const uint32_t oDci = __builtin_amdgcn_readlane(dci, src);
+					const uint32_t oGroups = __builtin_amdgcn_readlane(cnt[j], src);
+					const uint32_t oLod = __builtin_amdgcn_readlane(lodIndex, src);
+					const uint32_t oVis = __builtin_amdgcn_readlane(oldVis, src);
+					const uint32_t oMesh = __builtin_amdgcn_readlane(meshIndex[j], src);
+					const uint32_t oMvo = __builtin_amdgcn_readlane(mvo[j], src);
+					if (oDci + oGroups <= NV_TASK_WGLIMIT) // drop the whole draw on overflow (:128)
+					{
+						const char* mesh = meshBase + (size_t)oMesh * sizeof(NvMesh);
+						const uint32_t meshletOffset = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * oLod + 8);
+						const uint32_t meshletCount = *reinterpret_cast<const uint32_t*>(mesh + 48 + 20 * oLod + 12);
+						for (uint32_t i = lane; i < oGroups; i += 64)
+						{
+							NvMeshTaskCommand cmd;
+							cmd.drawId = oDraw;
+							cmd.taskOffset = meshletOffset + i * NV_TASK_WGSIZE;
+							uint32_t rest = meshletCount - i * NV_TASK_WGSIZE;
+							cmd.taskCount = rest < NV_TASK_WGSIZE ? rest : NV_TASK_WGSIZE;
+							cmd.lateDrawVisibility = oVis;
+							cmd.meshletVisibilityOffset = oMvo + i * NV_TASK_WGSIZE;
+							tc[oDci + i] = cmd;
+						}
+					}
+				}
+			}
+			else if (cnt[j])
 			{
 				// drawcull.comp.glsl:141-150
 				const char* mesh = meshBase + (size_t)meshIndex[j] * sizeof(NvMesh);
@@ -791,14 +891,22 @@ static void launch_dc(hipStream_t stream, const DrawArgs& a, int late, int task,
 		launch_decide<MESH_LDS, false>(stream, a, late, task, decideBlocks);
 	const uint32_t t = (a.cd.drawCount + a.scatterTiles - 1) / a.scatterTiles; // scatter_tile_draws, before rounding
 	const dim3 sgrid(a.scatterTiles);
+#define LAUNCH_TASK_SCATTER(PER)                                                                                      \
+	do                                                                                                                 \
+	{                                                                                                                  \
+		if (a.taskList)                                                                                                \
+			hipLaunchKernelGGL((draw_scatter_kernel<true, MESH_LDS, PER, true>), sgrid, block, 0, stream, a);          \
+		else                                                                                                           \
+			hipLaunchKernelGGL((draw_scatter_kernel<true, MESH_LDS, PER, false>), sgrid, block, 0, stream, a);         \
+	} while (0)
 	if (task)
 	{
 		if (t <= DC_THREADS)
-			hipLaunchKernelGGL((draw_scatter_kernel<true, MESH_LDS, 1>), sgrid, block, 0, stream, a);
+			LAUNCH_TASK_SCATTER(1);
 		else if (t <= DC_THREADS * 4)
-			hipLaunchKernelGGL((draw_scatter_kernel<true, MESH_LDS, 4>), sgrid, block, 0, stream, a);
+			LAUNCH_TASK_SCATTER(4);
 		else
-			hipLaunchKernelGGL((draw_scatter_kernel<true, MESH_LDS, 16>), sgrid, block, 0, stream, a);
+			LAUNCH_TASK_SCATTER(16);
 	}
 	else
 	{

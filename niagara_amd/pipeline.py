@@ -41,6 +41,7 @@ NV_OPT_CULL_WORKGROUPS_PER_CU = 3
 NV_OPT_SCATTER_WAVES = 4
 NV_OPT_CULL_FORM = 5
 NV_OPT_CULL_RING = 6
+NV_OPT_TASK_EMIT = 7
 
 
 class Context:

@@ -541,6 +541,29 @@ def test_pinned_kernel_variants_equal_the_oracle(ctx):
     ctx.status()
 
 
+@pytest.mark.parametrize("lod0", [60, 900])
+def test_task_emission_forms_equal_the_oracle(ctx, lod0):
+    """nv_drawcull (task = 1) writes its commands per draw or in the list form (one lane per output command, round 3); the host
+    picks by the statistic of earlier task passes, NV_OPT_TASK_EMIT pins it: both pinned forms and the automatic sequence (three
+    passes: the statistic arrives two launches late) leave the oracle's commands, for meshes of 1 and of up to 15 task groups"""
+    scene = make_scene(seed=41, n_draws=6000, n_meshes=5, lods=4, meshlets_lod0=lod0, scene_radius=40.0)
+    cd = passes.set_flags(scene["cull"], (1, 1, 0, 0, 1))
+    dvb = np.ones(len(scene["draws"]), np.uint32)
+    want, c4 = passes.run_drawcull(oracle, scene, cd, 0, 1, dvb.copy(), None)
+    assert int(c4[0]) > 500
+    g = G.GpuScene(ctx, scene)
+    try:
+        for emit in (1, 2, 0, 0, 0):
+            ctx.set_option(P.NV_OPT_TASK_EMIT, emit)
+            dcb, dccb, _ = g.drawcull(cd, 0, 1, dvb, with_pyramid=False)
+            assert (G.host_u32(dccb)[:1] == c4[:1]).all(), emit
+            n = int(c4[0])
+            assert P.from_device(dcb, L.TASKCMD)[:n].tobytes() == want[:n].tobytes(), emit
+    finally:
+        ctx.set_option(P.NV_OPT_TASK_EMIT, 0)
+    ctx.status()
+
+
 def test_three_contexts_share_one_scene_mirror():
     """contexts on three streams (three views in flight) use ONE set of SoA mirrors after nv_share_scene —
     device memory grows by one mirror, not three — and each produces the oracle's list for its own view."""

@@ -1,0 +1,9 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+show() { python3 -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print(d['config'][:70], d['parity'], {k: round(v, 1) for k, v in d.items() if k.endswith('_us')})"; }
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+timeout 600 python tools/bench_configs.py --iters 30 --only 3b,3b_fused,frame_py 2>/dev/null | show
