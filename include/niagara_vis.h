@@ -218,7 +218,10 @@ int nv_profile_read(nv_context* ctx, float out_ms[NV_PROF_SLOTS], uint32_t out_c
  * a caller that replays graphs, or wants run-to-run identical timing, pins it:
  *   NV_OPT_CULL_FORM  0 = by statistic (direct form when more than 35 % of the last launch's commands passed the frustum filter),
  *                     1 = always the filter form (sparse passes: few commands have survivors),
- *                     2 = always the direct form (dense passes: the commands of draws drawcull already found visible);
+ *                     2 = always the direct form (dense passes: the commands of draws drawcull already found visible); an early
+ *                         pass with visibility bits then tests one lane per SET BIT (last frame's visible clusters) instead of
+ *                         one wave per command,
+ *                     3 = as 2, but one wave per command also in the early pass with visibility bits;
  *   NV_OPT_CULL_RING  0 = by the last launch's command count, 4 = the 4-deep load ring (passes of a few hundred thousand commands),
  *                     8 = the 8-deep ring (long streams, late passes). */
 #define NV_OPT_CULL_FORM 5

@@ -2085,6 +2085,367 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Early pass with visibility bits, dense form: one LANE per cluster whose bit is set.
+//
+// clustercull.comp.glsl:86-95 lets only last frame's visible clusters through, so a wave that walks one command at a time
+// runs the sphere / cone arithmetic with most of its lanes off (a frame of the 1 M-draw scene: 29 % of the slots are set;
+// the direct form of cluster_mask_kernel spends 85 VALU + 60 SALU instructions per command whatever the bits say, 38-40 us).
+// This kernel is the occlusion stage's layout applied to the early pass: a block owns a contiguous range of commands (one per
+// lane), expands their set bits into an LDS list — one entry per cluster that can be visible at all — and tests the entries
+// with one LANE each: the certified two-sided test of pass B (certified_visible, same arithmetic and margins, decided per
+// lane instead of per wave), the reference's own arithmetic for the lanes it leaves undecided.  The per-draw coefficients
+// (make_filter) are computed once per command, lane-parallel, and read from LDS per entry.  Output as cluster_mask_kernel's:
+// one ballot per command, survivors per scatter tile, the statistic for the host's choice of the next launch's form.
+//
+// Measured on the frame's early pass (175 k commands, 2.98 M set bits): 27 us against 38-40 us, bound by instruction issue
+// (12 M wave-instructions, 4.5 cycles each per SIMD outside the launch's 4 us) — which is why the variants that only moved
+// latencies changed nothing: the entries' loads kept in flight by a counted ring instead of rounds (27.7 us), four
+// independent waves per block with a list each and no barrier (33-34 us: the per-command phases then run on 22 lanes
+// of every wave instead of on the full first wave of a block).  Without visibility bits every valid cluster is an entry and
+// the form loses to one command per wave (10 M clusters: 52-62 us against 40, whatever the variant), so it is used for the
+// early pass with bits only.
+constexpr int CB_THREADS = 256;
+constexpr int CB_CMDS = 128; // commands per block and iteration, at most (lanes 0 .. per - 1 own one each)
+constexpr int CB_U = 4;      // list entries per lane in flight
+
+// One round = CB_U list entries per lane, slot-major (slot k of lane t = entry base + k CB_THREADS + t), straight-line: all
+// loads unconditional (slots past the last entry re-read it) and issued together; a slot no lane of the wave holds an entry
+// for is skipped as a whole.  ONE instantiation per layout: with a copy per round size hipcc gave the copies' registers
+// to each other and waited for everything in flight (the prefetches) before the largest copy's first load.
+template <bool SOA>
+NV_DEV void bits_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint32_t tid, bool first, bool ownsCommand, const float4& d0, const float4& d1,
+                       const uint16_t* s_list, const uint32_t* s_taskOffset, float4 (*s_draw)[2], float4 (*s_cert)[5], uint32_t* s_visLo, uint32_t* s_visHi)
+{
+	constexpr int U = CB_U;
+	uint32_t e[U];
+	uint2 b[U];
+	uint32_t cone[U];
+#pragma unroll
+	for (int k = 0; k < U; ++k)
+	{
+		const uint32_t s = base + k * CB_THREADS + tid;
+		e[k] = s_list[s < total ? s : total - 1u];
+		const uint32_t mi = s_taskOffset[e[k] >> 6] + (e[k] & 63u);
+		if (SOA)
+		{
+			b[k] = a.soaBounds[mi];
+			cone[k] = a.soaCones[mi];
+		}
+		else
+		{
+			const uint32_t* p = reinterpret_cast<const uint32_t*>(a.meshlets + mi);
+			b[k] = make_uint2(p[0], p[1]);
+			cone[k] = p[2];
+		}
+	}
+	if (first) // (uniform)
+	{
+		// behind the first entries' loads: the per-command coefficients of the certified test (one command per lane).  The empty
+		// statement keeps them there: left alone hipcc hoists the arithmetic (it only depends on the prefetched draw) in front of
+		// the loads, together with a wait for the youngest prefetches — one full latency before the entries are even asked for.
+		float4 q0 = d0, q1 = d1;
+		asm volatile("; coefficients behind the entry loads" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w)::"memory");
+		if (ownsCommand)
+		{
+			DrawUniform u;
+			u.pos = { q0.x, q0.y, q0.z };
+			u.scale = q0.w;
+			u.q = { q1.x, q1.y, q1.z };
+			u.qw = q1.w;
+			const FilterDraw f = make_filter(a.cd, u, a.filterK);
+			s_draw[tid][0] = q0;
+			s_draw[tid][1] = q1;
+			s_cert[tid][0] = make_float4(f.m[0], f.m[1], f.m[2], f.b[0]);
+			s_cert[tid][1] = make_float4(f.m[3], f.m[4], f.m[5], f.b[1]);
+			s_cert[tid][2] = make_float4(f.m[6], f.m[7], f.m[8], f.b[2]);
+			s_cert[tid][3] = make_float4(f.aK, f.bK, f.aR, f.scale);
+			s_cert[tid][4] = make_float4(f.coneK, f.is127, 0.0f, 0.0f);
+		}
+		NV_LDS_BARRIER();
+	}
+	const NvCullData& cd = a.cd;
+	const bool useCert = a.filterK > 0.0f;
+#pragma unroll
+	for (int k = 0; k < U; ++k)
+	{
+		const uint32_t s = base + k * CB_THREADS + tid;
+		if (__ballot(s < total) == 0) // (uniform) nobody in this wave holds an entry in this slot
+			continue;
+		const uint32_t owner = e[k] >> 6, bit = e[k] & 63u;
+		const float4 r0 = s_cert[owner][0], r1 = s_cert[owner][1], r2 = s_cert[owner][2], r3 = s_cert[owner][3], r4 = s_cert[owner][4];
+		const uint32_t b0 = b[k].x, b1 = b[k].y;
+		// certified_visible, one lane = one cluster
+		const float vx = half_bits_to_float(b0 & 0xffffu), vy = half_bits_to_float(b0 >> 16), vz = half_bits_to_float(b1 & 0xffffu);
+		const float rad = half_bits_to_float(b1 >> 16);
+		const float cx = __builtin_fmaf(r0.x, vx, __builtin_fmaf(r0.y, vy, __builtin_fmaf(r0.z, vz, r0.w)));
+		const float cy = __builtin_fmaf(r1.x, vx, __builtin_fmaf(r1.y, vy, __builtin_fmaf(r1.z, vz, r1.w)));
+		const float cz = __builtin_fmaf(r2.x, vx, __builtin_fmaf(r2.y, vy, __builtin_fmaf(r2.z, vz, r2.w)));
+		const float aK = r3.x, bK = r3.y, aR = r3.z, scale = r3.w, coneK = r4.x, is127 = r4.y;
+		float T = __builtin_fmaf(aK, __builtin_fabsf(vx), bK);
+		T = __builtin_fmaf(aK, __builtin_fabsf(vy), T);
+		T = __builtin_fmaf(aK, __builtin_fabsf(vz), T);
+		T = __builtin_fmaf(aR, __builtin_fabsf(rad), T);
+		const float thrHi = __builtin_fmaf(scale, rad, T), thrLo = __builtin_fmaf(scale, rad, -T);
+		const float g1 = __builtin_fmaf(cz, cd.frustum[1], -(__builtin_fabsf(cx) * cd.frustum[0]));
+		const float g2 = __builtin_fmaf(cz, cd.frustum[3], -(__builtin_fabsf(cy) * cd.frustum[2]));
+		const float gn = cz - cd.znear;
+		const float gf = cd.zfar - cz;
+		const float g = __builtin_fminf(__builtin_fminf(g1, g2), __builtin_fminf(gn, gf));
+		const bool out = g < -thrHi, in = g > -thrLo;
+		bool decided = useCert && (out || in);
+		bool visible = in;
+		if (cd.clusterBackfaceEnabled != 0)
+		{
+			const float kx = s8_to_float(cone[k], 0), ky = s8_to_float(cone[k], 1), kz = s8_to_float(cone[k], 2), kc = s8_to_float(cone[k], 3);
+			const float wx = __builtin_fmaf(r0.x, kx, __builtin_fmaf(r0.y, ky, r0.z * kz));
+			const float wy = __builtin_fmaf(r1.x, kx, __builtin_fmaf(r1.y, ky, r1.z * kz));
+			const float wz = __builtin_fmaf(r2.x, kx, __builtin_fmaf(r2.y, ky, r2.z * kz));
+			const float lhs = __builtin_fmaf(cx, wx, __builtin_fmaf(cy, wy, cz * wz)) * is127;
+			const float len = __builtin_amdgcn_sqrtf(__builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, cz * cz)));
+			const float rhs = __builtin_fmaf(kc * 0.00787401574803149606f, len, scale * rad);
+			const float D = lhs - rhs;
+			const float Tc = T * coneK;
+			const bool cull = D > Tc, keep = D < -Tc;
+			decided = decided && (out || cull || keep); // (a cluster outside the frustum is decided whatever its cone says)
+			visible = visible && keep;
+		}
+		if (!decided) // the reference's arithmetic (clustercull.comp.glsl:72-80,102-108), as cull_command evaluates it
+		{
+			const float4 q0 = s_draw[owner][0], q1 = s_draw[owner][1];
+			DrawUniform u;
+			u.pos = { q0.x, q0.y, q0.z };
+			u.scale = q0.w;
+			u.q = { q1.x, q1.y, q1.z };
+			u.qw = q1.w;
+			LaneData l;
+			l.b0 = b0;
+			l.b1 = b1;
+			l.cone = cone[k];
+			l.mvbWord = 0;
+			f3 c;
+			float r;
+			lane_sphere(cd, u, l, c, r);
+			visible = frustum_test(cd, c, r);
+			if (cd.clusterBackfaceEnabled != 0 && visible)
+			{
+				f3 axis;
+				float cutoff;
+				lane_cone(cd, u, l, axis, cutoff);
+				visible = !cone_cull(c, r, axis, cutoff);
+			}
+		}
+		if (s < total && !visible)
+			atomicAnd(bit < 32u ? &s_visLo[owner] : &s_visHi[owner], ~(1u << (bit & 31u)));
+	}
+}
+
+// The block's share of the pass is cut into iterations of `per` <= CB_CMDS commands, and the loop is software-pipelined over
+// them: while the entries of iteration i are fetched and tested, the MeshDraws and visibility words of iteration i + 1 and
+// the commands of iteration i + 2 are in flight, so an iteration starts with its list instead of two memory latencies.
+// Plain loads: the prefetches are older than the entries' loads, so hipcc's in-order wait for the latter covers them, and
+// at the loop's back edge they have had the whole iteration to arrive.
+struct BitsCommand
+{
+	uint32_t drawId, taskOffset, taskCount, mvo;
+};
+
+// (unconditional: a lane without a command reads command 0 and its taskCount is zeroed where the record is USED — a load under
+// a branch is copied out of the branch by hipcc, behind a wait that also covers the prefetches issued just before it)
+NV_DEV BitsCommand bits_load_command(const ClusterArgs& a, uint32_t idx, bool live)
+{
+	const uint32_t* p = reinterpret_cast<const uint32_t*>(a.commands + (live ? idx : 0u));
+	BitsCommand c;
+	c.drawId = p[0];
+	c.taskOffset = p[1];
+	c.taskCount = p[2];
+	c.mvo = p[4];
+	return c;
+}
+
+template <bool SOA>
+__global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs a)
+{
+	__shared__ uint32_t s_visLo[CB_CMDS], s_visHi[CB_CMDS], s_taskOffset[CB_CMDS], s_excl[CB_CMDS];
+	__shared__ float4 s_draw[CB_CMDS][2];
+	__shared__ float4 s_cert[CB_CMDS][5];
+	__shared__ uint16_t s_list[CB_CMDS * 64]; // (command within the iteration << 6) | lane, in command-major order
+	__shared__ uint32_t s_part[CB_THREADS / 64];
+
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63u;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const uint32_t numCmds = indirect_command_count(a);
+	if (a.hostHint && blockIdx.x == 0 && tid == 0)
+		__hip_atomic_store(a.hostHint, numCmds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles);
+	const uint32_t bank = load_uniform_u32(&a.tileCounts->parity) & 1u;
+	if (blockIdx.x == 0 && tid == 0)
+	{
+		a.tileCounts->k2parity = bank;
+		a.tileCounts->base = a.fusedReset ? 0u : a.clusterCount4[0];
+	}
+	// every block the same number of iterations (the grid is resident at once: the last iteration is the launch's tail),
+	// iteration i of block b = commands [(i G + b) per, (i G + b + 1) per): neighbouring blocks read neighbouring commands
+	const uint32_t G = gridDim.x;
+	const uint32_t iters = (numCmds + G * (uint32_t)CB_CMDS - 1u) / (G * (uint32_t)CB_CMDS);
+	uint32_t per = iters ? (numCmds + G * iters - 1u) / (G * iters) : 0u;
+	per = per < 16u ? 16u : per; // (<= CB_CMDS by construction)
+	uint32_t passedAcc = 0;
+
+	// pipeline prologue: commands of iterations 0 and 1, MeshDraw and words of iteration 0
+	uint32_t chunk = blockIdx.x;
+	BitsCommand cur = bits_load_command(a, chunk * per + tid, tid < per && chunk * per + tid < numCmds);
+	BitsCommand nxt = bits_load_command(a, (chunk + G) * per + tid, tid < per && (chunk + G) * per + tid < numCmds);
+	float4 d0, d1;
+	uint32_t oldw[3];
+	auto load_dependents = [&](const BitsCommand& c, bool liveC, float4& o0, float4& o1, uint32_t* w)
+	{
+		// unconditional, clamped loads (see cluster_hiz_kernel): the command's MeshDraw and its <= 3 visibility words
+		const uint32_t tc = liveC ? c.taskCount : 0u;
+		const float4* dp = reinterpret_cast<const float4*>(a.draws + (tc ? c.drawId : 0u));
+		o0 = dp[0];
+		o1 = dp[1];
+		const uint32_t w0 = tc ? c.mvo >> 5 : 0u, wLast = tc ? (c.mvo + tc - 1u) >> 5 : 0u;
+#pragma unroll
+		for (uint32_t j = 0; j < 3; ++j) // word j holds the bits of lanes [32 j - sh, 32 j - sh + 32)
+			w[j] = a.mvb[w0 + j < wLast ? w0 + j : wLast];
+	};
+	load_dependents(cur, tid < per && chunk * per + tid < numCmds, d0, d1, oldw);
+	// (complete before the loop: otherwise the loop body must assume they may still be in flight, and the wait hipcc then puts
+	// in front of their use covers the youngest prefetches of every later iteration)
+	asm volatile("; prologue loads landed" : "+v"(d0.x), "+v"(d0.y), "+v"(d0.z), "+v"(d0.w), "+v"(d1.x), "+v"(d1.y), "+v"(d1.z), "+v"(d1.w), "+v"(oldw[0]), "+v"(oldw[1]), "+v"(oldw[2]),
+	             "+v"(nxt.drawId), "+v"(nxt.taskOffset), "+v"(nxt.taskCount), "+v"(nxt.mvo));
+
+	for (; chunk * per < numCmds; chunk += G)
+	{
+		const uint32_t idx = chunk * per + tid;
+		const bool live = tid < per && idx < numCmds;
+		const uint32_t taskCount = live ? cur.taskCount : 0u;
+		// clustercull.comp.glsl:86-95: only the clusters whose bit is set can be visible in the early pass
+		uint64_t cand = 0;
+		{
+			const uint32_t sh = cur.mvo & 31u;
+			uint64_t old = 0;
+#pragma unroll
+			for (int j = 0; j < 3; ++j)
+			{
+				const int lo = 32 * j - (int)sh;
+				if (lo >= (int)taskCount)
+					break;
+				old |= lo >= 0 ? (uint64_t)oldw[j] << lo : (uint64_t)(oldw[j] >> (-lo));
+			}
+			const uint64_t valid = taskCount >= 64u ? ~0ull : (1ull << taskCount) - 1ull;
+			cand = old & valid;
+		}
+
+		const uint32_t pc = (uint32_t)__builtin_popcountll(cand);
+		uint32_t incl = pc;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1)
+		{
+			const uint32_t t = __shfl_up(incl, o, 64);
+			if ((int)lane >= o)
+				incl += t;
+		}
+		if (lane == 63)
+			s_part[wave] = incl;
+		if (tid < CB_CMDS)
+		{
+			s_visLo[tid] = (uint32_t)cand;
+			s_visHi[tid] = (uint32_t)(cand >> 32);
+			s_taskOffset[tid] = cur.taskOffset;
+			s_excl[tid] = incl - pc; // (within the wave: the waves before it are added below)
+		}
+
+		// the prefetches, in front of this iteration's entry loads: iteration i + 1's MeshDraw and words, iteration i + 2's command
+		const float4 c0 = d0, c1 = d1; // (this iteration's draw: consumed in the first round)
+		float4 n0, n1;
+		uint32_t neww[3];
+		load_dependents(nxt, tid < per && idx + G * per < numCmds, n0, n1, neww);
+		const uint32_t idx2 = (chunk + 2u * G) * per + tid;
+		const BitsCommand nn = bits_load_command(a, idx2, tid < per && idx2 < numCmds);
+		NV_LDS_BARRIER();
+
+		// the list: the block's waves take the commands in turn, the LANES of a wave on a command's 64 bits — consecutive
+		// addresses.  (A loop over the set bits per lane, every lane expanding its own command, writes with a stride of one
+		// command's entries — at full density 128 B, all lanes on one LDS bank — and leaves the waves that own no command idle.)
+		uint32_t total = 0;
+		{
+			const uint32_t p0 = s_part[0], p1 = s_part[1];
+			total = p0 + p1; // (only commands 0 .. CB_CMDS - 1, i.e. the first two waves, have candidates)
+			if (NV_DBG(a, 67108864u)) // bit 26 (experiments): every lane expands its own command, one set bit at a time
+			{
+				uint32_t at = tid < (uint32_t)CB_CMDS ? s_excl[tid] + (tid >= 64u ? p0 : 0u) : 0u;
+				for (uint64_t rest = cand; rest; rest &= rest - 1)
+					s_list[at++] = (uint16_t)((tid << 6) | (uint32_t)__builtin_ctzll(rest));
+			}
+			else
+			for (uint32_t c = wave; c < per; c += CB_THREADS / 64)
+			{
+				const uint32_t lo = s_visLo[c], hi = s_visHi[c];
+				const uint32_t at = s_excl[c] + (c >= 64u ? p0 : 0u);
+				if ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u)
+					s_list[at + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u))] = (uint16_t)((c << 6) | lane);
+			}
+		}
+		NV_LDS_BARRIER();
+
+		for (uint32_t base = 0; base < total; base += CB_THREADS * CB_U)
+			bits_round<SOA>(a, base, total, tid, base == 0, cand != 0, c0, c1, s_list, s_taskOffset, s_draw, s_cert, s_visLo, s_visHi);
+		NV_LDS_BARRIER();
+		// (the prefetches are consumed HERE, in front of the stores below: vmcnt counts stores too, and a wait for the prefetched
+		// registers at the loop's end would also wait for this iteration's store and atomic to be acknowledged)
+		float4 p0 = n0, p1 = n1;
+		uint32_t pw0 = neww[0], pw1 = neww[1], pw2 = neww[2];
+		BitsCommand pn = nn;
+		asm volatile("; prefetches landed" : "+v"(p0.x), "+v"(p0.y), "+v"(p0.z), "+v"(p0.w), "+v"(p1.x), "+v"(p1.y), "+v"(p1.z), "+v"(p1.w), "+v"(pw0), "+v"(pw1), "+v"(pw2),
+		             "+v"(pn.drawId), "+v"(pn.taskOffset), "+v"(pn.taskCount), "+v"(pn.mvo));
+
+		// ---- one command per lane: the ballot (every command of the range, also those with no bit set) and the tile count
+		uint64_t m = 0;
+		if (live)
+		{
+			m = cand ? ((uint64_t)s_visHi[tid] << 32) | s_visLo[tid] : 0ull;
+			a.masks[idx] = m;
+			// The statistic for the host's choice of the next launch's form (cluster_mask_kernel counts the commands its filter
+			// does not finish): a command with a set bit was visible a frame ago, and nearly always still has a cluster the
+			// filter cannot finish — counting those per entry cost 8 instructions per cluster for a tuning hint.
+			passedAcc += cand ? 1u : 0u;
+		}
+		{
+			const uint32_t tileOf = idx / T2;
+			const uint32_t tile0 = __builtin_amdgcn_readfirstlane(tileOf);
+			const uint32_t pcm = (uint32_t)__builtin_popcountll(m);
+			if (__ballot(pcm != 0 && tileOf != tile0) == 0) // the wave's commands with survivors sit in one tile (lanes are consecutive commands)
+			{
+				const uint32_t sum = wave_sum_u32(pcm);
+				if (lane == 0 && sum)
+					atomicAdd(&a.tileCounts->counts[bank][tile0 * CC_COUNT_STRIDE], sum);
+			}
+			else if (pcm)
+				atomicAdd(&a.tileCounts->counts[bank][tileOf * CC_COUNT_STRIDE], pcm);
+		}
+		NV_LDS_BARRIER(); // the lists are rebuilt by the next iteration
+		cur = nxt;
+		nxt = pn;
+		d0 = p0;
+		d1 = p1;
+		oldw[0] = pw0;
+		oldw[1] = pw1;
+		oldw[2] = pw2;
+	}
+	// the launch's statistic (cluster_mask_kernel: word 1 of a tile counter's line; the scatter kernel sums them)
+	{
+		const uint32_t sum = wave_sum_u32(passedAcc);
+		if (lane == 0 && sum)
+		{
+			const uint32_t numTiles = (numCmds + T2 - 1) / T2;
+			atomicAdd(&a.tileCounts->counts[bank][((blockIdx.x * (CB_THREADS / 64) + wave) % (numTiles ? numTiles : 1u)) * CC_COUNT_STRIDE + 1], sum);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // task-shader form (meshlet.task.glsl:135-143): survivors compacted per command into its 64-entry payload
 template <bool LATE, bool SOA>
 __global__ __launch_bounds__(CC_THREADS) void taskcull_kernel(ClusterArgs a)
@@ -2243,6 +2604,17 @@ bool clustercull_prefers_shallow(uint32_t previousCommandCount) { return previou
 bool clustercull_prefers_direct(uint32_t previousCommandCount, uint32_t previousPassedFilter, uint32_t percent)
 {
 	return previousCommandCount != 0 && (uint64_t)previousPassedFilter * 100u > (uint64_t)previousCommandCount * percent;
+}
+
+// early pass with visibility bits, dense form (one lane per set bit): any grid size (equal contiguous shares per block, grid-stride beyond CB_CMDS commands per block)
+int launch_cluster_bits(hipStream_t stream, const ClusterArgs& a, bool soa, uint32_t gridBlocks)
+{
+	dim3 grid(gridBlocks), block(CB_THREADS);
+	if (soa)
+		hipLaunchKernelGGL((cluster_bits_kernel<true>), grid, block, 0, stream, a);
+	else
+		hipLaunchKernelGGL((cluster_bits_kernel<false>), grid, block, 0, stream, a);
+	return (int)hipGetLastError();
 }
 
 // late pass with HiZ, stage 2: any grid size (grid-stride over blocks of CH_CMDS commands)

@@ -23,6 +23,7 @@ bool clustercull_prefers_shallow(uint32_t previousCommandCount);
 bool clustercull_prefers_direct(uint32_t previousCommandCount, uint32_t previousPassedFilter, uint32_t percent);
 int launch_cluster_scatter(hipStream_t, const ClusterArgs&, uint32_t scatterBlocks, uint32_t waves);
 int launch_cluster_hiz(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
+int launch_cluster_bits(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
 size_t clustercull_mask_bytes();
 size_t clustercull_list_bytes();
 uint32_t clustercull_list_stride();
@@ -101,7 +102,8 @@ struct nv_context
 	uint32_t scatterTilesAbs; // experiments: absolute number of scatter tiles (0 = per CU)
 	uint32_t hizLds; // stage the coarse pyramid levels in LDS for drawcull's late pass (experiments: measured slower)
 	uint32_t directPercent; // share of commands passing the filter above which the next launch skips the filter pass
-	int forceDirect;        // NV_OPT_CULL_FORM: -1 = by the previous launch's statistic, 0 / 1 = always filter / always direct
+	uint32_t bitsBlocksPerCU; // cluster_bits_kernel: grid (blocks per CU)
+	int forceDirect;        // NV_OPT_CULL_FORM: -1 = by the previous launch's statistic, 0 / 1 = always filter / always direct, 2 = direct and never the bit-expanding early form
 	int forceTaskList;      // NV_OPT_TASK_EMIT: -1 = by the statistic of earlier TASK passes, 0 / 1 = per-draw / list form of drawcull's TASK scatter
 	int forceShallow;       // NV_OPT_CULL_RING: -1 = by the previous launch's command count, 0 / 1 = always the 8-deep / the 4-deep ring
 	// command count of the previous clustercull launch, written by its kernel into mapped host memory (tuning hint)
@@ -284,6 +286,7 @@ int nv_create(nv_context** out_ctx, int device)
 	ctx->scatterWaves = 16;
 	ctx->directPercent = 35; // measured crossover (config 3A geometry at several densities): ~36 % of the commands passing the filter
 	ctx->forceDirect = -1;
+	ctx->bitsBlocksPerCU = 4;
 	ctx->forceShallow = -1;
 	ctx->forceTaskList = -1;
 	ctx->listStride = nv::clustercull_list_stride();
@@ -294,6 +297,8 @@ int nv_create(nv_context** out_ctx, int device)
 		ctx->hizLds = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_DIRECT"))
 		ctx->forceDirect = atoi(v);
+	if (const char* v = getenv("NV_BITS_BLOCKS"))
+		ctx->bitsBlocksPerCU = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_DIRECT_PERCENT"))
 		ctx->directPercent = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_SCATTER_TILES_PER_CU"))
@@ -401,9 +406,9 @@ int nv_set_option(nv_context* ctx, int option, int value)
 		ctx->scatterWaves = (uint32_t)value;
 		return NV_OK;
 	case NV_OPT_CULL_FORM:
-		if (value < 0 || value > 2)
+		if (value < 0 || value > 3)
 			return NV_EINVAL;
-		ctx->forceDirect = value - 1; // 0 -> -1 (by statistic), 1 -> 0 (filter form), 2 -> 1 (direct form)
+		ctx->forceDirect = value - 1; // 0 -> -1 (by statistic), 1 -> 0 (filter form), 2 -> 1 (direct form), 3 -> 2 (direct, one command per wave also with visibility bits)
 		return NV_OK;
 	case NV_OPT_TASK_EMIT:
 		if (value < 0 || value > 2)
@@ -773,7 +778,14 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	// with one lane per survivor (clustercull.hip cluster_hiz_kernel: visibility bits, skip, tile counts), the scatter.
 	const bool twoStage = late && cull->clusterOcclusionEnabled == 1 && !(ctx->debugMode & 2097152u); // bit 21 (experiments): the probe inside the cull kernel (r1 form)
 	a.deferHiz = twoStage ? 1u : 0u;
-	rc = nv::launch_cluster_mask(s, a, twoStage ? 0 : late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), shallow, direct);
+	// Early pass with visibility bits where the filter would not pay: one lane per SET BIT instead of one wave per command
+	// (clustercull.hip cluster_bits_kernel; without bits every valid cluster would be an entry and one wave per command is
+	// faster).  NV_OPT_CULL_FORM 3 keeps the one-command-per-wave direct form.
+	const bool bitsForm = !late && direct && ctx->forceDirect != 2 && cull->clusterOcclusionEnabled == 1 && cull->postPass == 0;
+	if (bitsForm)
+		rc = nv::launch_cluster_bits(s, a, a.soaBounds != nullptr, persistent_grid(ctx, ctx->bitsBlocksPerCU));
+	else
+		rc = nv::launch_cluster_mask(s, a, twoStage ? 0 : late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), shallow, direct);
 	hipEvent_t e1 = prof_mark(ctx, s);
 	hipEvent_t eh = e1;
 	if (rc == 0 && twoStage)

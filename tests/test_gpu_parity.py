@@ -524,7 +524,7 @@ def test_pinned_kernel_variants_equal_the_oracle(ctx):
             cib_o, cc4_o = np.zeros(n * 64, np.uint32), np.zeros(4, np.uint32)
             oracle.clustercull(cd, 0, commands, c4, draws, meshlets, None, None, cib_o, cc4_o, threads=oracle.max_threads())
             total = int(cc4_o[0])
-            for form in (0, 1, 2):
+            for form in (0, 1, 2, 3):
                 for ring in (0, 4, 8):
                     ctx.set_option(P.NV_OPT_CULL_FORM, form)
                     ctx.set_option(P.NV_OPT_CULL_RING, ring)
@@ -532,7 +532,7 @@ def test_pinned_kernel_variants_equal_the_oracle(ctx):
                     ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
                     assert int(ccb[0].item()) == total, (radius_note, form, ring)
                     assert (G.host_u32(cib)[:total] == cib_o[:total]).all(), (radius_note, form, ring)
-        for opt, bad in ((P.NV_OPT_CULL_FORM, 3), (P.NV_OPT_CULL_RING, 5)):
+        for opt, bad in ((P.NV_OPT_CULL_FORM, 4), (P.NV_OPT_CULL_RING, 5)):
             with pytest.raises(P.NvError):
                 ctx.set_option(opt, bad)
     finally:
@@ -904,6 +904,15 @@ def test_cone_test_is_exact_on_the_threshold(ctx):
     c2["pyramidWidth"], c2["pyramidHeight"], c2["clusterOcclusionEnabled"] = pyr.width, pyr.height, 1
     _compare_cluster_pass(ctx, draws, meshlets, commands, n, c2, 1, mvb0, pyr, gp)
     _compare_cluster_pass(ctx, draws, meshlets, commands, n, c2, 0, mvb0, pyr, gp)
+    # ... and the early pass in its pinned dense forms with every bit set: one lane per set bit (2), one wave per command (3)
+    ones = np.full(n * 2 + 3, 0xffffffff, np.uint32)
+    try:
+        for form in (2, 3):
+            ctx.set_option(P.NV_OPT_CULL_FORM, form)
+            t = _compare_cluster_pass(ctx, draws, meshlets, commands, n, c2, 0, ones, pyr, gp)
+            assert t == total
+    finally:
+        ctx.set_option(P.NV_OPT_CULL_FORM, 0)
 
 
 @pytest.mark.parametrize("scale", [1.0, 37.5, 1e-3, 5e3, float("inf"), float("nan")])
@@ -1094,6 +1103,87 @@ def test_dense_passes_switch_to_the_direct_form(ctx, soa):
                         totals.append(_compare_cluster_pass(ctx, draws, meshlets, commands, n, c, late, mvb0, pyr, gp, soa))
                     _compare_cluster_pass(ctx, draws, meshlets, commands, n, sparse, late, mvb0, pyr, gp, soa)
     assert max(totals) > 0.3 * n * 64
+
+
+@pytest.mark.parametrize("soa", [True, False])
+def test_early_pass_bit_expanding_form(ctx, soa):
+    """The early pass with visibility bits in its dense form tests one lane per SET BIT (cluster_bits_kernel) instead of one wave
+    per command.  Pinned forms 1 (filter), 2 (direct: the bit-expanding kernel) and 3 (direct, one command per wave) on a dense view:
+    ragged task counts, visibility offsets that share words between commands, bit densities from none to all, backface on and
+    off, a pass of three commands and one of none — IDs and count equal the oracle's and no visibility word changes; then the
+    adversarial geometry of the plane and cone-threshold tests with every bit set, where the certified per-lane test must fall
+    back to the reference arithmetic."""
+    rng = np.random.default_rng(77)
+    draws, meshlets, commands, n, cd = _cluster_inputs(700, 6, seed=5)
+    draws["position"] *= np.float32(0.05)
+    dense = host.build_cull_data(cam_pos=(0, 0, 25), draw_count=len(draws), cullingEnabled=1, clusterBackfaceEnabled=1, clusterOcclusionEnabled=1)
+    commands["taskCount"][:n:5] = rng.integers(0, 65, len(commands["taskCount"][:n:5]))
+    tc = commands["taskCount"][:n].astype(np.int64)
+    packed = np.concatenate([[0], np.cumsum(tc)[:-1]]) + 7                     # slots packed back to back: words shared by neighbours
+    commands["meshletVisibilityOffset"][:n] = packed.astype(np.uint32)
+    words = int(packed[-1] + 64) // 32 + 4
+    totals = []
+    try:
+        for form in (2, 3, 1, 0):
+            ctx.set_option(P.NV_OPT_CULL_FORM, form)
+            for density in (0.0, 0.03, 0.3, 1.0):
+                bits = rng.random(words * 32) < density
+                mvb0 = np.packbits(bits.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).ravel()
+                for cbe in (1, 0):
+                    c = dense.copy()
+                    c["clusterBackfaceEnabled"] = cbe
+                    totals.append(_compare_cluster_pass(ctx, draws, meshlets, commands, n, c, 0, mvb0, None, None, soa))
+            few = commands[:64].copy()
+            few[3:] = 0
+            _compare_cluster_pass(ctx, draws, meshlets, few, 3, dense, 0, mvb0, None, None, soa)
+            _compare_cluster_pass(ctx, draws, meshlets, few, 0, dense, 0, mvb0, None, None, soa)
+        assert max(totals) > 0.2 * n * 64 and min(totals) == 0
+
+        # ---- on the planes and on the cone threshold, every bit set, bit-expanding form
+        ctx.set_option(P.NV_OPT_CULL_FORM, 2)
+        n_draws, cpd = 300, 2
+        d2 = host.synth_draws(n_draws, 1, 60.0)
+        c2 = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, clusterBackfaceEnabled=1, clusterOcclusionEnabled=1, draw_distance=80.0)
+        cm2 = synth.make_task_commands(n_draws, cpd)
+        n2 = n_draws * cpd
+        m2 = synth.make_meshlets(n2 * 64, seed=29)
+        f = c2["frustum"][0]
+        for i in range(n_draws):
+            z = np.float32(rng.uniform(2, 70))
+            kind = i % 5
+            if kind == 0:
+                x, y = z * f[1] / f[0] * (1 if i % 10 < 5 else -1), np.float32(rng.uniform(-0.3, 0.3)) * z
+            elif kind == 1:
+                x, y = np.float32(rng.uniform(-0.3, 0.3)) * z, z * f[3] / f[2] * (1 if i % 10 < 5 else -1)
+            elif kind == 2:
+                x, y, z = 0.0, 0.0, np.float32(0.1)
+            elif kind == 3:
+                x, y, z = 0.0, 0.0, np.float32(80.0)
+            else:
+                x, y = np.float32(rng.uniform(-0.5, 0.5)) * z, np.float32(rng.uniform(-0.5, 0.5)) * z
+            d2["position"][i] = (x, y, -z)
+            d2["scale"][i] = np.float32(rng.choice([1e-3, 0.5, 1.0, 3.0]))
+        cc = (rng.normal(size=(n2 * 64, 3)) * 10 ** rng.uniform(-6, -1, (n2 * 64, 1))).astype(np.float16)
+        m2["center"] = cc.view(np.uint16)
+        rr = (10 ** rng.uniform(-7, -1, n2 * 64)).astype(np.float16)
+        rr[::17] = 0
+        m2["radius"] = rr.view(np.uint16)
+        bad = rng.integers(0, n2 * 64, 200)
+        m2["center"][bad[:50], 0] = 0x7e00
+        m2["center"][bad[50:100], 1] = 0x7c00
+        m2["radius"][bad[100:150]] = 0x7bff
+        m2["radius"][bad[150:]] = 0xfc00
+        # generic draws: cone cutoffs that put the meshlets near the cone threshold (axis towards the camera, cutoff around dot / |c|)
+        m2["cone_cutoff"][::3] = rng.integers(-127, 128, len(m2["cone_cutoff"][::3])).astype(np.int8)
+        ones = np.full(n2 * 2 + 3, 0xffffffff, np.uint32)
+        t = _compare_cluster_pass(ctx, d2, m2, cm2, n2, c2, 0, ones, None, None, soa)
+        assert 0.01 * n2 * 64 < t < 0.99 * n2 * 64
+        d2["orientation"] *= np.float32(7.5)
+        d2["position"][::5] *= np.float32(1e6)
+        d2["scale"][::7] = np.float32(np.nan)
+        _compare_cluster_pass(ctx, d2, m2, cm2, n2, c2, 0, ones, None, None, soa)
+    finally:
+        ctx.set_option(P.NV_OPT_CULL_FORM, 0)
 
 
 @pytest.mark.parametrize("soa", [True, False])
