@@ -102,6 +102,12 @@ struct ClusterArgs
 	uint32_t scatterTiles; // grid of the scatter kernel (<= CC_MAX_SCATTER_TILES)
 	uint32_t generations;  // workgroups of the cull kernel per CU (its grid = generations x CUs)
 	uint32_t dealScale;    // percent of the nominal start-delay compensation of the dealing (tuning; 100)
+	// Divisions by launch constants, prepared by the host (context.hip magic_for): q = mulhi(n, magic) >> 7, exact for n < 2^39 / d;
+	// 0 = not available (d < 256 or > 8192: the kernels divide).  The cull launch's prologue is on every wave's start-up path and
+	// an instruction there costs what one per command costs in the filter loop (filler_sensitivity.sh).
+	uint32_t cullWavesMagic;  // d = waves of the cull launch (grid x 4)
+	uint32_t genBlocks, genBlocksMagic; // d = workgroups per generation of the cull launch (grid / generations)
+	uint32_t tilesMagic;      // d = scatterTiles
 	float filterK;         // 4 K u S of the conservative filter / certified test (clustercull.hip make_filter); 0 = both off
 	uint32_t* hostHint;    // mapped host word: the cull kernel leaves its command count here for the next launch's tuning
 	uint32_t commandCountOverride; // probe/taskcull: explicit command count (0 = use count4[1]*64)

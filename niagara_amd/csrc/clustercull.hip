@@ -865,9 +865,16 @@ NV_DEV void ring_release(SlotB& s) { asm volatile("; released %0 %1 %2" : "+v"(s
 NV_DEV void ring_release(SlotT& s) { asm volatile("; released %0 %1 %2 %3" : "+v"(s.t00), "+v"(s.t10), "+v"(s.t01), "+v"(s.t11)); }
 
 // commands per scatter tile: the same function of the indirect words in both kernels
-NV_DEV uint32_t scatter_tile_commands(uint32_t numCmds, uint32_t tiles)
+// n / d for a launch constant d whose magic the host prepared (ClusterArgs): one s_mul_hi_u32 and a shift instead of the ~18
+// instructions of a 32-bit division by a run-time value
+NV_DEV uint32_t div_launch_constant(uint32_t n, uint32_t d, uint32_t magic)
 {
-	uint32_t T = ((numCmds + tiles - 1) / tiles + CC_THREADS - 1) / CC_THREADS * CC_THREADS;
+	return magic ? __umulhi(n, magic) >> 7 : n / d;
+}
+
+NV_DEV uint32_t scatter_tile_commands(uint32_t numCmds, uint32_t tiles, uint32_t tilesMagic)
+{
+	uint32_t T = (div_launch_constant(numCmds + tiles - 1, tiles, tilesMagic) + CC_THREADS - 1) / CC_THREADS * CC_THREADS;
 	return T ? T : CC_THREADS;
 }
 
@@ -896,25 +903,27 @@ NV_DEV bool __all_quad_same(uint32_t v, uint32_t ref)
 // chunk, or the plain round-robin when the pass is not weighted (other grid shapes, tiny passes, or more than 64
 // chunks per wave — where a start-up delay of a few commands no longer matters).
 NV_DEV uint32_t make_dealing(uint32_t numChunks, uint32_t wave, uint32_t lane, uint32_t generations, uint32_t gen, bool weighted, uint32_t scalePercent,
-                             uint32_t* chunkOf, bool* isWeighted)
+                             uint32_t wavesMagic, uint32_t genBlocks, uint32_t* chunkOf, bool* isWeighted)
 {
 	const uint32_t W = gridDim.x * CC_WAVES;
 	const uint32_t w = blockIdx.x * CC_WAVES + wave;
 	*chunkOf = lane * W + w;
 	*isWeighted = false;
-	const uint32_t perWaveChunks = numChunks / W;
+	const uint32_t perWaveChunks = div_launch_constant(numChunks, W, wavesMagic);
 	const uint32_t even = perWaveChunks + (w < numChunks - perWaveChunks * W ? 1u : 0u);
-	if (!weighted || generations != 6u || gridDim.x % 6u != 0u || perWaveChunks < 4u || perWaveChunks >= 60u)
+	if (!weighted || generations != 6u || genBlocks * 6u != gridDim.x || perWaveChunks < 4u || perWaveChunks >= 60u)
 		return even;
-	const uint32_t genWaves = W / 6u;
+	const uint32_t genWaves = genBlocks * CC_WAVES;
 	// delays in 1/16 command: { 0, 0.5, 2.4, 4.2, 7.1, 13.1 }, mean 4.55
 	const int delay16[6] = { 0, 8, 38, 67, 114, 210 };
-	const int perWave16 = (int)((numChunks * (CC_CHUNK * 16u)) / W); // numChunks < 2^22 / CC_CHUNK: no overflow
+	const int perWave16 = (int)div_launch_constant(numChunks * (CC_CHUNK * 16u), W, wavesMagic); // numChunks < 2^22 / CC_CHUNK: no overflow, and < 2^39 / W
 	uint32_t roundsOf[6], weightedTotal = 0;
 #pragma unroll
 	for (int k = 0; k < 6; ++k)
 	{
-		const int target16 = perWave16 + ((int)scalePercent * (73 - delay16[k])) / 100 - (int)(CC_CHUNK * 16u); // keep one even round for the remainder
+		// (the nominal scale is a constant per generation; any other one divides)
+		const int adjust16 = scalePercent == 100u ? 73 - delay16[k] : ((int)scalePercent * (73 - delay16[k])) / 100;
+		const int target16 = perWave16 + adjust16 - (int)(CC_CHUNK * 16u); // keep one even round for the remainder
 		roundsOf[k] = target16 > 0 ? (uint32_t)target16 / (CC_CHUNK * 16u) : 0u;
 		weightedTotal += roundsOf[k] * genWaves;
 	}
@@ -923,10 +932,11 @@ NV_DEV uint32_t make_dealing(uint32_t numChunks, uint32_t wave, uint32_t lane, u
 	if (weightedTotal > numChunks) // cannot happen (floors of targets that sum to less than the total); stay safe
 		return even;
 	const uint32_t rest = numChunks - weightedTotal;
+	const uint32_t restPerWave = div_launch_constant(rest, W, wavesMagic);
 	// the lane-parallel table holds 64 chunks; decided for the whole grid at once (every wave must take the same branch)
-	if (roundsOf[0] + rest / W + 1u > 64u)
+	if (roundsOf[0] + restPerWave + 1u > 64u)
 		return even;
-	const uint32_t mine = rounds + rest / W + (w < rest % W ? 1u : 0u);
+	const uint32_t mine = rounds + restPerWave + (w < rest - restPerWave * W ? 1u : 0u);
 	// lane j: round j of the weighted part (chunks of earlier rounds = genWaves * sum over generations of min(j, roundsOf)),
 	// then the even remainder
 	uint32_t before = 0;
@@ -973,7 +983,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 	// a CU got its first data 11 k cycles after the first one)
 	if (!NV_DBG(a, 262144u)) // bit 18 (experiments)
 		__builtin_amdgcn_s_setprio(3);
-	const uint32_t gen = blockIdx.x / (gridDim.x / 6u ? gridDim.x / 6u : 1u);
+	const uint32_t gen = a.genBlocks ? div_launch_constant(blockIdx.x, a.genBlocks, a.genBlocksMagic) : 0u; // (workgroups are numbered generation-major)
 	const uint32_t numCmds = indirect_command_count(a);
 	if (a.hostHint && blockIdx.x == 0 && threadIdx.x == 0)
 		__hip_atomic_store(a.hostHint, numCmds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -981,9 +991,9 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 	const uint32_t numChunks = (numCmds + CH - 1) / CH;
 	uint32_t chunkOf;
 	bool dealtWeighted;
-	const uint32_t myChunks = make_dealing(numChunks, wave, lane, a.generations, gen, !LATE && !NV_DBG(a, 32768u), a.dealScale, &chunkOf, &dealtWeighted); // (late pass: even — the weights are calibrated on the early pass, and the extra state costs the late variants two resident workgroups per CU) // bit 15 (experiments): even dealing
+	const uint32_t myChunks = make_dealing(numChunks, wave, lane, a.generations, gen, !LATE && !NV_DBG(a, 32768u), a.dealScale, a.cullWavesMagic, a.genBlocks, &chunkOf, &dealtWeighted); // (late pass: even — the weights are calibrated on the early pass, and the extra state costs the late variants two resident workgroups per CU) // bit 15 (experiments): even dealing
 	const uint32_t myCmds = myChunks * CH; // the last chunk of the pass may run past numCmds: guarded below
-	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles);
+	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles, a.tilesMagic);
 	const uint32_t bank = load_uniform_u32(&a.tileCounts->parity) & 1u;
 	if (w == 0 && lane == 0)
 	{
@@ -1000,6 +1010,17 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 		stamps[6] = wall_clock64(); // 100 MHz, chip-wide: comparable across CUs (the cycle counter is not)
 
 	uint32_t passedFilter = 0; // commands of this wave the conservative filter does not finish (DIRECT: would not have finished)
+	// (the same per WAVE, in front of its first segment: NV_FILLER_PS / NV_FILLER_PV)
+#if defined(NV_FILLER_PS)
+#pragma unroll
+	for (int f = 0; f < NV_FILLER_PS; ++f)
+		asm volatile("s_cmp_eq_u32 0, 0" : : : "scc");
+#endif
+#if defined(NV_FILLER_PV)
+#pragma unroll
+	for (int f = 0; f < NV_FILLER_PV; ++f)
+		asm volatile("v_nop");
+#endif
 	for (uint32_t seg = 0; seg < myCmds; seg += 64)
 	{
 		const uint32_t cnt = myCmds - seg < 64u ? myCmds - seg : 64u;
@@ -1097,6 +1118,20 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 					const uint32_t mvo = __builtin_amdgcn_readlane(r.meshletVisibilityOffset, c);
 					offw = tc ? ((mvo + (lane < tc ? lane : 0u)) >> 5) * 4u : 0u;
 				}
+				// Sensitivity of the launch to its instruction mix ("no experiment has isolated SALU count"): builds with
+				// -DNV_FILLER_S=n / -DNV_FILLER_V=n issue n more scalar / vector instructions per command here (register-free, results
+				// unchanged; tools/experiments/filler_sensitivity.sh).  Compile-time: a run-time switch in this lambda — even around
+				// an empty statement — costs the kernel 13 VGPRs and a scratch frame.
+#if defined(NV_FILLER_S)
+#pragma unroll
+				for (int f = 0; f < NV_FILLER_S; ++f)
+					asm volatile("s_cmp_eq_u32 0, 0" : : : "scc");
+#endif
+#if defined(NV_FILLER_V)
+#pragma unroll
+				for (int f = 0; f < NV_FILLER_V; ++f)
+					asm volatile("v_nop");
+#endif
 				ringA_issue<BITS_A>(slot, a, off8, offw, order);
 			};
 
@@ -1548,7 +1583,7 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
 	const uint32_t numCmds = indirect_command_count(a);
-	const uint32_t T = scatter_tile_commands(numCmds, a.scatterTiles);
+	const uint32_t T = scatter_tile_commands(numCmds, a.scatterTiles, a.tilesMagic);
 	const uint32_t numTiles = (numCmds + T - 1) / T; // <= gridDim.x
 	const uint32_t tile = blockIdx.x;
 	const bool dbgNoScatter = NV_DBG(a, 4u); // experiments only
@@ -1906,7 +1941,7 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 	const uint32_t count1 = load_uniform_u32(&a.tileCounts->listCount[1][sub * CC_COUNT_STRIDE]);
 	const uint32_t over0 = load_uniform_u32(&a.tileCounts->listOverflow[0]), over1 = load_uniform_u32(&a.tileCounts->listOverflow[1]);
 	const uint32_t numCmds = indirect_command_count(a);
-	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles);
+	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles, a.tilesMagic);
 	const bool scan = (bank ? over1 : over0) != 0;
 	const uint32_t items = scan ? numCmds : (bank ? count1 : count0);
 	const uint32_t share = scan ? gridDim.x : sharers;
@@ -2277,7 +2312,7 @@ __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs
 	const uint32_t numCmds = indirect_command_count(a);
 	if (a.hostHint && blockIdx.x == 0 && tid == 0)
 		__hip_atomic_store(a.hostHint, numCmds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles);
+	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles, a.tilesMagic);
 	const uint32_t bank = load_uniform_u32(&a.tileCounts->parity) & 1u;
 	if (blockIdx.x == 0 && tid == 0)
 	{

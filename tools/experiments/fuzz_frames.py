@@ -4,6 +4,7 @@ frames of the HIP passes, every buffer of every phase compared with the oracle (
 tests/test_gpu_parity.py::test_two_frame_protocol, wider parameter space).  Needs a GPU.
 
     python tools/experiments/fuzz_frames.py [seconds=120] [first_seed=1000]
+    FUZZ_CULL_FORM=2 ...   pins NV_OPT_CULL_FORM (2: the early passes with visibility bits run cluster_bits_kernel from the first frame on)
 """
 import os
 import sys
@@ -22,6 +23,8 @@ from scenes import make_scene, random_case  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 ctx = P.Context(0)
+if os.environ.get("FUZZ_CULL_FORM"):
+    ctx.set_option(P.NV_OPT_CULL_FORM, int(os.environ["FUZZ_CULL_FORM"]))
 t0 = time.time()
 runs = bad = 0
 while time.time() - t0 < budget:
