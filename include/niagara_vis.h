@@ -391,6 +391,9 @@ uint32_t nv_previous_pow2(uint32_t v);                        /* src/niagara.cpp
 uint32_t nv_image_mip_levels(uint32_t width, uint32_t height); /* src/resources.cpp:280-292 */
 /* fills width/height/levels/mipOffset/totalTexels from the depth target size; d_base untouched */
 int nv_pyramid_desc_init(NvPyramidDesc* desc, uint32_t depthWidth, uint32_t depthHeight);
+/* the multiplier with which the kernels divide by a launch constant d (grid sizes): mulhi(n, m) >> 7 == n / d for every
+ * n < 2^39 / d; 0 (the kernels then divide) for d outside 256 .. 8192.  Exported so that the bound can be tested. */
+uint32_t nv_division_magic(uint32_t d);
 /* src/niagara.cpp:424-437,1487-1516: CullData from a camera (position, orientation quat xyzw, fovY,
  * znear), viewport, draw distance and pyramid size; flags are left 0 for the caller to set. */
 int nv_build_cull_data(NvCullData* out, const float cameraPosition[3], const float cameraOrientation[4],

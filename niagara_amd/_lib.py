@@ -71,6 +71,7 @@ _SIGS = {
     "nv_trianglecull": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "nv_depthreduce": (_i, [_vp, _vp, _vp, _u32, _u32, C.POINTER(PyramidDesc)]),
     "nv_previous_pow2": (_u32, [_u32]),
+    "nv_division_magic": (_u32, [_u32]),
     "nv_image_mip_levels": (_u32, [_u32, _u32]),
     "nv_pyramid_desc_init": (_i, [C.POINTER(PyramidDesc), _u32, _u32]),
     "nv_build_cull_data": (_i, [_vp, _vp, _vp, _f, _f, _f, _u32, _u32, _u32, _u32, _u32, _i]),

@@ -721,14 +721,13 @@ static int fill_cluster_args(nv_context* ctx, nv::ClusterArgs& a, const NvCullDa
 	a.generations = ctx->ccBlocksPerCU;
 	a.dealScale = ctx->dealScale;
 	{
-		// divisions by launch constants, for the kernels' prologues (args.h): magic = floor(2^39 / d) + 1 fits 32 bits for d >= 256,
-		// and mulhi(n, magic) >> 7 == n / d for n < 2^39 / d — the largest numerator is 64 x the chunk count < 2^26, d <= 8192
-		auto magic_for = [](uint32_t d) -> uint32_t { return d >= 256u && d <= 8192u ? (uint32_t)((1ull << 39) / d) + 1u : 0u; };
+		// divisions by launch constants, for the kernels' prologues (args.h, host.cpp nv_division_magic): exact for n < 2^39 / d — the
+		// largest numerator is 64 x the chunk count < 2^26, d <= 8192
 		const uint32_t cullGrid = persistent_grid(ctx, ctx->ccBlocksPerCU);
-		a.cullWavesMagic = magic_for(cullGrid * 4u);
+		a.cullWavesMagic = nv_division_magic(cullGrid * 4u);
 		a.genBlocks = cullGrid / 6u ? cullGrid / 6u : 1u;
-		a.genBlocksMagic = magic_for(a.genBlocks);
-		a.tilesMagic = magic_for(a.scatterTiles);
+		a.genBlocksMagic = nv_division_magic(a.genBlocks);
+		a.tilesMagic = nv_division_magic(a.scatterTiles);
 	}
 	// Margin scale of the conservative filter / certified test (clustercull.hip make_filter): 4 K u S with K = 48,
 	// u = 2^-24 and S = max(1, |f0| + |f1|, |f2| + |f3|) — the error analysis is written for unit-length plane

@@ -10,6 +10,13 @@
 extern "C" {
 
 // src/niagara.cpp:439-447 — largest power of two strictly below v (1 for v <= 2)
+// n / d for a launch constant d: m = floor(2^39 / d) + 1 = 2^39 / d + e with 0 < e <= 1, so n m / 2^39 = n / d + n e / 2^39 and the
+// floor is that of n / d while n e / 2^39 < 1 / d, i.e. for n < 2^39 / d; m fits 32 bits for d >= 256 (kernels: args.h)
+uint32_t nv_division_magic(uint32_t d)
+{
+	return d >= 256u && d <= 8192u ? (uint32_t)((1ull << 39) / d) + 1u : 0u;
+}
+
 uint32_t nv_previous_pow2(uint32_t v)
 {
 	uint32_t r = 1;

@@ -74,3 +74,23 @@ def test_s8_over_127_is_exact():
         q2 = rn(Fraction(float(q)) + Fraction(float(r)) * fc)
         assert q2 == np.float32(k) / np.float32(127.0), k
         assert q2 == rn(Fraction(k, 127)), k
+
+
+def test_division_magic_is_exact_where_the_kernels_use_it():
+    """nv_division_magic (host.cpp): mulhi(n, m) >> 7 == n // d for every d it serves (256 .. 8192) and every n < 2^39 / d — the
+    cull launch divides chunk counts (< 2^20), 64 x chunk counts (< 2^26), workgroup indices and command counts (< 2^23) by its grid
+    constants this way (clustercull.hip div_launch_constant).  Checked at the multiples of d and their neighbours, at random n and
+    at the top of the range; outside the served divisors the magic is 0 and the kernels divide."""
+    from niagara_amd._lib import lib
+    rng = np.random.default_rng(5)
+    for d in list(range(256, 8193, 7)) + [256, 257, 1024, 1536, 4096, 6144, 8191, 8192]:
+        m = int(lib.nv_division_magic(d))
+        assert 0 < m < 2 ** 32
+        top = (1 << 39) // d
+        q = rng.integers(0, top // d, 64, dtype=np.int64)
+        n = np.concatenate([q * d, q * d + d - 1, q * d + 1, rng.integers(0, top, 256, dtype=np.int64), [0, 1, d - 1, d, top - 1, (1 << 26) - 1]])
+        n = n[(n >= 0) & (n < top)]
+        got = [((int(x) * m) >> 32) >> 7 for x in n]
+        assert got == [int(x) // d for x in n], d
+    for d in (0, 1, 42, 255, 8193, 1 << 20):
+        assert int(lib.nv_division_magic(d)) == 0
