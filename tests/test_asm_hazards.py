@@ -1,8 +1,9 @@
 """The hazard recognizer of hipcc does not look inside inline asm (clustercull.hip, rules above SlotA): every asm statement
 that reads an SGPR a VALU instruction produced just before it must bring its own s_nop.  tools/check_asm_hazards.py
-compiles the file to gfx950 ISA and checks that, and (check 2) that no instruction touches a ring register between the
-asm statement that issues its load and the asm statement that waits for it; this test runs both on the real file and
-feeds each scanner a violation."""
+compiles the file to gfx950 ISA and checks that, (check 2) that no instruction touches a ring register between the
+asm statement that issues its load and the asm statement that waits for it, and (check 3) that every hand-counted
+vmcnt(N) has at least N younger vector-memory operations behind the load it names on every path; this test runs them on the
+real file and feeds each scanner a violation."""
 import importlib.util
 import os
 import shutil
@@ -43,6 +44,31 @@ def test_scanner_flags_a_touched_in_flight_register():
     branchy = kernel[:4] + ["\ts_cbranch_scc1 .LBB0_2", "\t;;#ASMSTART", "\ts_waitcnt vmcnt(0) ; nv_ready v[0:1]", "\t;;#ASMEND",
                             ".LBB0_2:", "\tv_mov_b32_e32 v3, v0", "\ts_endpgm"]
     assert len(chk.scan_inflight("k", branchy)) >= 1
+
+
+def test_scanner_flags_a_counted_wait_that_is_too_weak():
+    """check 3: vmcnt(N) that names a slot needs N younger vector-memory operations behind the slot's load on EVERY path"""
+    def ring(n_younger, count, extra=()):
+        k = ["\t;;#ASMSTART", "\ts_nop 4", "\tglobal_load_dwordx2 v[0:1], v20, s[28:29]", "\t;;#ASMEND"]
+        for i in range(n_younger):
+            k += ["\t;;#ASMSTART", "\ts_nop 4", "\tglobal_load_dwordx2 v[%d:%d], v20, s[28:29]" % (2 + 2 * i, 3 + 2 * i), "\t;;#ASMEND"]
+        k += list(extra)
+        k += ["\t;;#ASMSTART", "\ts_waitcnt vmcnt(%d) ; nv_ready v[0:1]" % count, "\t;;#ASMEND", "\tv_mul_f32_e32 v40, v0, v1",
+              "\t;;#ASMSTART", "\ts_waitcnt vmcnt(0) ; nv_ready all", "\t;;#ASMEND", "\ts_endpgm"]
+        return k
+
+    assert chk.scan_counts("k", ring(3, 3)) == []
+    assert chk.scan_counts("k", ring(3, 2)) == []                       # stricter than needed is fine
+    weak = chk.scan_counts("k", ring(2, 3))                             # only two younger loads: the slot may be one of the three outstanding
+    assert [(r, k, n) for _, _, r, k, n in weak] == [(0, 2, 3), (1, 2, 3)]
+    # a compiler-issued store between issue and wait counts (vmcnt counts stores on gfx9) ...
+    assert chk.scan_counts("k", ring(2, 3, extra=["\tglobal_store_dword v30, v31, s[4:5]"])) == []
+    # ... but not when it sits on one side of a branch only: the weakest path decides
+    branchy = ring(2, 3, extra=["\ts_cbranch_scc1 .LBB0_2", "\tglobal_store_dword v30, v31, s[4:5]", ".LBB0_2:"])
+    assert len(chk.scan_counts("k", branchy)) == 2
+    # a loop that reissues the slot: the count restarts at the reissue
+    loop = [".LBB0_1:"] + ring(3, 3)[:-4] + ["\ts_cbranch_scc1 .LBB0_1"] + ring(3, 3)[-4:]
+    assert chk.scan_counts("k", loop) == []
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
