@@ -109,6 +109,11 @@ struct ClusterArgs
 	uint32_t genBlocks, genBlocksMagic; // d = workgroups per generation of the cull launch (grid / generations)
 	uint32_t tilesMagic;      // d = scatterTiles
 	float filterK;         // 4 K u S of the conservative filter / certified test (clustercull.hip make_filter); 0 = both off
+	// what make_filter derives from the view matrix alone, done once on the host in the same fp32 operations (context.hip view_norms):
+	// every wave computed these ~40 instructions in its prologue, and an instruction there costs what 1 / 25 per command costs (§4.1)
+	float viewRowNorm;     // max over rows r of |V(r,0)| + |V(r,1)| + |V(r,2)|
+	float viewTransNorm;   // max over rows r of |V(r,3)|
+	float viewSum;         // the sum of the twelve entries, in make_filter's order: 0 x it is 0, or NaN for a non-finite view
 	uint32_t* hostHint;    // mapped host word: the cull kernel leaves its command count here for the next launch's tuning
 	uint32_t commandCountOverride; // probe/taskcull: explicit command count (0 = use count4[1]*64)
 	float* __restrict__ probeOut;

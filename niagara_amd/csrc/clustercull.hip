@@ -427,7 +427,7 @@ struct FilterDraw
 // filterK = 4 K u S (rounded up), S = max(1, |f0| + |f1|, |f2| + |f3|) of the frustum coefficients: the margins above
 // assume |f| <= 1; the host scales them for other coefficients and passes 0 (no filter, no certified test) for
 // non-finite or absurd ones (fill_cluster_args).
-NV_DEV FilterDraw make_filter(const NvCullData& cd, const DrawUniform& u, float filterK)
+NV_DEV FilterDraw make_filter(const NvCullData& cd, const DrawUniform& u, float filterK, float Vn, float V3n, float sumV)
 {
 	const float x = u.q.x, y = u.q.y, z = u.q.z, w = u.qw, s = u.scale;
 	// R = (1 - 2|q_xyz|^2) I + 2 q q^T + 2 w [q]x  (valid for any q, unit or not) — same map as rotateQuat
@@ -453,13 +453,8 @@ NV_DEV FilterDraw make_filter(const NvCullData& cd, const DrawUniform& u, float 
 	}
 	const float Qa = __builtin_fabsf(x) + __builtin_fabsf(y) + __builtin_fabsf(z);
 	const float rotAbs = 1.0f + 2.0f * Qa * (Qa + __builtin_fabsf(w));
-	float Vn = 0.0f, V3n = 0.0f;
-#pragma unroll
-	for (int r = 0; r < 3; ++r)
-	{
-		Vn = __builtin_fmaxf(Vn, __builtin_fabsf(V[r]) + __builtin_fabsf(V[4 + r]) + __builtin_fabsf(V[8 + r]));
-		V3n = __builtin_fmaxf(V3n, __builtin_fabsf(V[12 + r]));
-	}
+	// (Vn, V3n = the row norms of the view matrix's linear part and of its translation, sumV = the sum of its twelve entries:
+	// the host's, ClusterArgs::viewRowNorm ..., computed with the operations that stood here)
 	const float pn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(u.pos.x), __builtin_fabsf(u.pos.y)), __builtin_fabsf(u.pos.z));
 	const float alpha = Vn * __builtin_fabsf(s) * rotAbs;
 	const float beta = Vn * pn + V3n;
@@ -467,10 +462,6 @@ NV_DEV FilterDraw make_filter(const NvCullData& cd, const DrawUniform& u, float 
 	// non-finite draw or view fields are caught by a sum that is 0 or NaN, and magnitudes outside a generous range
 	// (every intermediate of both chains, including the certified cone test's products, then stays far from the fp32
 	// limits) make the margin infinite: nothing is certain for such a draw and the reference arithmetic decides.
-	float sumV = 0.0f;
-#pragma unroll
-	for (int i = 0; i < 15; ++i)
-		sumV += (i & 3) == 3 ? 0.0f : V[i];
 	const float poison = 0.0f * ((((x + y) + (z + w)) + (s + ((u.pos.x + u.pos.y) + u.pos.z))) + sumV); // 0, or NaN
 	const bool sane = alpha <= 1e12f && beta <= 1e12f && __builtin_fabsf(s) >= 1e-15f;
 	f.aK = filterK * alpha;
@@ -1047,7 +1038,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				r.d0 = d[0];
 				r.d1 = d[1];
 			}
-			r.f = make_filter(a.cd, lane_draw(r), a.filterK); // lane-parallel: one filter per command of the segment
+			r.f = make_filter(a.cd, lane_draw(r), a.filterK, a.viewRowNorm, a.viewTransNorm, a.viewSum); // lane-parallel: one filter per command of the segment
 		}
 		NV_STAMP(1);
 
@@ -1069,7 +1060,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 		{
 			r.d0 = make_float4(__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w));
 			r.d1 = make_float4(__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z), __uint_as_float(g1.w));
-			r.f = make_filter(a.cd, lane_draw(r), a.filterK);
+			r.f = make_filter(a.cd, lane_draw(r), a.filterK, a.viewRowNorm, a.viewTransNorm, a.viewSum);
 		};
 
 		const bool useFilter = a.filterK > 0.0f && !NV_DBG(a, 32u);   // filterK 0: coefficients outside the proven range (host); bit 5 (experiments): every valid command goes to the exact pass
@@ -2187,7 +2178,7 @@ NV_DEV void bits_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint
 			u.scale = q0.w;
 			u.q = { q1.x, q1.y, q1.z };
 			u.qw = q1.w;
-			const FilterDraw f = make_filter(a.cd, u, a.filterK);
+			const FilterDraw f = make_filter(a.cd, u, a.filterK, a.viewRowNorm, a.viewTransNorm, a.viewSum);
 			s_draw[tid][0] = q0;
 			s_draw[tid][1] = q1;
 			s_cert[tid][0] = make_float4(f.m[0], f.m[1], f.m[2], f.b[0]);

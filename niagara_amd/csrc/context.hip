@@ -742,6 +742,23 @@ static int fill_cluster_args(nv_context* ctx, nv::ClusterArgs& a, const NvCullDa
 		const bool finite = s01 <= 1e3f && s23 <= 1e3f && fabsf(cull->znear) <= 1e30f && fabsf(cull->zfar) <= 1e30f; // false on NaN
 		a.filterK = finite ? 4.0f * 48.0f * 5.9604644775390625e-8f * 1.001f * S : 0.0f;
 	}
+	{
+		// the view-only terms of clustercull.hip make_filter, in its operations and order (fp32, no contraction: this file is compiled
+		// with -ffp-contract=off like the kernels)
+		const float* V = cull->view; // column-major: V(r,k) = V[4k + r]
+		float Vn = 0.0f, V3n = 0.0f;
+		for (int r = 0; r < 3; ++r)
+		{
+			Vn = fmaxf(Vn, fabsf(V[r]) + fabsf(V[4 + r]) + fabsf(V[8 + r]));
+			V3n = fmaxf(V3n, fabsf(V[12 + r]));
+		}
+		float sumV = 0.0f;
+		for (int i = 0; i < 15; ++i)
+			sumV += (i & 3) == 3 ? 0.0f : V[i];
+		a.viewRowNorm = Vn;
+		a.viewTransNorm = V3n;
+		a.viewSum = sumV;
+	}
 	a.hostHint = ctx->hintDevice;
 	return NV_OK;
 }
