@@ -1522,6 +1522,26 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 			const uint64_t m = ((uint64_t)maskHi << 32) | maskLo;
 			a.masks[myIdx] = m;
 		}
+		const bool payloadForm = !LATE && !DEFER && a.payloadCounts != nullptr; // (uniform) nv_taskcull's early pass: see below
+		if (payloadForm)
+		{
+			// The task-shader form (meshlet.task.glsl:135-143) straight from this launch: a command's survivors compacted into its own
+			// 64-entry payload, its count beside it — no ordered append, so no tile counts and no second launch.  The segment's ballots
+			// are final here and the rings have drained; the commands that have survivors are walked with the lanes on a command's
+			// 64 bits (rank = v_mbcnt: one contiguous store per command).
+			const bool liveCmd = lane < cnt && myIdx < numCmds;
+			const uint32_t mlo = liveCmd ? maskLo : 0u, mhi = liveCmd ? maskHi : 0u;
+			if (liveCmd)
+				a.payloadCounts[myIdx] = (uint32_t)__builtin_popcount(mlo) + (uint32_t)__builtin_popcount(mhi);
+			for (uint64_t owners = __ballot((mlo | mhi) != 0); owners; owners &= owners - 1)
+			{
+				const uint32_t src = (uint32_t)__builtin_ctzll(owners);
+				const uint32_t lo = __builtin_amdgcn_readlane(mlo, src), hi = __builtin_amdgcn_readlane(mhi, src);
+				const uint32_t ci = __builtin_amdgcn_readlane(myIdx, src);
+				if ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u)
+					a.clusterIndices[(size_t)ci * 64 + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u))] = ci | (lane << 24);
+			}
+		}
 		// survivors per scatter tile: fire-and-forget adds.  The four commands of a chunk sit in four neighbouring lanes
 		// and nearly always in one tile: their counts are summed across the quad first (3x fewer atomics).
 		{
@@ -1538,13 +1558,13 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				if (lane & 3u)
 					pc = 0;
 			}
-			if (pc && !DEFER && !NV_DBG(a, 2048u)) // DEFER: the occlusion stage counts the final ballots; bit 11 (experiments): no tile counts
+			if (pc && !DEFER && !payloadForm && !NV_DBG(a, 2048u)) // DEFER: the occlusion stage counts the final ballots; payloads: nothing is appended; bit 11 (experiments): no tile counts
 				atomicAdd(&a.tileCounts->counts[bank][tileOf * CC_COUNT_STRIDE], pc);
 		}
 	}
 	// the launch's filter statistic for the host's choice of the next launch's form: one add per wave, spread over the tile
 	// counters' lines (word 1 of a line; the scatter kernel sums them)
-	if (lane == 0 && passedFilter)
+	if (lane == 0 && passedFilter && !(!LATE && !DEFER && a.payloadCounts != nullptr)) // (payloads: no scatter launch follows that would sum and clear them)
 	{
 		const uint32_t numTiles = (numCmds + T2 - 1) / T2;
 		atomicAdd(&a.tileCounts->counts[bank][(w % (numTiles ? numTiles : 1u)) * CC_COUNT_STRIDE + 1], passedFilter);
@@ -2433,11 +2453,26 @@ __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs
 		{
 			m = cand ? ((uint64_t)s_visHi[tid] << 32) | s_visLo[tid] : 0ull;
 			a.masks[idx] = m;
+			if (a.payloadCounts)
+				a.payloadCounts[idx] = (uint32_t)__builtin_popcountll(m);
 			// The statistic for the host's choice of the next launch's form (cluster_mask_kernel counts the commands its filter
 			// does not finish): a command with a set bit was visible a frame ago, and nearly always still has a cluster the
 			// filter cannot finish — counting those per entry cost 8 instructions per cluster for a tuning hint.
 			passedAcc += cand ? 1u : 0u;
 		}
+		if (a.payloadCounts) // (uniform) nv_taskcull's early pass: the payloads straight from here (see cluster_mask_kernel), no tile counts
+		{
+			const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
+			for (uint64_t owners = __ballot(m != 0); owners; owners &= owners - 1)
+			{
+				const uint32_t src = (uint32_t)__builtin_ctzll(owners);
+				const uint32_t lo = __builtin_amdgcn_readlane(mlo, src), hi = __builtin_amdgcn_readlane(mhi, src);
+				const uint32_t ci = __builtin_amdgcn_readlane(idx, src);
+				if ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u)
+					a.clusterIndices[(size_t)ci * 64 + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u))] = ci | (lane << 24);
+			}
+		}
+		else
 		{
 			const uint32_t tileOf = idx / T2;
 			const uint32_t tile0 = __builtin_amdgcn_readfirstlane(tileOf);
@@ -2463,7 +2498,7 @@ __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs
 	// the launch's statistic (cluster_mask_kernel: word 1 of a tile counter's line; the scatter kernel sums them)
 	{
 		const uint32_t sum = wave_sum_u32(passedAcc);
-		if (lane == 0 && sum)
+		if (lane == 0 && sum && !a.payloadCounts)
 		{
 			const uint32_t numTiles = (numCmds + T2 - 1) / T2;
 			atomicAdd(&a.tileCounts->counts[bank][((blockIdx.x * (CB_THREADS / 64) + wave) % (numTiles ? numTiles : 1u)) * CC_COUNT_STRIDE + 1], sum);

@@ -103,6 +103,7 @@ struct nv_context
 	uint32_t hizLds; // stage the coarse pyramid levels in LDS for drawcull's late pass (experiments: measured slower)
 	uint32_t directPercent; // share of commands passing the filter above which the next launch skips the filter pass
 	uint32_t bitsBlocksPerCU; // cluster_bits_kernel: grid (blocks per CU)
+	uint32_t taskcullOneLaunch; // experiments: nv_taskcull's early pass as the one-command-per-wave kernel (the round-1 form)
 	int forceDirect;        // NV_OPT_CULL_FORM: -1 = by the previous launch's statistic, 0 / 1 = always filter / always direct, 2 = direct and never the bit-expanding early form
 	int forceTaskList;      // NV_OPT_TASK_EMIT: -1 = by the statistic of earlier TASK passes, 0 / 1 = per-draw / list form of drawcull's TASK scatter
 	int forceShallow;       // NV_OPT_CULL_RING: -1 = by the previous launch's command count, 0 / 1 = always the 8-deep / the 4-deep ring
@@ -287,6 +288,7 @@ int nv_create(nv_context** out_ctx, int device)
 	ctx->directPercent = 35; // measured crossover (config 3A geometry at several densities): ~36 % of the commands passing the filter
 	ctx->forceDirect = -1;
 	ctx->bitsBlocksPerCU = 4;
+	ctx->taskcullOneLaunch = 0;
 	ctx->forceShallow = -1;
 	ctx->forceTaskList = -1;
 	ctx->listStride = nv::clustercull_list_stride();
@@ -297,6 +299,8 @@ int nv_create(nv_context** out_ctx, int device)
 		ctx->hizLds = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_DIRECT"))
 		ctx->forceDirect = atoi(v);
+	if (const char* v = getenv("NV_TASKCULL_ONE_LAUNCH"))
+		ctx->taskcullOneLaunch = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_BITS_BLOCKS"))
 		ctx->bitsBlocksPerCU = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_DIRECT_PERCENT"))
@@ -851,6 +855,29 @@ int nv_taskcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 	DeviceGuard guard(ctx->device);
 	a.clusterIndices = d_payloads;
 	a.payloadCounts = d_payloadCounts;
+	if (!late && !ctx->taskcullOneLaunch)
+	{
+		// Early pass: nv_clustercull's cull launch (filter / direct / lane-per-set-bit form by the same statistics), which writes the
+		// payloads itself when ClusterArgs::payloadCounts is set (clustercull.hip: the end of a segment) — the filter form streams a
+		// sparse pass at 8 bytes per meshlet and finishes most commands in 23 instructions, where the one-command-per-wave kernel
+		// reads 12 and runs the reference's ~190 for every command (10 M meshlets: 38 us).  The cull kernel only snapshots the count
+		// word when the reset is not fused; there is no count word here.
+		hipStream_t s = (hipStream_t)stream;
+		a.fusedReset = 1u;
+		a.clusterCount4 = nullptr;
+		bool shallow = ctx->hintHost && nv::clustercull_prefers_shallow(*ctx->hintHost);
+		if (ctx->forceShallow >= 0)
+			shallow = ctx->forceShallow != 0;
+		bool direct = ctx->hintHost && nv::clustercull_prefers_direct(ctx->hintHost[0], ctx->hintHost[1], ctx->directPercent);
+		if (ctx->forceDirect >= 0)
+			direct = ctx->forceDirect != 0;
+		const bool bitsForm = direct && ctx->forceDirect != 2 && cull->clusterOcclusionEnabled == 1 && cull->postPass == 0;
+		if (bitsForm)
+			rc = nv::launch_cluster_bits(s, a, a.soaBounds != nullptr, persistent_grid(ctx, ctx->bitsBlocksPerCU));
+		else
+			rc = nv::launch_cluster_mask(s, a, 0, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), shallow, direct);
+		return rc;
+	}
 	return nv::launch_taskcull((hipStream_t)stream, a, late, a.soaBounds != nullptr, (uint32_t)ctx->numCUs * 8);
 }
 
