@@ -19,7 +19,8 @@ Default = weak scaling (10 M meshlets per GPU); `--total-meshlets T` = strong sc
 ranks; `--gpus 8 --total-meshlets 100000000` is BASELINE config 5).
 
 Prints ONE JSON line (rank 0):  metric/value/unit as in BASELINE.json + "roofline" (dominant kernel) + "cpu_baseline"
-(the CPU oracle timed on this host's cores; a reported baseline, not a target).
+(the CPU oracle timed on this host's cores; a reported baseline, not a target) + "parity" (every rank's visible-ID list of the
+benchmarked pass against the CPU oracle on its shard, outside the timed region; a difference on any rank is a non-zero exit).
 """
 import argparse
 import json
@@ -56,6 +57,8 @@ def parse():
                          "(independent passes in flight) and says so in the line")
     ap.add_argument("--overlap-streams", type=int, default=3, help="streams of the `throughput_overlapped` side leg (N = 1 only; 0 = skip it)")
     ap.add_argument("--scatter-waves", type=int, default=0, help="NV_OPT_SCATTER_WAVES (4, 8 or 16) of the timed region; 0 = 16 with one stream, 8 with several")
+    ap.add_argument("--dump-ids", default="", help="directory: every rank saves the visible-ID list of its last profiled pass, rebased to pool-wide command "
+                                                   "indices (shard.to_global_ids), as ids_<rank>.npy — tests/test_distributed_gpu.py concatenates them")
     ap.add_argument("--explicit-reset", action="store_true",
                     help="reference contract: zero the count word with a separate launch (nv_reset_count) instead of NV_OPT_FUSED_COUNT_RESET")
     return ap.parse_args()
@@ -252,6 +255,8 @@ def main():
 
     visible = int(ccb[0].item())
     visible_ids = cib[:min(visible, L.CLUSTER_LIMIT)].cpu().numpy().view(np.uint32)  # the list the profiled run's last pass left: checked against the oracle below
+    if args.dump_ids:
+        np.save(os.path.join(args.dump_ids, "ids_%d.npy" % rank), shard.to_global_ids(visible_ids, cmd_b))
 
     # ---- side leg (N = 1): independent passes in flight on `--overlap-streams` streams, contexts sharing one scene mirror, the
     # scatter launch with 8 waves per workgroup.  A throughput figure for multi-view callers; never `value`.
@@ -338,8 +343,28 @@ def main():
         }
         if S == 1 and kernel_avg_s > step_s * 1.02:
             out["note"] = "inconsistent: the dominant kernel's event time exceeds ms_per_step"
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, cd, draws, meshlets, cmd_b, cmd_e, visible, visible_ids)
+
+    # ---- parity + CPU baseline, outside every timed region.  Every rank holds its visible-ID list of the last profiled pass against
+    # the CPU oracle on ITS shard (same inputs, same command range); the line says "bit-identical" only if all ranks agree.  The timed
+    # CPU baseline runs on rank 0's host cores after the other ranks' checks have finished (they share the host): at N = 1 over the
+    # whole batch, at N > 1 over rank 0's shard — a bounded sample of the same workload, reported as a rate.
+    if not args.no_cpu_baseline:
+        ok, detail = oracle_check(args, cd, draws, meshlets, cmd_b, cmd_e, visible, visible_ids) if world > 1 else (True, "")
+        if world > 1:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+            agreeing = int(flag.item())
+            if not ok:
+                print("rank %d: %s" % (rank, detail), file=sys.stderr, flush=True)
+            dist.barrier()
+            if agreeing != world:
+                raise SystemExit("parity failure: %d of %d ranks differ from the CPU oracle on their shard" % (world - agreeing, world))
+        if rank == 0:
+            out["cpu_baseline"] = cpu_baseline(args, cd, draws, meshlets, cmd_b, cmd_e, visible, visible_ids, world)
+            out["parity"] = "bit-identical"
+            out["parity_checked"] = ("visible-ID list and count of the benchmarked pass against the CPU oracle: " +
+                                     ("the whole batch" if world == 1 else "every rank on its own shard, %d of %d ranks agree" % (world, world)))
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
     for c in ctxs:
@@ -366,7 +391,22 @@ def pmc_traffic(n_meshlets, args):
     return None, None
 
 
-def cpu_baseline(args, cd, draws, meshlets, cmd_b, cmd_e, gpu_visible, gpu_ids):
+def oracle_check(args, cd, draws, meshlets, cmd_b, cmd_e, gpu_visible, gpu_ids):
+    """one untimed pass of the CPU oracle over this rank's shard (oracle/ = test infrastructure; here ONLY as a checker): (ok, detail)"""
+    import oracle
+    from niagara_amd import synth
+    n_cmd = cmd_e - cmd_b
+    commands = make_commands(cmd_b, cmd_e, args.commands_per_draw)
+    cib, cc4 = np.zeros(n_cmd * 64, np.uint32), np.zeros(4, np.uint32)
+    oracle.clustercull(cd, 0, commands, synth.count4_for(n_cmd), draws, meshlets, None, None, cib, cc4, threads=max(1, oracle.max_threads() // max(1, args.gpus)))
+    if int(cc4[0]) != gpu_visible:
+        return False, "CPU oracle sees %d visible meshlets on commands [%d, %d), GPU %d" % (int(cc4[0]), cmd_b, cmd_e, gpu_visible)
+    if not (gpu_ids == cib[:len(gpu_ids)]).all():
+        return False, "the visible-ID lists differ on commands [%d, %d)" % (cmd_b, cmd_e)
+    return True, ""
+
+
+def cpu_baseline(args, cd, draws, meshlets, cmd_b, cmd_e, gpu_visible, gpu_ids, world=1):
     """the CPU oracle (oracle/ = test infrastructure; here ONLY as the timed baseline and as a checker) on this host"""
     import oracle
     from niagara_amd import synth
@@ -391,8 +431,8 @@ def cpu_baseline(args, cd, draws, meshlets, cmd_b, cmd_e, gpu_visible, gpu_ids):
     best, med = min(times), sorted(times)[len(times) // 2]
     return {"value": n_cmd * 64 / med, "unit": "meshlets/s", "cores": threads, "kind": "port", "best_pass_value": n_cmd * 64 / best,
             "visible_list": "bit-identical to the GPU's (%d IDs)" % len(gpu_ids),
-            "sample": "%d passes of the full %d-meshlet batch, OpenMP oracle: median pass %.1f ms (value), best pass %.1f ms"
-                      % (len(times), n_cmd * 64, med * 1e3, best * 1e3)}
+            "sample": "%d passes of %s (%d meshlets), OpenMP oracle: median pass %.1f ms (value), best pass %.1f ms"
+                      % (len(times), "the full batch" if world == 1 else "rank 0's shard, 1 / %d of the pool" % world, n_cmd * 64, med * 1e3, best * 1e3)}
 
 
 if __name__ == "__main__":

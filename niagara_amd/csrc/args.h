@@ -41,12 +41,32 @@
 namespace nv
 {
 
+// Wave-wide inclusive prefix sum in six DPP adds (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then row_bcast 15 and 31 across
+// them: the sequence LLVM's own atomic optimizer emits for gfx9 wave64).  hipcc lowers __shfl_up / __shfl_xor to ds_bpermute_b32 — an
+// LDS round trip of ~100 cycles per step, six steps per scan, on the dependent chain of every scatter launch and of every iteration of the
+// lane kernels (round 4).  A lane whose DPP source is outside its row, masked by row_mask or inactive keeps `old` = 0, i.e. adds
+// nothing.  Every call site runs with all 64 lanes active (a scan over a partial wave would also have been wrong with the shuffles).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_pull_u32(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
+__device__ __forceinline__ uint32_t wave_scan_inclusive_u32(uint32_t v)
+{
+	v += dpp_pull_u32<0x111, 0xf>(v); // row_shr:1
+	v += dpp_pull_u32<0x112, 0xf>(v); // row_shr:2
+	v += dpp_pull_u32<0x114, 0xf>(v); // row_shr:4
+	v += dpp_pull_u32<0x118, 0xf>(v); // row_shr:8
+	v += dpp_pull_u32<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+	v += dpp_pull_u32<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3
+	return v;
+}
+
+// the sum over the wave, in every lane (wave-uniform: lane 63 of the scan)
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1)
-		v += __shfl_xor(v, o, 64);
-	return v;
+	return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_inclusive_u32(v), 63);
 }
 
 // Per-tile survivor counts handed from the cull kernel to the scatter kernel (clustercull.hip).  Two banks: a pass adds

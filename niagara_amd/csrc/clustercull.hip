@@ -246,57 +246,6 @@ NV_DEV uint64_t cull_command(const ClusterArgs& a, const NvMeshTaskCommand& cmd,
 	return __ballot(visible && !skip);
 }
 
-// The late pass with HiZ in two halves, so that the exact pass can keep several commands' texel fetches in flight (the
-// texel addresses depend on the projection, so one command after the other costs a full memory latency each — measured:
-// the waves that own the visible part of the scene spent 10-27 us there while two thirds of the waves had nothing to do).
-// late_prepare = cull_command up to hiz_prepare; flags: bits 0..4 HizProbe::use, bit 5 visible so far, bit 6 skip.
-template <bool BITS>
-NV_DEV HizProbe late_prepare(const ClusterArgs& a, const NvMeshTaskCommand& cmd, const DrawUniform& u, const LaneData& l, uint32_t lane, uint32_t& flags,
-                             const uint32_t* mipOffsets, const uint64_t* decided = nullptr)
-{
-	const NvCullData& cd = a.cd;
-	bool visible = lane < cmd.taskCount;
-	bool skip = false;
-	if (BITS)
-	{
-		const uint32_t mvi = lane + cmd.meshletVisibilityOffset;
-		const bool bit = (l.mvbWord & (1u << (mvi & 31))) != 0;
-		if (cmd.lateDrawVisibility == 1 && bit)
-			skip = true;
-	}
-	HizProbe p = { 0, 0, 0, 0, 0, 0.0f };
-	if (decided) // frustum and cone already decided by the certified test: only the HiZ probe needs the reference's sphere
-		visible = (*decided >> lane & 1ull) != 0;
-	if (__ballot(visible) != 0)
-	{
-		f3 c;
-		float r;
-		lane_sphere(cd, u, l, c, r);
-		if (!decided)
-		{
-			visible = visible && frustum_test(cd, c, r);
-			if (cd.clusterBackfaceEnabled != 0 && __ballot(visible) != 0)
-			{
-				f3 axis;
-				float cutoff;
-				lane_cone(cd, u, l, axis, cutoff);
-				visible = visible && !cone_cull(c, r, axis, cutoff);
-			}
-		}
-		if (visible && !NV_DBG(a, 512u)) // bit 9 (experiments): no HiZ
-			p = hiz_prepare(cd, a.pyr, c, r, mipOffsets);
-	}
-	flags = p.use | (visible ? 32u : 0u) | (skip ? 64u : 0u);
-	return p;
-}
-
-// second half: `visible` of clustercull.comp.glsl:110-123 from the four texels
-NV_DEV bool late_finish(uint32_t flags, float depthSphere, float t00, float t10, float t01, float t11)
-{
-	HizProbe p = { 0, 0, 0, 0, flags & 31u, depthSphere };
-	return (flags & 32u) != 0 && hiz_finish(p, t00, t10, t01, t11);
-}
-
 // Late pass, lane-parallel form of the same update for a whole segment: lane c owns the segment's c-th command and
 // holds its `visible` ballot in vis (0 for commands the filter rejected).  Runs after the load rings have drained, so
 // its stores and atomics never sit between counted loads (a store issued inside a ring lengthens every s_waitcnt
@@ -803,48 +752,6 @@ NV_DEV void ringB_wait(SlotB& s)
 		NV_COUNTED_WAIT("s_waitcnt vmcnt(%2) ; nv_ready %0 %1" : "+v"(s.bounds), "+v"(s.cone) : "i"(YOUNGER * 2) : "memory");
 }
 
-// the same wait with the number of younger LOADS given directly (exact pass with texel fetches between the ring issues)
-template <bool BITS, int LOADS>
-NV_DEV void ringB_wait_loads(SlotB& s)
-{
-	static_assert(LOADS < 64, "vmcnt is a 6-bit counter");
-	if (BITS)
-		NV_COUNTED_WAIT("s_waitcnt vmcnt(%3) ; nv_ready %0 %1 %2" : "+v"(s.bounds), "+v"(s.cone), "+v"(s.mvbWord) : "i"(LOADS) : "memory");
-	else
-		NV_COUNTED_WAIT("s_waitcnt vmcnt(%2) ; nv_ready %0 %1" : "+v"(s.bounds), "+v"(s.cone) : "i"(LOADS) : "memory");
-}
-
-// the four HiZ texels of one command in flight (late pass): offsets in floats from the pyramid base, always in range
-struct SlotT
-{
-	float t00, t10, t01, t11;
-};
-
-NV_DEV void ringT_issue(SlotT& s, const float* base, uint32_t o00, uint32_t o10, uint32_t o01, uint32_t o11, uint64_t order)
-{
-	const uint32_t b00 = o00 * 4u, b10 = o10 * 4u, b01 = o01 * 4u, b11 = o11 * 4u;
-#ifdef NV_PLAIN_LOADS
-	(void)order;
-	const char* bp = reinterpret_cast<const char*>(base);
-	s.t00 = *reinterpret_cast<const float*>(bp + b00);
-	s.t10 = *reinterpret_cast<const float*>(bp + b10);
-	s.t01 = *reinterpret_cast<const float*>(bp + b01);
-	s.t11 = *reinterpret_cast<const float*>(bp + b11);
-#else
-	asm volatile("s_nop 4\n\tglobal_load_dword %0, %4, %8\n\tglobal_load_dword %1, %5, %8\n\tglobal_load_dword %2, %6, %8\n\tglobal_load_dword %3, %7, %8"
-	             : "=&v"(s.t00), "=&v"(s.t10), "=&v"(s.t01), "=&v"(s.t11)
-	             : "v"(b00), "v"(b10), "v"(b01), "v"(b11), "s"(base), "s"(order)
-	             : "memory");
-#endif
-}
-
-template <int LOADS>
-NV_DEV void ringT_wait(SlotT& s)
-{
-	static_assert(LOADS < 64, "vmcnt is a 6-bit counter");
-	NV_COUNTED_WAIT("s_waitcnt vmcnt(%4) ; nv_ready %0 %1 %2 %3" : "+v"(s.t00), "+v"(s.t10), "+v"(s.t01), "+v"(s.t11) : "i"(LOADS) : "memory");
-}
-
 // End of a ring: wait for everything, THEN release the slots.  The last loads of a ring are redundant (clamped re-reads
 // whose values nobody uses), so for the compiler the slots are dead as soon as their last consumer has run — and it
 // reuses their registers for whatever comes next (observed: a division sunk below the filter loop computed in two slot
@@ -853,7 +760,6 @@ NV_DEV void ringT_wait(SlotT& s)
 NV_DEV void ring_drain() { asm volatile("s_waitcnt vmcnt(0) ; nv_ready all" ::: "memory"); }
 NV_DEV void ring_release(SlotA& s) { asm volatile("; released %0 %1" : "+v"(s.bounds), "+v"(s.mvbWord)); }
 NV_DEV void ring_release(SlotB& s) { asm volatile("; released %0 %1 %2" : "+v"(s.bounds), "+v"(s.cone), "+v"(s.mvbWord)); }
-NV_DEV void ring_release(SlotT& s) { asm volatile("; released %0 %1 %2 %3" : "+v"(s.t00), "+v"(s.t10), "+v"(s.t01), "+v"(s.t11)); }
 
 // commands per scatter tile: the same function of the indirect words in both kernels
 // n / d for a launch constant d whose magic the host prepared (ClusterArgs): one s_mul_hi_u32 and a shift instead of the ~18
@@ -976,8 +882,10 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 		__builtin_amdgcn_s_setprio(3);
 	const uint32_t gen = a.genBlocks ? div_launch_constant(blockIdx.x, a.genBlocks, a.genBlocksMagic) : 0u; // (workgroups are numbered generation-major)
 	const uint32_t numCmds = indirect_command_count(a);
+	// (nv_taskcull's payload form has its own word: no scatter launch follows it that would refresh the filter statistic in word 1, so
+	// its count must not become the denominator of nv_clustercull's next filter / direct choice — ADVICE r3)
 	if (a.hostHint && blockIdx.x == 0 && threadIdx.x == 0)
-		__hip_atomic_store(a.hostHint, numCmds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__hip_atomic_store(a.hostHint + (a.payloadCounts ? 4 : 0), numCmds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	constexpr uint32_t CH = LATE ? CC_CHUNK_LATE : CC_CHUNK;
 	const uint32_t numChunks = (numCmds + CH - 1) / CH;
 	uint32_t chunkOf;
@@ -1192,146 +1100,6 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 			// top priority for pass B, because it is on the launch's critical path — late pass 44.8 -> 48.8 us, early pass
 			// unchanged: the boosted wave takes issue slots from the streaming waves that keep HBM busy; likewise
 			// keeping level 3 out of the streaming waves' rotation: early pass +1.5 us.)
-#ifdef NV_EXPERIMENTS // the r1 form of the late pass (NV_DEBUG_MODE bit 21): the product defers the probe to cluster_hiz_kernel
-			if (LATE && candMask && a.cd.clusterOcclusionEnabled == 1 && !NV_DBG(a, 1024u | 524288u)) // bit 19 (experiments): texels fetched per command
-			{
-				// Late pass with HiZ: the same ring for bounds + cone, and behind it the texel fetches of CC_PT commands in
-				// flight.  A visit = wait for the slot's bounds, first half of the test (up to the texel addresses), second
-				// half of the command visited CC_PT visits ago, issue this command's texels, reissue the slot.  Every visit
-				// issues the same CC_UL loads (inactive probes and empty slots fetch texel 0 / re-read the last command), so
-				// all waits are counted; the first round, which follows CC_DL ring issues without texels, has its own counts.
-				constexpr int CC_DL = 2, CC_PT = 1;                  // ring slots, texel sets in flight (r2 sweep, config 4: 4 + 2 gave
-				                                                     // 42.1 us and scratch spills, 2 + 1 gives 40.0 us and none)
-				constexpr int CC_RL = BITS ? 3 : 2, CC_UL = 4 + CC_RL; // loads per ring issue, per visit
-				static_assert(CC_DL % CC_PT == 0, "the texel set of a visit is chosen statically");
-				uint32_t curDraw = ~0u, certDraw = ~0u;
-				DrawUniform du = {};
-				CertUniform cf = {};
-				uint64_t pending = candMask;
-				uint32_t cIssued[CC_DL];
-				SlotB ring[CC_DL];
-				SlotT tex[CC_PT];
-				uint32_t tFlags[CC_PT], tCmd[CC_PT];
-				float tDepth[CC_PT];
-				uint32_t last = (uint32_t)__builtin_ctzll(candMask);
-#pragma unroll
-				for (int j = 0; j < CC_PT; ++j)
-				{
-					tFlags[j] = 0;
-					tCmd[j] = ~0u;
-					tDepth[j] = 0.0f;
-					tex[j] = { 0.0f, 0.0f, 0.0f, 0.0f };
-				}
-				bool firstRound = true;
-#pragma unroll
-				for (int k = 0; k < CC_DL; ++k)
-				{
-					if (pending)
-					{
-						last = (uint32_t)__builtin_ctzll(pending);
-						pending &= pending - 1;
-						cIssued[k] = last;
-					}
-					else
-						cIssued[k] = ~0u;
-					ringB_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, last), __builtin_amdgcn_readlane(r.taskCount, last),
-					                  __builtin_amdgcn_readlane(r.meshletVisibilityOffset, last), lane, 0);
-				}
-				for (bool more = true; more;)
-				{
-					more = false;
-#pragma unroll
-					for (int k = 0; k < CC_DL; ++k)
-					{
-						const int j = k % CC_PT; // static after unrolling
-						if (firstRound) // younger than this slot's issue: the later slots of the prologue and k full visits
-							NV_COUNTED_WAIT("s_waitcnt vmcnt(%0)" ::"i"(CC_RL * (CC_DL - 1 - k) + k * CC_UL) : "memory");
-						ringB_wait_loads<BITS, (CC_DL - 1) * CC_UL>(ring[k]);
-						const uint32_t c = cIssued[k];
-						HizProbe probe = { 0, 0, 0, 0, 0, 0.0f };
-						uint32_t flags = 0;
-						if (c != ~0u)
-						{
-							const NvMeshTaskCommand cmd = segment_command(r, c);
-							LaneData cur;
-							cur.b0 = (uint32_t)ring[k].bounds;
-							cur.b1 = (uint32_t)(ring[k].bounds >> 32);
-							cur.cone = ring[k].cone;
-							cur.mvbWord = ring[k].mvbWord;
-							// frustum + cone through the certified test; the reference's sphere only where the HiZ probe needs it
-							uint64_t vis = 0;
-							bool decided = false;
-							if (useCert)
-							{
-								if (cmd.drawId != certDraw)
-								{
-									certDraw = cmd.drawId;
-									cf = segment_cert(r, c);
-								}
-								bool rejects = false;
-								decided = certified_visible(a.cd, cf, cur.b0, cur.b1, cur.cone, cmd.taskCount >= 64u ? ~0ull : (1ull << cmd.taskCount) - 1ull, &vis, &rejects);
-								if (DIRECT && !rejects)
-									++passedFilter;
-							}
-							else if (DIRECT)
-								++passedFilter;
-							if (!decided || vis)
-							{
-								if (cmd.drawId != curDraw)
-								{
-									curDraw = cmd.drawId;
-									du = load_draw(a.draws, cmd.drawId); // scalar loads: the gathered copy lives only until the filters are derived
-								}
-								probe = late_prepare<BITS>(a, cmd, du, cur, lane, flags, s_mipOffset, decided ? &vis : nullptr);
-							}
-						}
-						// second half of the command whose texels were requested CC_PT visits ago
-						ringT_wait<CC_RL + (CC_PT - 1) * CC_UL>(tex[j]);
-						uint64_t m = 0;
-						if (tCmd[j] != ~0u)
-						{
-							const bool visible = late_finish(tFlags[j], tDepth[j], tex[j].t00, tex[j].t10, tex[j].t01, tex[j].t11);
-							const uint64_t vis = __ballot(visible);
-							m = __ballot(visible && !(tFlags[j] & 64u));
-							maskLo = writelane_u32(maskLo, (uint32_t)m, tCmd[j]);
-							maskHi = writelane_u32(maskHi, (uint32_t)(m >> 32), tCmd[j]);
-							visLo = writelane_u32(visLo, (uint32_t)vis, tCmd[j]);
-							visHi = writelane_u32(visHi, (uint32_t)(vis >> 32), tCmd[j]);
-						}
-						tFlags[j] = flags;
-						tDepth[j] = probe.depthSphere;
-						tCmd[j] = c;
-						ringT_issue(tex[j], a.pyr.d_base, probe.o00, probe.o10, probe.o01, probe.o11, m);
-						if (c != ~0u)
-							more = true; // its second half is still to come
-						if (pending)
-						{
-							last = (uint32_t)__builtin_ctzll(pending);
-							pending &= pending - 1;
-							cIssued[k] = last;
-							more = true;
-						}
-						else
-							cIssued[k] = ~0u;
-						ringB_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, last), __builtin_amdgcn_readlane(r.taskCount, last),
-						                  __builtin_amdgcn_readlane(r.meshletVisibilityOffset, last), lane, m);
-					}
-					firstRound = false;
-					if (!more)
-#pragma unroll
-						for (int k = 0; k < CC_DL; ++k)
-							more = more || cIssued[k] != ~0u;
-				}
-				ring_drain();
-#pragma unroll
-				for (int k = 0; k < CC_DL; ++k)
-					ring_release(ring[k]);
-#pragma unroll
-				for (int j = 0; j < CC_PT; ++j)
-					ring_release(tex[j]);
-			}
-			else
-#endif
 			if (candMask && !NV_DBG(a, 1024u)) // bit 10 (experiments): no exact pass
 			{
 				uint32_t curDraw = ~0u, certDraw = ~0u;
@@ -1768,14 +1536,7 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 			pc[j] = (uint32_t)__builtin_popcountll(m4[j]);
 			mine += pc[j];
 		}
-		uint32_t incl = mine;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1)
-		{
-			uint32_t t = __shfl_up(incl, o, 64);
-			if ((int)lane >= o)
-				incl += t;
-		}
+		uint32_t incl = wave_scan_inclusive_u32(mine);
 		__syncthreads(); // s_part free (prefix reduction / previous step's readers are done)
 		if (lane == 63)
 			s_part[wave] = incl;
@@ -2017,14 +1778,7 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 		}
 
 		const uint32_t pc = (uint32_t)__builtin_popcountll(cand);
-		uint32_t incl = pc;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1)
-		{
-			const uint32_t t = __shfl_up(incl, o, 64);
-			if ((int)lane >= o)
-				incl += t;
-		}
+		uint32_t incl = wave_scan_inclusive_u32(pc);
 		if (lane == 63)
 			s_part[wave] = incl;
 		if (tid < CH_CMDS)
@@ -2158,9 +1912,10 @@ constexpr int CB_U = 4;      // list entries per lane in flight
 // loads unconditional (slots past the last entry re-read it) and issued together; a slot no lane of the wave holds an entry
 // for is skipped as a whole.  ONE instantiation per layout: with a copy per round size hipcc gave the copies' registers
 // to each other and waited for everything in flight (the prefetches) before the largest copy's first load.
-template <bool SOA>
+template <bool SOA, bool STAT>
 NV_DEV void bits_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint32_t tid, bool first, bool ownsCommand, const float4& d0, const float4& d1,
-                       const uint16_t* s_list, const uint32_t* s_taskOffset, float4 (*s_draw)[2], float4 (*s_cert)[5], uint32_t* s_visLo, uint32_t* s_visHi)
+                       const uint16_t* s_list, const uint32_t* s_taskOffset, float4 (*s_draw)[2], float4 (*s_cert)[5], uint32_t* s_visLo, uint32_t* s_visHi,
+                       uint32_t* s_passed)
 {
 	constexpr int U = CB_U;
 	uint32_t e[U];
@@ -2280,6 +2035,18 @@ NV_DEV void bits_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint
 				visible = !cone_cull(c, r, axis, cutoff);
 			}
 		}
+		if (STAT)
+		{
+			// the statistic of a pass WITHOUT visibility bits: what pass A's filter would have let through (the same comparison) —
+			// with bits a set bit stands in for it (kernel), here every valid cluster is an entry and the host must see a pass whose
+			// commands lie outside the frustum turn sparse.  One store per streak of such lanes within a command's entries, not one per lane.
+			const bool passes = s < total && !(useCert && out);
+			const uint64_t passM = __ballot(passes);
+			const uint32_t lane = tid & 63u;
+			const uint32_t prevOwner = __shfl_up(owner, 1, 64);
+			if (passes && (lane == 0u || prevOwner != owner || !(passM >> (lane - 1u) & 1ull)))
+				s_passed[owner] = 1u;
+		}
 		if (s < total && !visible)
 			atomicAnd(bit < 32u ? &s_visLo[owner] : &s_visHi[owner], ~(1u << (bit & 31u)));
 	}
@@ -2308,10 +2075,18 @@ NV_DEV BitsCommand bits_load_command(const ClusterArgs& a, uint32_t idx, bool li
 	return c;
 }
 
-template <bool SOA>
+// BITS: the early pass with visibility bits (candidates = set bits).  Without: every valid cluster is a candidate — the form for a dense
+// EARLY pass over a meshlet pool that stays in the caches (instanced scenes: the host decides, context.hip; round 4: config 3B's cluster
+// pass 27.0 against 28.4 us).  The two LATE applications of the form were built and measured in round 4 and are not here
+// (tools/experiments/lane_late_forms_r4.diff): as the late pass's first stage (the survivors' commands listed for cluster_hiz_kernel)
+// it takes 48.7 us where one command per wave takes 40.2 us at frame scale (10.2 M candidates: 86 bytes of LDS reads and two gathered
+// loads per entry, four waves per SIMD), and with the occlusion probes fused in (second compaction of the survivors, hiz_round in the
+// same block, no list and no second launch) 109.3 us against 40.2 + 63.9 — the block's phases serialise behind its barriers and the
+// other blocks of the CU do not fill the gaps.
+template <bool SOA, bool BITS>
 __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs a)
 {
-	__shared__ uint32_t s_visLo[CB_CMDS], s_visHi[CB_CMDS], s_taskOffset[CB_CMDS], s_excl[CB_CMDS];
+	__shared__ uint32_t s_visLo[CB_CMDS], s_visHi[CB_CMDS], s_taskOffset[CB_CMDS], s_excl[CB_CMDS], s_passed[BITS ? 1 : CB_CMDS];
 	__shared__ float4 s_draw[CB_CMDS][2];
 	__shared__ float4 s_cert[CB_CMDS][5];
 	__shared__ uint16_t s_list[CB_CMDS * 64]; // (command within the iteration << 6) | lane, in command-major order
@@ -2322,7 +2097,7 @@ __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const uint32_t numCmds = indirect_command_count(a);
 	if (a.hostHint && blockIdx.x == 0 && tid == 0)
-		__hip_atomic_store(a.hostHint, numCmds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__hip_atomic_store(a.hostHint + (a.payloadCounts ? 4 : 0), numCmds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // (word 4: see cluster_mask_kernel)
 	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles, a.tilesMagic);
 	const uint32_t bank = load_uniform_u32(&a.tileCounts->parity) & 1u;
 	if (blockIdx.x == 0 && tid == 0)
@@ -2330,6 +2105,8 @@ __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs
 		a.tileCounts->k2parity = bank;
 		a.tileCounts->base = a.fusedReset ? 0u : a.clusterCount4[0];
 	}
+	if (numCmds == 0) // an empty pass: the pipeline prologue below reads commands[0], draws[0] and mvb[0] unconditionally
+		return;
 	// every block the same number of iterations (the grid is resident at once: the last iteration is the launch's tail),
 	// iteration i of block b = commands [(i G + b) per, (i G + b + 1) per): neighbouring blocks read neighbouring commands
 	const uint32_t G = gridDim.x;
@@ -2354,7 +2131,7 @@ __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs
 		const uint32_t w0 = tc ? c.mvo >> 5 : 0u, wLast = tc ? (c.mvo + tc - 1u) >> 5 : 0u;
 #pragma unroll
 		for (uint32_t j = 0; j < 3; ++j) // word j holds the bits of lanes [32 j - sh, 32 j - sh + 32)
-			w[j] = a.mvb[w0 + j < wLast ? w0 + j : wLast];
+			w[j] = BITS ? a.mvb[w0 + j < wLast ? w0 + j : wLast] : 0u;
 	};
 	load_dependents(cur, tid < per && chunk * per + tid < numCmds, d0, d1, oldw);
 	// (complete before the loop: otherwise the loop body must assume they may still be in flight, and the wait hipcc then puts
@@ -2381,18 +2158,11 @@ __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs
 				old |= lo >= 0 ? (uint64_t)oldw[j] << lo : (uint64_t)(oldw[j] >> (-lo));
 			}
 			const uint64_t valid = taskCount >= 64u ? ~0ull : (1ull << taskCount) - 1ull;
-			cand = old & valid;
+			cand = BITS ? old & valid : valid; // (without visibility bits: every valid cluster)
 		}
 
 		const uint32_t pc = (uint32_t)__builtin_popcountll(cand);
-		uint32_t incl = pc;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1)
-		{
-			const uint32_t t = __shfl_up(incl, o, 64);
-			if ((int)lane >= o)
-				incl += t;
-		}
+		uint32_t incl = wave_scan_inclusive_u32(pc);
 		if (lane == 63)
 			s_part[wave] = incl;
 		if (tid < CB_CMDS)
@@ -2401,6 +2171,8 @@ __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs
 			s_visHi[tid] = (uint32_t)(cand >> 32);
 			s_taskOffset[tid] = cur.taskOffset;
 			s_excl[tid] = incl - pc; // (within the wave: the waves before it are added below)
+			if (!BITS)
+				s_passed[tid] = 0u;
 		}
 
 		// the prefetches, in front of this iteration's entry loads: iteration i + 1's MeshDraw and words, iteration i + 2's command
@@ -2437,7 +2209,7 @@ __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs
 		NV_LDS_BARRIER();
 
 		for (uint32_t base = 0; base < total; base += CB_THREADS * CB_U)
-			bits_round<SOA>(a, base, total, tid, base == 0, cand != 0, c0, c1, s_list, s_taskOffset, s_draw, s_cert, s_visLo, s_visHi);
+			bits_round<SOA, !BITS>(a, base, total, tid, base == 0, cand != 0, c0, c1, s_list, s_taskOffset, s_draw, s_cert, s_visLo, s_visHi, s_passed);
 		NV_LDS_BARRIER();
 		// (the prefetches are consumed HERE, in front of the stores below: vmcnt counts stores too, and a wait for the prefetched
 		// registers at the loop's end would also wait for this iteration's store and atomic to be acknowledged)
@@ -2458,7 +2230,7 @@ __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs
 			// The statistic for the host's choice of the next launch's form (cluster_mask_kernel counts the commands its filter
 			// does not finish): a command with a set bit was visible a frame ago, and nearly always still has a cluster the
 			// filter cannot finish — counting those per entry cost 8 instructions per cluster for a tuning hint.
-			passedAcc += cand ? 1u : 0u;
+			passedAcc += BITS ? (cand ? 1u : 0u) : (cand ? s_passed[tid] : 0u);
 		}
 		if (a.payloadCounts) // (uniform) nv_taskcull's early pass: the payloads straight from here (see cluster_mask_kernel), no tile counts
 		{
@@ -2668,13 +2440,22 @@ bool clustercull_prefers_direct(uint32_t previousCommandCount, uint32_t previous
 }
 
 // early pass with visibility bits, dense form (one lane per set bit): any grid size (equal contiguous shares per block, grid-stride beyond CB_CMDS commands per block)
-int launch_cluster_bits(hipStream_t stream, const ClusterArgs& a, bool soa, uint32_t gridBlocks)
+template <bool SOA>
+static void launch_cb(hipStream_t stream, const ClusterArgs& a, uint32_t gridBlocks)
 {
 	dim3 grid(gridBlocks), block(CB_THREADS);
-	if (soa)
-		hipLaunchKernelGGL((cluster_bits_kernel<true>), grid, block, 0, stream, a);
+	if (a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0)
+		hipLaunchKernelGGL((cluster_bits_kernel<SOA, true>), grid, block, 0, stream, a);
 	else
-		hipLaunchKernelGGL((cluster_bits_kernel<false>), grid, block, 0, stream, a);
+		hipLaunchKernelGGL((cluster_bits_kernel<SOA, false>), grid, block, 0, stream, a);
+}
+
+int launch_cluster_bits(hipStream_t stream, const ClusterArgs& a, bool soa, uint32_t gridBlocks)
+{
+	if (soa)
+		launch_cb<true>(stream, a, gridBlocks);
+	else
+		launch_cb<false>(stream, a, gridBlocks);
 	return (int)hipGetLastError();
 }
 

@@ -140,6 +140,77 @@ struct DeviceGuard
 
 uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
+// Library-owned device memory goes through these two.  Product: hipMalloc / hipFree.  Experiments build (tests with
+// NV_LIBRARY_PATH = libniagara_vis_exp.so, tools/): every block sits between two 4 KiB canary zones (0xC5) that
+// nv_debug_check_scratch compares, and starts out as 0xAB bytes instead of whatever the driver hands out — an out-of-range store of a
+// kernel into the library's own scratch, or a kernel that reads a scratch word nobody wrote, shows up in ANY process instead of only
+// in a long one whose allocations are recycled.
+#ifdef NV_EXPERIMENTS
+constexpr size_t NV_GUARD_BYTES = 4096;
+struct GuardedBlock
+{
+	char* base;
+	size_t bytes; // payload
+};
+std::vector<GuardedBlock>& guarded_blocks()
+{
+	static std::vector<GuardedBlock> v;
+	return v;
+}
+std::atomic_flag g_guardLock = ATOMIC_FLAG_INIT;
+struct GuardLock
+{
+	GuardLock() { while (g_guardLock.test_and_set(std::memory_order_acquire)) { } }
+	~GuardLock() { g_guardLock.clear(std::memory_order_release); }
+};
+#endif
+
+template <class T>
+hipError_t scratch_alloc(T** out, size_t bytes)
+{
+#ifdef NV_EXPERIMENTS
+	char* base = nullptr;
+	const size_t padded = (bytes + 255) / 256 * 256;
+	hipError_t e = hipMalloc(&base, padded + 2 * NV_GUARD_BYTES);
+	if (e != hipSuccess)
+		return e;
+	(void)hipMemset(base, 0xC5, NV_GUARD_BYTES);
+	(void)hipMemset(base + NV_GUARD_BYTES, 0xAB, padded);
+	(void)hipMemset(base + NV_GUARD_BYTES + padded, 0xC5, NV_GUARD_BYTES);
+	{
+		GuardLock lock;
+		guarded_blocks().push_back(GuardedBlock{ base, padded });
+	}
+	*out = reinterpret_cast<T*>(base + NV_GUARD_BYTES);
+	return hipSuccess;
+#else
+	return hipMalloc(out, bytes);
+#endif
+}
+
+void scratch_free(void* p)
+{
+	if (!p)
+		return;
+#ifdef NV_EXPERIMENTS
+	char* base = static_cast<char*>(p) - NV_GUARD_BYTES;
+	{
+		GuardLock lock;
+		std::vector<GuardedBlock>& v = guarded_blocks();
+		for (size_t i = 0; i < v.size(); ++i)
+			if (v[i].base == base)
+			{
+				v[i] = v.back();
+				v.pop_back();
+				break;
+			}
+	}
+	(void)hipFree(base);
+#else
+	(void)hipFree(p);
+#endif
+}
+
 // profiling: returns an event recorded on `stream` now, or nullptr when profiling is off
 hipEvent_t prof_mark(nv_context* ctx, hipStream_t stream)
 {
@@ -177,11 +248,11 @@ int reserve_draw_results(nv_context* ctx, uint32_t drawCount)
 	if (e != hipSuccess)
 		return (int)e;
 	if (ctx->drawResults)
-		(void)hipFree(ctx->drawResults);
+		scratch_free(ctx->drawResults);
 	ctx->drawResults = nullptr;
 	ctx->drawResultsCapacity = 0;
 	const size_t cap = need < (size_t(1) << 21) ? (size_t(1) << 21) : need;
-	if (hipMalloc(&ctx->drawResults, cap) != hipSuccess)
+	if (scratch_alloc(&ctx->drawResults, cap) != hipSuccess)
 		return NV_ENOMEM;
 	ctx->drawResultsCapacity = cap;
 	return NV_OK;
@@ -217,15 +288,15 @@ void scene_release(nv_scene* sc)
 	if (!sc || sc->refs.fetch_sub(1) != 1)
 		return;
 	if (sc->soaBounds)
-		(void)hipFree(sc->soaBounds);
+		scratch_free(sc->soaBounds);
 	if (sc->soaCones)
-		(void)hipFree(sc->soaCones);
+		scratch_free(sc->soaCones);
 	if (sc->soaWorld)
-		(void)hipFree(sc->soaWorld);
+		scratch_free(sc->soaWorld);
 	if (sc->soaScaleMesh)
-		(void)hipFree(sc->soaScaleMesh);
+		scratch_free(sc->soaScaleMesh);
 	if (sc->soaPostPass)
-		(void)hipFree(sc->soaPostPass);
+		scratch_free(sc->soaPostPass);
 	delete sc;
 }
 
@@ -324,12 +395,12 @@ int nv_create(nv_context** out_ctx, int device)
 		ctx->ccBlocksPerCU = (uint32_t)atoi(v) ? ((uint32_t)atoi(v) > 8 ? 8u : (uint32_t)atoi(v)) : 6; // (the stamp buffer holds 8 per CU)
 #endif
 
-	if (hipMalloc(&ctx->masks, nv::clustercull_mask_bytes()) != hipSuccess || hipMalloc(&ctx->tileCounts, sizeof(nv::ClusterCounts)) != hipSuccess ||
-	    hipMalloc(&ctx->candList, nv::clustercull_list_bytes()) != hipSuccess ||
+	if (scratch_alloc(&ctx->masks, nv::clustercull_mask_bytes()) != hipSuccess || scratch_alloc(&ctx->tileCounts, sizeof(nv::ClusterCounts)) != hipSuccess ||
+	    scratch_alloc(&ctx->candList, nv::clustercull_list_bytes()) != hipSuccess ||
 	    hipMemset(ctx->tileCounts, 0, sizeof(nv::ClusterCounts)) != hipSuccess ||
-	    hipMalloc(&ctx->drawTileCounts, sizeof(nv::ClusterCounts)) != hipSuccess ||
+	    scratch_alloc(&ctx->drawTileCounts, sizeof(nv::ClusterCounts)) != hipSuccess ||
 	    hipMemset(ctx->drawTileCounts, 0, sizeof(nv::ClusterCounts)) != hipSuccess || reserve_draw_results(ctx, 1u << 20) != NV_OK ||
-	    hipMalloc(&ctx->totalsPartials, (size_t)persistent_grid(ctx, 8) * 3 * sizeof(unsigned long long)) != hipSuccess)
+	    scratch_alloc(&ctx->totalsPartials, (size_t)persistent_grid(ctx, 8) * 3 * sizeof(unsigned long long)) != hipSuccess)
 	{
 		nv_destroy(ctx);
 		return NV_ENOMEM;
@@ -363,20 +434,20 @@ void nv_destroy(nv_context* ctx)
 	if (ctx->hintHost)
 		(void)hipHostFree(const_cast<uint32_t*>(ctx->hintHost));
 	if (ctx->drawResults)
-		(void)hipFree(ctx->drawResults);
+		scratch_free(ctx->drawResults);
 	if (ctx->drawTileCounts)
-		(void)hipFree(ctx->drawTileCounts);
+		scratch_free(ctx->drawTileCounts);
 	if (ctx->totalsPartials)
-		(void)hipFree(ctx->totalsPartials);
+		scratch_free(ctx->totalsPartials);
 	if (ctx->masks)
-		(void)hipFree(ctx->masks);
+		scratch_free(ctx->masks);
 	if (ctx->tileCounts)
-		(void)hipFree(ctx->tileCounts);
+		scratch_free(ctx->tileCounts);
 	if (ctx->candList)
-		(void)hipFree(ctx->candList);
+		scratch_free(ctx->candList);
 	scene_release(ctx->scene);
 	if (ctx->timing)
-		(void)hipFree(ctx->timing);
+		scratch_free(ctx->timing);
 	delete ctx->prof;
 	delete ctx;
 }
@@ -531,15 +602,15 @@ int nv_upload_meshlets(nv_context* ctx, void* stream, const NvMeshlet* d_meshlet
 		if (e != hipSuccess)
 			return (int)e;
 		if (ctx->scene->soaBounds)
-			(void)hipFree(ctx->scene->soaBounds);
+			scratch_free(ctx->scene->soaBounds);
 		if (ctx->scene->soaCones)
-			(void)hipFree(ctx->scene->soaCones);
+			scratch_free(ctx->scene->soaCones);
 		ctx->scene->soaBounds = nullptr;
 		ctx->scene->soaCones = nullptr;
 		ctx->scene->soaCapacity = 0;
 		ctx->scene->mirroredFrom = nullptr;
-		if (hipMalloc(&ctx->scene->soaBounds, (size_t)padded * sizeof(uint2)) != hipSuccess ||
-		    hipMalloc(&ctx->scene->soaCones, (size_t)padded * sizeof(uint32_t)) != hipSuccess)
+		if (scratch_alloc(&ctx->scene->soaBounds, (size_t)padded * sizeof(uint2)) != hipSuccess ||
+		    scratch_alloc(&ctx->scene->soaCones, (size_t)padded * sizeof(uint32_t)) != hipSuccess)
 			return NV_ENOMEM;
 		ctx->scene->soaCapacity = padded;
 	}
@@ -580,19 +651,19 @@ int nv_upload_draws(nv_context* ctx, void* stream, const NvMeshDraw* d_draws, ui
 		if (e != hipSuccess)
 			return (int)e;
 		if (ctx->scene->soaWorld)
-			(void)hipFree(ctx->scene->soaWorld);
+			scratch_free(ctx->scene->soaWorld);
 		if (ctx->scene->soaScaleMesh)
-			(void)hipFree(ctx->scene->soaScaleMesh);
+			scratch_free(ctx->scene->soaScaleMesh);
 		if (ctx->scene->soaPostPass)
-			(void)hipFree(ctx->scene->soaPostPass);
+			scratch_free(ctx->scene->soaPostPass);
 		ctx->scene->soaWorld = nullptr;
 		ctx->scene->soaScaleMesh = nullptr;
 		ctx->scene->soaPostPass = nullptr;
 		ctx->scene->drawsCapacity = 0;
 		ctx->scene->drawsFrom = nullptr;
 		const size_t cap = (size_t)drawCount + 64;
-		if (hipMalloc(&ctx->scene->soaWorld, cap * sizeof(float4)) != hipSuccess || hipMalloc(&ctx->scene->soaScaleMesh, cap * sizeof(uint2)) != hipSuccess ||
-		    hipMalloc(&ctx->scene->soaPostPass, cap * sizeof(uint32_t)) != hipSuccess)
+		if (scratch_alloc(&ctx->scene->soaWorld, cap * sizeof(float4)) != hipSuccess || scratch_alloc(&ctx->scene->soaScaleMesh, cap * sizeof(uint2)) != hipSuccess ||
+		    scratch_alloc(&ctx->scene->soaPostPass, cap * sizeof(uint32_t)) != hipSuccess)
 			return NV_ENOMEM;
 		ctx->scene->drawsCapacity = drawCount;
 	}
@@ -789,7 +860,7 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	if (ctx->debugMode & 8u)
 	{
 		if (!ctx->timing)
-			(void)hipMalloc(&ctx->timing, (size_t)persistent_grid(ctx, 8) * 4 * 8 * sizeof(unsigned long long)); // (room for any NV_OPT_CULL_WORKGROUPS_PER_CU)
+			(void)scratch_alloc(&ctx->timing, (size_t)persistent_grid(ctx, 8) * 4 * 8 * sizeof(unsigned long long)); // (room for any NV_OPT_CULL_WORKGROUPS_PER_CU)
 		a.probeOut = ctx->timing;
 	}
 #endif
@@ -806,13 +877,17 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 		direct = ctx->forceDirect != 0;
 	// Late pass with HiZ = three launches: the cull kernel in its early form (frustum + cone ballots), the occlusion probe
 	// with one lane per survivor (clustercull.hip cluster_hiz_kernel: visibility bits, skip, tile counts), the scatter.
-	const bool twoStage = late && cull->clusterOcclusionEnabled == 1 && !(ctx->debugMode & 2097152u); // bit 21 (experiments): the probe inside the cull kernel (r1 form)
+	const bool twoStage = late && cull->clusterOcclusionEnabled == 1;
 	a.deferHiz = twoStage ? 1u : 0u;
-	// Early pass with visibility bits where the filter would not pay: one lane per SET BIT instead of one wave per command
-	// (clustercull.hip cluster_bits_kernel; without bits every valid cluster would be an entry and one wave per command is
-	// faster).  NV_OPT_CULL_FORM 3 keeps the one-command-per-wave direct form.
-	const bool bitsForm = !late && direct && ctx->forceDirect != 2 && cull->clusterOcclusionEnabled == 1 && cull->postPass == 0;
-	if (bitsForm)
+	// Where the filter would not pay (direct), EARLY passes test one LANE per cluster that can be visible at all instead of one wave per
+	// command (clustercull.hip cluster_bits_kernel): with visibility bits (candidates = set bits: 26 against 38-40 us at frame scale), and,
+	// while the registered meshlet pool is small enough to stay in the caches (an instanced scene; a pool streamed from HBM loses: 52-62
+	// against 40 us for 10 M meshlets), also without (every valid cluster a candidate).  The late pass keeps one command per wave: both
+	// lane forms of it measured slower (clustercull.hip, above cluster_bits_kernel).  NV_OPT_CULL_FORM 3 keeps one command per wave throughout.
+	const bool poolInCache = a.soaBounds != nullptr && (uint64_t)ctx->scene->mirroredCount * 12u <= (48ull << 20);
+	const bool bits = cull->clusterOcclusionEnabled == 1 && cull->postPass == 0;
+	const bool laneForm = !late && direct && ctx->forceDirect != 2 && (bits || poolInCache);
+	if (laneForm)
 		rc = nv::launch_cluster_bits(s, a, a.soaBounds != nullptr, persistent_grid(ctx, ctx->bitsBlocksPerCU));
 	else
 		rc = nv::launch_cluster_mask(s, a, twoStage ? 0 : late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), shallow, direct);
@@ -865,13 +940,17 @@ int nv_taskcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 		hipStream_t s = (hipStream_t)stream;
 		a.fusedReset = 1u;
 		a.clusterCount4 = nullptr;
-		bool shallow = ctx->hintHost && nv::clustercull_prefers_shallow(*ctx->hintHost);
+		// mapped hint words: [4] = the command count of the previous nv_taskcull (ring depth); [0], [1] = command count and filter
+		// statistic of the previous nv_clustercull, a consistent pair (the payload form writes neither: no scatter launch follows it
+		// that would publish its statistic).  A context that only ever calls nv_taskcull stays on the filter form.
+		bool shallow = ctx->hintHost && nv::clustercull_prefers_shallow(ctx->hintHost[4]);
 		if (ctx->forceShallow >= 0)
 			shallow = ctx->forceShallow != 0;
 		bool direct = ctx->hintHost && nv::clustercull_prefers_direct(ctx->hintHost[0], ctx->hintHost[1], ctx->directPercent);
 		if (ctx->forceDirect >= 0)
 			direct = ctx->forceDirect != 0;
-		const bool bitsForm = direct && ctx->forceDirect != 2 && cull->clusterOcclusionEnabled == 1 && cull->postPass == 0;
+		const bool poolInCache = a.soaBounds != nullptr && (uint64_t)ctx->scene->mirroredCount * 12u <= (48ull << 20);
+		const bool bitsForm = direct && ctx->forceDirect != 2 && ((cull->clusterOcclusionEnabled == 1 && cull->postPass == 0) || poolInCache);
 		if (bitsForm)
 			rc = nv::launch_cluster_bits(s, a, a.soaBounds != nullptr, persistent_grid(ctx, ctx->bitsBlocksPerCU));
 		else
@@ -944,6 +1023,30 @@ int nv_depthreduce(nv_context* ctx, void* stream, const float* d_depth, uint32_t
 	prof_push(ctx, NV_PROF_DEPTHREDUCE, e0, prof_mark(ctx, (hipStream_t)stream));
 	return rc;
 }
+
+#ifdef NV_EXPERIMENTS
+// experiments build only: number of library-owned blocks (of every context of this process) whose canary zones no longer hold
+// their pattern, after synchronising the device; tests/conftest.py calls it after every GPU test
+int nv_debug_check_scratch(void)
+{
+	if (hipDeviceSynchronize() != hipSuccess)
+		return -1;
+	GuardLock lock;
+	int damaged = 0;
+	std::vector<unsigned char> host(2 * NV_GUARD_BYTES);
+	for (const GuardedBlock& b : guarded_blocks())
+	{
+		if (hipMemcpy(host.data(), b.base, NV_GUARD_BYTES, hipMemcpyDeviceToHost) != hipSuccess ||
+		    hipMemcpy(host.data() + NV_GUARD_BYTES, b.base + NV_GUARD_BYTES + b.bytes, NV_GUARD_BYTES, hipMemcpyDeviceToHost) != hipSuccess)
+			return -1;
+		bool ok = true;
+		for (unsigned char c : host)
+			ok = ok && c == 0xC5;
+		damaged += ok ? 0 : 1;
+	}
+	return damaged;
+}
+#endif
 
 #ifdef NV_EXPERIMENTS
 // experiments build only (not part of the public header): copies the NV_DEBUG_MODE bit-3 wave stamps to the host

@@ -247,16 +247,66 @@ NV_DEV float sample_min(const NvPyramidDesc& p, float u, float v, float level)
 	return sample_min_image(p.d_base + p.mipOffset[l], mip_dim(p.width, (uint32_t)l), mip_dim(p.height, (uint32_t)l), u, v);
 }
 
-// The HiZ test in two halves, so that a caller can put other work between requesting the (up to) four texels and
-// comparing them (clustercull.hip's late pass).  hiz_prepare: projection, mip selection and the footprint's texel
-// offsets relative to the pyramid base; hiz_finish: MIN over the texels that carry weight, in the oracle's order
+// The HiZ test in two halves, so that a caller can put other work between requesting the four texels and comparing them
+// (clustercull.hip's occlusion stage, drawcull.hip's compacted probes).  hiz_prepare: projection, mip selection and the footprint's
+// texel offsets relative to the pyramid base; hiz_finish: MIN over the texels that carry weight, in the oracle's order
 // (x0,y0) (x1,y0) (x0,y1) (x1,y1), and the comparison.  Offsets are always in range (clamped), also for an inactive probe.
+//
+// Round 4: the stage that runs these is bound by VALU issue (6.9 M probes x 348 instructions at frame scale), and
+// 140 of the 348 were not the reference's arithmetic but the selection logic around it.  Three restatements of that logic, none of
+// which touches a floating-point operation of the reference:
+//   * a texel WITHOUT weight is not flagged and skipped in hiz_finish — its offset is replaced by the offset of the texel of the
+//     same row / column that has weight (an axis always has one: fr cannot be 0 and 1 at once; NaN gives both).  The MIN chain
+//     `best = t < best ? t : best` over a sequence with such repeats equals the chain over the distinct weighted texels in the
+//     oracle's order: the first element is the same (so a NaN first texel still poisons the chain, a later NaN is still skipped),
+//     a repeat never wins `t < best`, and among equal values (-0 / +0) the first occurrence is kept in both;
+//   * ceil(log2(m)) from v_frexp_exp / v_frexp_mant (m = f 2^e, f in [0.5, 1): e - (f == 0.5)) instead of field extraction with a
+//     branch per class — same integer for every positive finite m including denormals; +inf and everything above 2^32 clamp to 32
+//     like before, non-positive and NaN sizes give level 0 like before;
+//   * the footprint's index clamps with integer min / max on the converted floor (the conversion saturates) instead of compares and
+//     selects on the float.
 struct HizProbe
 {
-	uint32_t o00, o10, o01, o11; // texel offsets (floats) from pyr.d_base
-	uint32_t use;                // bit 0..3: the texel carries weight; bit 4: the probe is active (projectSphere succeeded)
+	uint32_t o00, o10, o01, o11; // texel offsets (floats) from pyr.d_base: the weighted texels in the oracle's order, weightless ones aliased
+	uint32_t use;                // bit 4: the probe is active (projectSphere succeeded); bits 0..3 unused since round 4
 	float depthSphere;
 };
+
+// math.h:24-39 as occlusion_mip above, integer result in [0, 32], branch-free
+NV_DEV int occlusion_level(const float aabb[4], float pw, float ph)
+{
+	const float sx = aabb[2] - aabb[0];
+	const float sy = aabb[3] - aabb[1];
+	const float m = gl_max(sx * pw, sy * ph);
+	// ceil_log2_exact(m) for 0 < m < inf; frexp of NaN / inf / 0 gives exponent 0
+	int level = __builtin_amdgcn_frexp_expf(m) - (__builtin_amdgcn_frexp_mantf(m) == 0.5f ? 1 : 0);
+	level = m > 4294967296.0f ? 32 : level; // (level > 32 -> 32; +inf -> 129 -> 32)
+	level = m > 0.0f ? level : 0;            // (!(m > 0) -> 0: negative sizes have a positive exponent)
+	level = level < 0 ? 0 : level;           // (level <= 0 -> 0)
+	const float scale = __uint_as_float((uint32_t)(127 + 1 - level) << 23); // exp2(1 - level), exact (level 0: 2.0, result unused)
+	const float fx = pw * scale, fy = ph * scale;
+	const bool fits = (fract1(aabb[0] * fx) + sx * fx <= 2.0f) && (fract1(aabb[1] * fy) + sy * fy <= 2.0f);
+	return level - (fits && level > 0 ? 1 : 0);
+}
+
+// one axis of the bilinear footprint as footprint() above, the two indices already aliased: a0 / a1 = the index of the first /
+// second texel of the axis if it has weight, else the other one's
+NV_DEV void footprint_aliased(float t, uint32_t size, uint32_t& a0, uint32_t& a1)
+{
+	float f0 = __builtin_floorf(t);
+	const float fr = t - f0;
+	f0 = __builtin_amdgcn_fmed3f(f0, -1.0f, 16777216.0f); // !(f0 >= -1) -> -1 (a NaN too: v_med3_f32 then returns the MIN3); the upper bound
+	                                                      // only keeps the conversion in range (size <= 2^24: the index clamp below decides)
+	const int hi = (int)size - 1;
+	int a = (int)f0;
+	a = a < hi ? a : hi;             // -1 <= a <= hi
+	const int b = a + 1;
+	const int i0 = a < 0 ? 0 : a;
+	const int i1 = b < hi ? b : hi;
+	const bool u0 = (1.0f - fr) != 0.0f, u1 = fr != 0.0f;
+	a0 = (uint32_t)(u0 ? i0 : i1);
+	a1 = (uint32_t)(u1 ? i1 : i0);
+}
 
 // mipOffsets = pyr.mipOffset, or a copy of it in LDS: indexed per lane, the kernel-argument array costs a vector load
 // (and a full memory latency) per probe
@@ -266,25 +316,23 @@ NV_DEV HizProbe hiz_prepare(const NvCullData& cd, const NvPyramidDesc& pyr, f3 c
 	float aabb[4];
 	if (project_sphere(c, r, cd.znear, cd.P00, cd.P11, aabb))
 	{
-		const float level = occlusion_mip(aabb, cd.pyramidWidth, cd.pyramidHeight);
-		int l = (int)level;
+		int l = occlusion_level(aabb, cd.pyramidWidth, cd.pyramidHeight);
 		const int top = (int)pyr.levels - 1;
-		l = l < 0 ? 0 : (l > top ? top : l);
+		l = l > top ? top : l; // (l >= 0)
 		const uint32_t w = mip_dim(pyr.width, (uint32_t)l), h = mip_dim(pyr.height, (uint32_t)l);
 		const float u = (aabb[0] + aabb[2]) * 0.5f, v = (aabb[1] + aabb[3]) * 0.5f;
-		int x0, x1, y0, y1;
-		bool ux0, ux1, uy0, uy1;
-		footprint(u * (float)w - 0.5f, w, x0, x1, ux0, ux1);
-		footprint(v * (float)h - 0.5f, h, y0, y1, uy0, uy1);
+		uint32_t x0, x1, y0, y1;
+		footprint_aliased(u * (float)w - 0.5f, w, x0, x1);
+		footprint_aliased(v * (float)h - 0.5f, h, y0, y1);
 		const uint32_t base = mipOffsets[l];
 		// rows and widths are below 2^24 (a mip chain addressed with 32-bit texel offsets): the 24-bit multiply-add is exact,
 		// and unlike the 64-bit form hipcc otherwise picks it reads no register pair (tools/check_asm_hazards.py, check 2)
-		const uint32_t row0 = __umul24((uint32_t)y0, w) + base, row1 = __umul24((uint32_t)y1, w) + base;
-		p.o00 = row0 + (uint32_t)x0;
-		p.o10 = row0 + (uint32_t)x1;
-		p.o01 = row1 + (uint32_t)x0;
-		p.o11 = row1 + (uint32_t)x1;
-		p.use = (ux0 && uy0 ? 1u : 0u) | (ux1 && uy0 ? 2u : 0u) | (ux0 && uy1 ? 4u : 0u) | (ux1 && uy1 ? 8u : 0u) | 16u;
+		const uint32_t row0 = __umul24(y0, w) + base, row1 = __umul24(y1, w) + base;
+		p.o00 = row0 + x0;
+		p.o10 = row0 + x1;
+		p.o01 = row1 + x0;
+		p.o11 = row1 + x1;
+		p.use = 16u;
 		p.depthSphere = cd.znear / (c.z - r);
 	}
 	return p;
@@ -292,31 +340,11 @@ NV_DEV HizProbe hiz_prepare(const NvCullData& cd, const NvPyramidDesc& pyr, f3 c
 
 NV_DEV bool hiz_finish(const HizProbe& p, float t00, float t10, float t01, float t11)
 {
-	if (!(p.use & 16u))
-		return true;
-	float best = 0.0f;
-	bool have = false;
-	if (p.use & 1u)
-	{
-		best = t00;
-		have = true;
-	}
-	if (p.use & 2u)
-	{
-		best = have ? gl_min(best, t10) : t10;
-		have = true;
-	}
-	if (p.use & 4u)
-	{
-		best = have ? gl_min(best, t01) : t01;
-		have = true;
-	}
-	if (p.use & 8u)
-	{
-		best = have ? gl_min(best, t11) : t11;
-		have = true;
-	}
-	return p.depthSphere > best;
+	float best = t00;
+	best = gl_min(best, t10);
+	best = gl_min(best, t01);
+	best = gl_min(best, t11);
+	return !(p.use & 16u) || p.depthSphere > best;
 }
 
 // drawcull.comp.glsl:86-99 / clustercull.comp.glsl:110-123: returns the sphere's visibility against the pyramid

@@ -47,14 +47,8 @@ struct DrawResult
 
 NV_DEV uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
 {
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1)
-	{
-		uint32_t t = __shfl_up(v, o, 64);
-		if ((int)lane >= o)
-			v += t;
-	}
-	return v;
+	(void)lane;
+	return wave_scan_inclusive_u32(v); // six DPP adds (args.h) instead of six ds_bpermute round trips
 }
 
 // drawcull.comp.glsl:56-118 + :154-155 for one draw

@@ -46,8 +46,9 @@ class CountsReducer:
         for i in range(steps): red.before_pass(i); ctx.clustercull(...); red.after_pass(i)
         red.drain(steps); total = red.last(steps)          # int64[3], summed over the ranks (world size 1: the pass's own counts)
 
-    Rows of a block that no pass has written since the block's last reduction are zero, so a partial last batch reduces
-    zeros there, never the sums of an earlier use.
+    After a block's in-place all-reduce its rows hold SUMS; a pass overwrites its own row before the block is reduced again, and
+    drain() zeroes the rows a partial last batch did not write before it reduces that block.  So: call drain(n) before last(n),
+    and do not read a block between before_pass and drain — rows not yet rewritten still hold the previous use's sums.
     """
 
     def __init__(self, ctx, device, batch=8, stream=None):

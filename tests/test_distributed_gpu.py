@@ -40,7 +40,7 @@ def test_bench_two_ranks_on_one_device(batch, streams, total):
     for attempt in range(2):  # (a rendezvous that never completes — seen once on the GPU box — gets one more try on a fresh port)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
                str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--shared-device", "--steps", str(steps), "--warmup", "3",
-               "--counts-batch", str(batch), "--streams", str(streams), "--draws", str(draws_per_rank), "--no-cpu-baseline"] + (["--total-meshlets", str(total)] if total else [])
+               "--counts-batch", str(batch), "--streams", str(streams), "--draws", str(draws_per_rank)] + (["--total-meshlets", str(total), "--cpu-seconds", "0.2"] if total else ["--no-cpu-baseline"])
         try:
             out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=180, cwd=ROOT)
             break
@@ -67,6 +67,47 @@ def test_bench_two_ranks_on_one_device(batch, streams, total):
         assert (total // 64 // 2) % cpd != 0  # the boundary splits a draw's commands
     assert rec["config"]["visible_rank0"] == want[0]
     assert rec["config"]["visible_total"] == want[0] + want[1] and want[1] > 0
+    if total:  #  the N > 1 line is gradeable: parity on every rank's shard and a CPU baseline
+        assert rec["parity"] == "bit-identical" and "2 of 2 ranks" in rec["parity_checked"] and rec["cpu_baseline"]["value"] > 0
+
+
+def test_config5_eight_ranks_100m_meshlets(tmp_path):
+    """BASELINE config 5 end to end with the HIP kernels: `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 --total-meshlets
+    100000000` (gloo, the eight ranks sharing the box's one device — on an 8-GPU node the same command with the default backend is the
+    RCCL run).  The line must carry `parity` (every rank against the oracle on its shard, inside bench.py) and `cpu_baseline`; and the
+    eight ranks' rebased ID lists, concatenated in rank order, must be the oracle's list over the UNSHARDED 100 M-meshlet pool."""
+    import argparse
+    import oracle
+    sys.path.insert(0, ROOT)
+    import bench
+    from niagara_amd import host, synth
+    world, total, cpd = 8, 100_000_000, 10
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--shared-device", "--steps", "3", "--warmup", "2",
+           "--total-meshlets", str(total), "--copies", "2", "--cpu-seconds", "0.5", "--dump-ids", str(tmp_path)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["n_gpus"] == world and rec["scaling"] == "strong" and rec["config"]["meshlets_total"] == total // 64 * 64
+    assert rec["parity"] == "bit-identical" and "8 of 8 ranks" in rec["parity_checked"]
+    assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["kind"] == "port" and "1 / 8" in rec["cpu_baseline"]["sample"]
+    # the unsharded pool: rank r's meshlets are its own seeded stream, packed in rank order; one oracle pass over all of it
+    args = argparse.Namespace(draws=0, commands_per_draw=cpd, total_meshlets=total)
+    total_cmd = total // 64
+    pool = []
+    for rank in range(world):
+        _, meshlets, cd, (b, e), tc = bench.make_inputs(args, rank, world)
+        assert tc == total_cmd and len(meshlets) == (e - b) * 64
+        pool.append(meshlets)
+    pool = np.concatenate(pool)
+    draws = host.synth_draws((total_cmd + cpd - 1) // cpd, 1, 300.0)
+    commands = bench.make_commands(0, total_cmd, cpd)
+    cib, cc4 = np.zeros(total_cmd * 64, np.uint32), np.zeros(4, np.uint32)
+    oracle.clustercull(cd, 0, commands, synth.count4_for(total_cmd), draws, pool, None, None, cib, cc4, threads=oracle.max_threads())
+    ids = np.concatenate([np.load(tmp_path / ("ids_%d.npy" % r)) for r in range(world)])
+    assert rec["config"]["visible_total"] == int(cc4[0]) == len(ids) and len(ids) > 1_000_000
+    assert (ids == cib[:len(ids)]).all()
 
 
 def test_bench_single_gpu_line_is_one_regime():
@@ -82,6 +123,7 @@ def test_bench_single_gpu_line_is_one_regime():
     assert abs(rec["roofline"]["ms_per_pass_single_stream"] - rec["ms_per_step"]) < 1e-9
     assert rec["throughput_overlapped"]["streams"] == 3 and rec["throughput_overlapped"]["value"] > 0
     assert rec["cpu_baseline"]["visible_list"].startswith("bit-identical") and rec["config"]["visible_total"] == rec["config"]["visible_rank0"]
+    assert rec["parity"] == "bit-identical"
 
 
 def _worker(rank, world, port, out_dir):

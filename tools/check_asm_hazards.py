@@ -312,26 +312,18 @@ def main():
         bad += len(found)
     weak = 0
     waits = 0
-    listed = 0
     for name, lines in kernels(isa):
         waits += sum(1 for ln in lines if "nv_ready" in ln)
         found = scan_counts(name, lines)
-        # The experiments build keeps round 1's late pass (HiZ probe inside the cull kernel, NV_DEBUG_MODE bit 21) for comparison:
-        # its ring's FIRST visit is covered by an extra wait under a run-time flag (`if (firstRound) s_waitcnt vmcnt(..)`), which a
-        # path-insensitive dataflow cannot tell from the later visits — it merges the prologue's counts into the path that skips that
-        # wait.  Those kernels (LATE = true; not in the product, which defers the probe to cluster_hiz_kernel) are listed, not failed.
-        tolerated = "-DNV_EXPERIMENTS" in defines and "cluster_mask_kernelILb1" in name
         if found:
-            print("%s: %d counted wait(s) that may return before the load they name has landed%s" % (name, len(found), " (experiments-only kernel with a flag-guarded first-round wait: not failed)" if tolerated else ""))
+            print("%s: %d counted wait(s) that may return before the load they name has landed" % (name, len(found)))
             for no, t, r, k, n in found[:12]:
                 print("   +%d  %s    v%d: only %d younger VMEM operation(s) on some path, the wait allows %d outstanding" % (no, t, r, k, n))
-        weak += 0 if tolerated else len(found)
-        listed += len(found) if tolerated else 0
+        weak += len(found)
     bad += weak
     if not bad:
         print("in-flight scan: no instruction touches a ring register between its issue and its wait (%d kernels)" % len(kernels(isa)))
-        print("counted waits: every vmcnt(N) that names a slot has at least N younger vector-memory operations behind the slot's load on every path (%d waits%s)"
-              % (waits, ", apart from the %d listed above in experiments-only kernels" % listed if listed else ""))
+        print("counted waits: every vmcnt(N) that names a slot has at least N younger vector-memory operations behind the slot's load on every path (%d waits, no exemptions)" % waits)
     return 1 if bad else 0
 
 
