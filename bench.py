@@ -242,6 +242,7 @@ def main():
         single.drain(n_prof)
         torch.cuda.synchronize()
         serial = (time.perf_counter() - t2) / n_prof
+    ctx.profile_variants()  # (reset: the counts below are the profiled loop's)
     ctx.profile(True)
     t1 = time.perf_counter()
     for i in range(n_prof):
@@ -250,6 +251,7 @@ def main():
     torch.cuda.synchronize()
     profiled = time.perf_counter() - t1
     prof = ctx.profile_read()
+    variants = ctx.profile_variants()  # which kernel form the host's per-launch choices resolved to in the timed launches
     ctx.profile(False)
     ctx.status()
 
@@ -332,7 +334,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_measured_in_run": False, "traffic_source": traffic_note,
                          "kernel": "cluster_mask_kernel", "kernel_avg_us": kernel_avg_s * 1e6, "timed_in": "one pass after the other on one stream (HIP events on the launch stream)",
-                         "algorithmic_bytes": algo_bytes, "launches_timed": cull_n,
+                         "algorithmic_bytes": algo_bytes, "launches_timed": cull_n, "kernel_variants": variants,
                          "scatter_kernel_avg_us": scatter_avg_s * 1e6, "ms_per_step_with_events": profiled / n_prof * 1e3,
                          "pass_algorithmic_bytes": pass_bytes,
                          # the whole pass (cull + scatter launches) against the roofline, one pass after the other, un-instrumented

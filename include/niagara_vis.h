@@ -188,6 +188,20 @@ int nv_status(nv_context* ctx, void* stream);
 #define NV_PROF_SLOTS 5
 int nv_profile_enable(nv_context* ctx, int enabled);
 int nv_profile_read(nv_context* ctx, float out_ms[NV_PROF_SLOTS], uint32_t out_count[NV_PROF_SLOTS]);
+/* Which kernel variant the passes took since the last call (the host picks per launch from the previous launches' statistics, or
+ * what NV_OPT_CULL_FORM / NV_OPT_CULL_RING / NV_OPT_TASK_EMIT pin): launch counts per variant, so that a profile can say what it
+ * timed.  Counted whether or not event profiling is enabled; reading resets the counts. */
+#define NV_VARIANT_CULL_FILTER_RING4 0 /* cluster cull launch: conservative filter pass + certified pass, 4-deep ring */
+#define NV_VARIANT_CULL_FILTER_RING8 1 /* the same with the 8-deep ring */
+#define NV_VARIANT_CULL_DIRECT 2       /* no filter pass, one command per wave */
+#define NV_VARIANT_CULL_LANES_BITS 3   /* early pass, one lane per set visibility bit */
+#define NV_VARIANT_CULL_LANES 4        /* early pass over a cache-resident pool, one lane per valid cluster */
+#define NV_VARIANT_CULL_AOS 5          /* no SoA mirror registered for the meshlet buffer: records read in place */
+#define NV_VARIANT_HIZ_STAGE 6         /* late pass with HiZ: occlusion-stage launches */
+#define NV_VARIANT_TASK_LIST 7         /* drawcull TASK scatter: one lane per output command */
+#define NV_VARIANT_TASK_PER_DRAW 8     /* drawcull TASK scatter: per-draw form */
+#define NV_VARIANT_SLOTS 9
+int nv_profile_variants(nv_context* ctx, uint32_t out_count[NV_VARIANT_SLOTS]);
 
 /* ---- options ----
  * NV_OPT_FUSED_COUNT_RESET (default 0): when 1, nv_drawcull and nv_clustercull start their append at index 0 whatever

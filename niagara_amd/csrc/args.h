@@ -63,6 +63,17 @@ __device__ __forceinline__ uint32_t wave_scan_inclusive_u32(uint32_t v)
 	return v;
 }
 
+// lane permutations that stay inside the VALU (DPP) where hipcc's __shfl* would go through LDS (ds_bpermute_b32)
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_move_u32(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_shift_up1_u32(uint32_t v) { return dpp_move_u32<0x138>(v); } // lane l <- lane l - 1 (wave_shr:1; lane 0 keeps its own)
+__device__ __forceinline__ uint32_t quad_first_u32(uint32_t v) { return dpp_move_u32<0x00>(v); }      // quad_perm:[0,0,0,0]
+__device__ __forceinline__ uint32_t quad_xor1_u32(uint32_t v) { return dpp_move_u32<0xB1>(v); }       // quad_perm:[1,0,3,2]
+__device__ __forceinline__ uint32_t quad_xor2_u32(uint32_t v) { return dpp_move_u32<0x4E>(v); }       // quad_perm:[2,3,0,1]
+
 // the sum over the wave, in every lane (wave-uniform: lane 63 of the scan)
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {

@@ -993,7 +993,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 			// "the draw changes" must be judged on the draw whose filter the lane actually holds: an empty command
 			// (taskCount 0) gathered draw 0 above, whatever its drawId says (tests/test_special_values.py)
 			const uint32_t heldDraw = r.taskCount ? r.drawId : 0u;
-			const uint32_t prevDraw = __shfl_up(heldDraw, 1, 64);
+			const uint32_t prevDraw = wave_shift_up1_u32(heldDraw);
 			const uint64_t changeMask = __ballot(lane == 0 || heldDraw != prevDraw) | 1ull;
 			const uint32_t base8 = (r.taskCount ? r.taskOffset : 0u) * 8u; // lane-parallel: byte offset of each command's bounds
 			const uint32_t lane8 = lane * 8u;
@@ -1317,12 +1317,12 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 			const uint64_t m = live ? ((uint64_t)maskHi << 32) | maskLo : 0ull;
 			const uint32_t tileOf = live ? myIdx / T2 : ~0u;
 			uint32_t pc = (uint32_t)__builtin_popcountll(m);
-			const uint32_t tile0 = __shfl(tileOf, lane & ~3u, 64);
+			const uint32_t tile0 = quad_first_u32(tileOf);
 			const bool quadUniform = __all_quad_same(tileOf, tile0);
 			if (quadUniform)
 			{
-				pc += __shfl_xor(pc, 1, 64);
-				pc += __shfl_xor(pc, 2, 64);
+				pc += quad_xor1_u32(pc);
+				pc += quad_xor2_u32(pc);
 				if (lane & 3u)
 					pc = 0;
 			}
@@ -1605,7 +1605,7 @@ constexpr int CH_U = 8;         // survivors per lane in flight: a round probes 
 // flight together.  The first round also hands the MeshDraws over through LDS, behind the bounds loads.
 template <int U, bool SOA, bool FIRST>
 NV_DEV void hiz_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint32_t tid, bool ownsDraw, const float4& d0, const float4& d1,
-                      const uint16_t* s_list, const uint32_t* s_taskOffset, float4 (*s_draw)[2], const uint32_t* s_mip, uint32_t* s_visLo, uint32_t* s_visHi)
+                      const uint16_t* s_list, const uint32_t* s_taskOffset, float4 (*s_draw)[2], const MipRecord* s_mip, uint32_t* s_visLo, uint32_t* s_visHi)
 {
 	const float* __restrict__ texels = a.pyr.d_base;
 	uint32_t e[U];
@@ -1650,7 +1650,7 @@ NV_DEV void hiz_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint3
 		f3 c;
 		float r;
 		lane_sphere(a.cd, u, l, c, r);
-		const HizProbe p = hiz_prepare(a.cd, a.pyr, c, r, s_mip);
+		const HizProbe p = hiz_prepare<true>(a.cd, a.pyr, c, r, s_mip);
 		use[k] = p.use;
 		depth[k] = p.depthSphere;
 		const uint32_t zero = NV_DBG(a, 16777216u) ? 0u : ~0u; // bit 24 (experiments): every probe reads texel 0
@@ -1675,7 +1675,7 @@ NV_DEV void hiz_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint3
 template <bool SOA, bool BITS>
 __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 {
-	__shared__ uint32_t s_mip[NV_MAX_MIPS];
+	__shared__ __attribute__((aligned(16))) MipRecord s_mip[NV_MAX_MIPS];
 	__shared__ uint32_t s_visLo[CH_CMDS], s_visHi[CH_CMDS], s_taskOffset[CH_CMDS];
 	__shared__ float4 s_draw[CH_CMDS][2];
 	__shared__ uint16_t s_list[CH_CMDS * 64]; // (command within the block << 6) | lane, in command-major order
@@ -1685,12 +1685,13 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 	const uint32_t lane = tid & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	{
+		// per-level records for the probes (cullmath.h MipRecord), built from the scalar kernel arguments with constant indices
 		uint32_t off = 0;
 #pragma unroll
 		for (uint32_t i = 0; i < NV_MAX_MIPS; ++i)
 			off = tid == i ? a.pyr.mipOffset[i] : off;
 		if (tid < NV_MAX_MIPS)
-			s_mip[tid] = off;
+			s_mip[tid] = make_mip_record(a.pyr, tid, off);
 	}
 	// The cull kernel listed the commands that have survivors in CC_LISTS sub-lists; block b works on sub-list b % CC_LISTS
 	// together with the gridDim.x / CC_LISTS - 1 other blocks of that sub-list, in chunks: listMinPer (8) listed commands per
@@ -2043,7 +2044,7 @@ NV_DEV void bits_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint
 			const bool passes = s < total && !(useCert && out);
 			const uint64_t passM = __ballot(passes);
 			const uint32_t lane = tid & 63u;
-			const uint32_t prevOwner = __shfl_up(owner, 1, 64);
+			const uint32_t prevOwner = wave_shift_up1_u32(owner);
 			if (passes && (lane == 0u || prevOwner != owner || !(passM >> (lane - 1u) & 1ull)))
 				s_passed[owner] = 1u;
 		}

@@ -117,6 +117,7 @@ struct nv_context
 	int profiling;
 	std::vector<ProfRecord>* prof;
 	float* timing; // NV_DEBUG_MODE bit 3: 8 x u64 stamps per wave of the last clustercull
+	uint32_t variants[NV_VARIANT_SLOTS]; // nv_profile_variants: launches per kernel variant since the last read
 };
 
 namespace
@@ -311,6 +312,21 @@ uint32_t scatter_grid(const nv_context* ctx)
 uint32_t persistent_grid(const nv_context* ctx, uint32_t blocksPerCU)
 {
 	return (uint32_t)ctx->numCUs * blocksPerCU;
+}
+
+// nv_profile_variants: what launch_cluster_bits / launch_cluster_mask resolve the host's choices to (clustercull.hip)
+void count_cull_variant(nv_context* ctx, const nv::ClusterArgs& a, bool lanes, bool bits, bool late, bool shallow, bool direct)
+{
+	int v;
+	if (lanes)
+		v = bits ? NV_VARIANT_CULL_LANES_BITS : NV_VARIANT_CULL_LANES;
+	else if (!a.soaBounds)
+		v = NV_VARIANT_CULL_AOS;
+	else if (direct && a.filterK > 0.0f)
+		v = NV_VARIANT_CULL_DIRECT;
+	else
+		v = !late && shallow ? NV_VARIANT_CULL_FILTER_RING4 : NV_VARIANT_CULL_FILTER_RING8;
+	ctx->variants[v] += 1u;
 }
 
 } // namespace
@@ -588,6 +604,18 @@ int nv_profile_read(nv_context* ctx, float out_ms[NV_PROF_SLOTS], uint32_t out_c
 	return rc;
 }
 
+int nv_profile_variants(nv_context* ctx, uint32_t out_count[NV_VARIANT_SLOTS])
+{
+	if (!ctx || !out_count)
+		return NV_EINVAL;
+	for (int i = 0; i < NV_VARIANT_SLOTS; ++i)
+	{
+		out_count[i] = ctx->variants[i];
+		ctx->variants[i] = 0;
+	}
+	return NV_OK;
+}
+
 int nv_upload_meshlets(nv_context* ctx, void* stream, const NvMeshlet* d_meshlets, uint32_t meshletCount)
 {
 	if (!ctx || (!d_meshlets && meshletCount))
@@ -744,6 +772,8 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 				break;
 			}
 #endif
+	if (task)
+		ctx->variants[a.taskList ? NV_VARIANT_TASK_LIST : NV_VARIANT_TASK_PER_DRAW] += 1u;
 	hipEvent_t e0 = prof_mark(ctx, (hipStream_t)stream);
 	rc = nv::launch_drawcull((hipStream_t)stream, a, late, task);
 	prof_push(ctx, NV_PROF_DRAWCULL, e0, prof_mark(ctx, (hipStream_t)stream));
@@ -891,6 +921,8 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 		rc = nv::launch_cluster_bits(s, a, a.soaBounds != nullptr, persistent_grid(ctx, ctx->bitsBlocksPerCU));
 	else
 		rc = nv::launch_cluster_mask(s, a, twoStage ? 0 : late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), shallow, direct);
+	count_cull_variant(ctx, a, laneForm, bits, late && !twoStage, shallow, direct); // (the two-stage late pass launches the early form)
+	ctx->variants[NV_VARIANT_HIZ_STAGE] += twoStage ? 1u : 0u;
 	hipEvent_t e1 = prof_mark(ctx, s);
 	hipEvent_t eh = e1;
 	if (rc == 0 && twoStage)
@@ -955,6 +987,7 @@ int nv_taskcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 			rc = nv::launch_cluster_bits(s, a, a.soaBounds != nullptr, persistent_grid(ctx, ctx->bitsBlocksPerCU));
 		else
 			rc = nv::launch_cluster_mask(s, a, 0, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), shallow, direct);
+		count_cull_variant(ctx, a, bitsForm, cull->clusterOcclusionEnabled == 1 && cull->postPass == 0, false, shallow, direct);
 		return rc;
 	}
 	return nv::launch_taskcull((hipStream_t)stream, a, late, a.soaBounds != nullptr, (uint32_t)ctx->numCUs * 8);

@@ -308,9 +308,50 @@ NV_DEV void footprint_aliased(float t, uint32_t size, uint32_t& a0, uint32_t& a1
 	a1 = (uint32_t)(u1 ? i1 : i0);
 }
 
+// What a probe needs to know about its mip level, as a table a kernel keeps in LDS (two 16-byte reads per probe instead of the
+// shift / max / convert / decrement sequence per axis: 7 VALU instructions of a 293-instruction probe)
+struct MipRecord
+{
+	float wf, hf;      // (float)w, (float)h
+	uint32_t w, base;  // row pitch, first texel of the level (from pyr.d_base)
+	uint32_t hx, hy;   // w - 1, h - 1
+	uint32_t pad0, pad1;
+};
+
+NV_DEV MipRecord make_mip_record(const NvPyramidDesc& pyr, uint32_t level, uint32_t base)
+{
+	MipRecord m;
+	m.w = mip_dim(pyr.width, level);
+	const uint32_t h = mip_dim(pyr.height, level);
+	m.wf = (float)m.w;
+	m.hf = (float)h;
+	m.base = base;
+	m.hx = m.w - 1u;
+	m.hy = h - 1u;
+	m.pad0 = m.pad1 = 0u;
+	return m;
+}
+
+// footprint_aliased with the level's float size and last index given
+NV_DEV void footprint_aliased_rec(float t, int hi, uint32_t& a0, uint32_t& a1)
+{
+	float f0 = __builtin_floorf(t);
+	const float fr = t - f0;
+	f0 = __builtin_amdgcn_fmed3f(f0, -1.0f, 16777216.0f);
+	int a = (int)f0;
+	a = a < hi ? a : hi;
+	const int b = a + 1;
+	const int i0 = a < 0 ? 0 : a;
+	const int i1 = b < hi ? b : hi;
+	const bool u0 = (1.0f - fr) != 0.0f, u1 = fr != 0.0f;
+	a0 = (uint32_t)(u0 ? i0 : i1);
+	a1 = (uint32_t)(u1 ? i1 : i0);
+}
+
 // mipOffsets = pyr.mipOffset, or a copy of it in LDS: indexed per lane, the kernel-argument array costs a vector load
-// (and a full memory latency) per probe
-NV_DEV HizProbe hiz_prepare(const NvCullData& cd, const NvPyramidDesc& pyr, f3 c, float r, const uint32_t* mipOffsets)
+// (and a full memory latency) per probe.  RECORDS: `table` is a MipRecord[levels] in LDS instead (clustercull.hip's occlusion stage).
+template <bool RECORDS = false>
+NV_DEV HizProbe hiz_prepare(const NvCullData& cd, const NvPyramidDesc& pyr, f3 c, float r, const void* table)
 {
 	HizProbe p = { 0, 0, 0, 0, 0, 0.0f };
 	float aabb[4];
@@ -319,12 +360,25 @@ NV_DEV HizProbe hiz_prepare(const NvCullData& cd, const NvPyramidDesc& pyr, f3 c
 		int l = occlusion_level(aabb, cd.pyramidWidth, cd.pyramidHeight);
 		const int top = (int)pyr.levels - 1;
 		l = l > top ? top : l; // (l >= 0)
-		const uint32_t w = mip_dim(pyr.width, (uint32_t)l), h = mip_dim(pyr.height, (uint32_t)l);
 		const float u = (aabb[0] + aabb[2]) * 0.5f, v = (aabb[1] + aabb[3]) * 0.5f;
-		uint32_t x0, x1, y0, y1;
-		footprint_aliased(u * (float)w - 0.5f, w, x0, x1);
-		footprint_aliased(v * (float)h - 0.5f, h, y0, y1);
-		const uint32_t base = mipOffsets[l];
+		uint32_t x0, x1, y0, y1, w, base;
+		if (RECORDS)
+		{
+			const uint4* rec = reinterpret_cast<const uint4*>(static_cast<const MipRecord*>(table) + l);
+			const uint4 r0 = rec[0], r1 = rec[1];
+			w = r0.z;
+			base = r0.w;
+			footprint_aliased_rec(u * __uint_as_float(r0.x) - 0.5f, (int)r1.x, x0, x1);
+			footprint_aliased_rec(v * __uint_as_float(r0.y) - 0.5f, (int)r1.y, y0, y1);
+		}
+		else
+		{
+			w = mip_dim(pyr.width, (uint32_t)l);
+			const uint32_t h = mip_dim(pyr.height, (uint32_t)l);
+			footprint_aliased(u * (float)w - 0.5f, w, x0, x1);
+			footprint_aliased(v * (float)h - 0.5f, h, y0, y1);
+			base = static_cast<const uint32_t*>(table)[l];
+		}
 		// rows and widths are below 2^24 (a mip chain addressed with 32-bit texel offsets): the 24-bit multiply-add is exact,
 		// and unlike the 64-bit form hipcc otherwise picks it reads no register pair (tools/check_asm_hazards.py, check 2)
 		const uint32_t row0 = __umul24(y0, w) + base, row1 = __umul24(y1, w) + base;
@@ -354,7 +408,7 @@ NV_DEV bool hiz_finish(const HizProbe& p, float t00, float t10, float t01, float
 template <bool TABLE = false>
 NV_DEV bool hiz_test(const NvCullData& cd, const NvPyramidDesc& pyr, f3 c, float r, const uint32_t* mipOffsets = nullptr)
 {
-	const HizProbe p = TABLE ? hiz_prepare(cd, pyr, c, r, mipOffsets) : hiz_prepare(cd, pyr, c, r, pyr.mipOffset);
+	const HizProbe p = TABLE ? hiz_prepare<false>(cd, pyr, c, r, mipOffsets) : hiz_prepare<false>(cd, pyr, c, r, pyr.mipOffset);
 	if (!(p.use & 16u))
 		return true;
 	const float* base = pyr.d_base;

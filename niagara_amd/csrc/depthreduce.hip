@@ -257,7 +257,11 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(ChainArgs a)
 		return;
 
 	// level L+2: lane pairs; (x0,y0) = even lane's h[0], (x1,y0) = odd lane's h[0], (x0,y1) = even h[1], (x1,y1) = odd h[1]
-	const float t = min4(h[0], __shfl_xor(h[0], 1, 64), h[1], __shfl_xor(h[1], 1, 64)); // meaningful on even lanes
+	// (the neighbour lane's values through DPP quad_perm:[1,0,3,2] — a VALU move — where __shfl_xor goes through LDS: two round trips on
+	// every wave's load -> reduce -> store chain)
+	const float n0 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(h[0]), 0xB1, 0xf, 0xf, false));
+	const float n1 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(h[1]), 0xB1, 0xf, 0xf, false));
+	const float t = min4(h[0], n0, h[1], n1); // meaningful on even lanes
 	if ((lane & 1u) == 0)
 	{
 		const uint32_t lw = a.sw / 8;

@@ -168,3 +168,40 @@ def test_sub_lists_filled_to_exactly_their_capacity(n_cmds):
         p.run(cd, 1, mvb0)
     finally:
         ctx.close()
+
+
+def test_profile_variants_name_the_form_each_launch_took():
+    """nv_profile_variants: a profile can say which kernel variant it timed.  Pinned forms on a sparse and a dense view of
+    an instanced pool: the counts name the filter form with the ring depth the command count selects, the direct form, the two lane forms,
+    the occlusion stage and the AoS path; reading resets them."""
+    ctx = P.Context()
+    try:
+        draws, meshlets, commands, n = _instanced_scene(600, 7, 300)
+        draws["position"] *= np.float32(0.05)
+        pyr, gp = _pyramid(ctx)
+        cd = host.build_cull_data(cam_pos=(0, 0, 25), draw_count=len(draws), cullingEnabled=1, clusterBackfaceEnabled=1)
+        cd["pyramidWidth"], cd["pyramidHeight"] = pyr.width, pyr.height
+        bits = cd.copy()
+        bits["clusterOcclusionEnabled"] = 1
+        mvb0 = np.random.default_rng(1).integers(0, 2 ** 32, len(commands) * 2 + 3, dtype=np.uint64).astype(np.uint32)
+        p = _Pass(ctx, draws, meshlets, commands, n, pyr, gp)
+        assert ctx.profile_variants() == {}
+        ctx.set_option(P.NV_OPT_CULL_FORM, 1)
+        ctx.set_option(P.NV_OPT_CULL_RING, 4)
+        p.run(cd, 0, None)
+        ctx.set_option(P.NV_OPT_CULL_RING, 8)
+        p.run(cd, 0, None)
+        assert ctx.profile_variants() == {"cull_filter_ring4": 1, "cull_filter_ring8": 1}
+        ctx.set_option(P.NV_OPT_CULL_FORM, 2)
+        p.run(cd, 0, None)       # cache-resident pool, no visibility bits: one lane per valid cluster
+        p.run(bits, 0, mvb0)     # with bits: one lane per set bit
+        p.run(bits, 1, mvb0)     # late with HiZ: one command per wave (direct) + the occlusion stage
+        assert ctx.profile_variants() == {"cull_lanes": 1, "cull_lanes_bits": 1, "cull_direct": 1, "hiz_stage": 1}
+        ctx.set_option(P.NV_OPT_CULL_FORM, 3)
+        p.run(bits, 0, mvb0)
+        assert ctx.profile_variants() == {"cull_direct": 1}
+        ctx.upload_meshlets(None, 0)  # no mirror: the records are read in place
+        p.run(cd, 0, None)
+        assert ctx.profile_variants() == {"cull_aos": 1} and ctx.profile_variants() == {}
+    finally:
+        ctx.close()

@@ -396,6 +396,7 @@ def config_frame(ctx, iters, n_draws=1_000_000, lod0=2200, size=4096, copies=3, 
     names = ("early_drawcull", "early_cluster_cull", "early_cluster_scatter", "pyramid", "late_drawcull", "late_cluster_cull", "late_cluster_hiz", "late_cluster_scatter")
     acc = dict.fromkeys(names, 0.0)
     ctx.profile(True)
+    ctx.profile_variants()  # (reset)
     n_b = max(3, min(iters, 10))
     for _ in range(n_b):
         c = k % copies
@@ -415,6 +416,7 @@ def config_frame(ctx, iters, n_draws=1_000_000, lod0=2200, size=4096, copies=3, 
         frames_of[c] += 1
         k += 1
     ctx.profile(False)
+    kernel_variants = ctx.profile_variants()  # which forms the host's per-launch choices resolved to in the frames of the breakdown
     breakdown = {n + "_us": acc[n] / n_b * 1e3 for n in names}
 
     # ---- parity: one more frame on the next copy with every buffer of both phases read back, against the oracle after the same
@@ -459,7 +461,7 @@ def config_frame(ctx, iters, n_draws=1_000_000, lod0=2200, size=4096, copies=3, 
     tested = e["tested"] + l["tested"]
     out = dict(config="frame: 1M draws, early cull -> pyramid -> late cull at BASELINE scale" + (" (fused: 11 launches)" if fused else " (reference dispatch sequence: 19 launches)"),
                draws=n_draws, lod0_meshlets=lod0, depth=size, scene_copies_rotated=copies, frames_timed=iters, frame_us=frame_us, **breakdown,
-               sum_of_kernels_us=sum(breakdown.values()),
+               sum_of_kernels_us=sum(breakdown.values()), kernel_variants=kernel_variants,
                early=dict(task_commands=int(e["count4"][0]), meshlets_tested=e["tested"], visible=int(e["cc4"][0])),
                late=dict(task_commands=int(l["count4"][0]), meshlets_tested=l["tested"], visible=int(l["cc4"][0]), draws_visible=int(l["dvb"].sum())),
                algorithmic_bytes=algo, algorithmic_bytes_by_pass=bytes_, achieved_GBs=algo / frame_us / 1e3, frac=algo / frame_us / 1e3 / HBM,
