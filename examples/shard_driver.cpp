@@ -5,7 +5,7 @@
 // phase over xGMI.  No meshlet data is exchanged; the reference has no multi-GPU path at all (one VkPhysicalDevice,
 // src/device.cpp:190-248), so this host is new, not a replacement.
 //
-//   shard_driver [--devices N] [--total-meshlets T | --draws D] [--commands-per-draw C] [--steps K] [--warmup W] [--dump PREFIX]
+//   shard_driver [--devices N] [--shards S] [--total-meshlets T | --draws D] [--commands-per-draw C] [--steps K] [--warmup W] [--dump PREFIX]
 //
 //   --total-meshlets T   strong scaling: the pool of T meshlets (T / 64 full task commands) is split over the devices
 //                        (100000000 on 8 devices = BASELINE config 5: 12.5 M meshlets each)
@@ -142,7 +142,8 @@ void make_meshlets(std::vector<NvMeshlet>& out, size_t count, uint64_t seed)
 
 struct Device
 {
-	int id;
+	int id;  // rank
+	int dev; // HIP device the rank runs on (= id unless --shards oversubscribes the devices)
 	hipStream_t stream;
 	nv_context* ctx;
 	uint64_t cmdBegin, cmdEnd; // the device's range of the pool's commands
@@ -176,7 +177,7 @@ T* deviceArray(size_t count, const T* init = nullptr)
 
 int main(int argc, char** argv)
 {
-	int wantDevices = 0, steps = 50, warmup = 5;
+	int wantDevices = 0, wantShards = 0, steps = 50, warmup = 5;
 	uint64_t totalMeshlets = 0;
 	uint32_t drawsPerDevice = 15625, cpd = 10;
 	std::string dump;
@@ -185,6 +186,8 @@ int main(int argc, char** argv)
 		const bool more = i + 1 < argc;
 		if (!strcmp(argv[i], "--devices") && more)
 			wantDevices = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--shards") && more)
+			wantShards = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "--total-meshlets") && more)
 			totalMeshlets = strtoull(argv[++i], nullptr, 10);
 		else if (!strcmp(argv[i], "--draws") && more)
@@ -199,7 +202,7 @@ int main(int argc, char** argv)
 			dump = argv[++i];
 		else
 		{
-			fprintf(stderr, "usage: %s [--devices N] [--total-meshlets T | --draws D] [--commands-per-draw C] [--steps K] [--warmup W] [--dump PREFIX]\n", argv[0]);
+			fprintf(stderr, "usage: %s [--devices N] [--shards S] [--total-meshlets T | --draws D] [--commands-per-draw C] [--steps K] [--warmup W] [--dump PREFIX]\n", argv[0]);
 			return 1;
 		}
 	}
@@ -212,16 +215,23 @@ int main(int argc, char** argv)
 		fprintf(stderr, "no HIP device\n");
 		return 5;
 	}
-	const int N = wantDevices > 0 && wantDevices <= visible ? wantDevices : visible;
+	const int D = wantDevices > 0 && wantDevices <= visible ? wantDevices : visible;
+	// --shards S > devices: S ranks dealt round-robin over the D devices — the sharding, the per-rank passes and the ID rebasing of an
+	// S-GPU node on fewer GPUs (config 5's eight shards on a one-GPU box).  RCCL refuses the same device twice in one communicator
+	// (ncclCommInitAll: "duplicate GPU"), so the phase's counts are then summed on the host instead of by ncclAllReduce; with one rank per
+	// device (the default) nothing changes.
+	const int N = wantShards > D ? wantShards : D;
+	const bool oversubscribed = N > D;
 	const uint64_t totalCmd = totalMeshlets ? totalMeshlets / 64 : (uint64_t)drawsPerDevice * cpd * N;
 	const uint32_t totalDraws = (uint32_t)((totalCmd + cpd - 1) / cpd);
 
 	// ---- the communicator: one rank per device, one process (ncclCommInitAll)
-	std::vector<int> devlist(N);
-	for (int r = 0; r < N; ++r)
+	std::vector<int> devlist(D);
+	for (int r = 0; r < D; ++r)
 		devlist[r] = r;
-	std::vector<ncclComm_t> comms(N);
-	CHECK_NCCL(ncclCommInitAll(comms.data(), N, devlist.data()));
+	std::vector<ncclComm_t> comms(D);
+	if (!oversubscribed)
+		CHECK_NCCL(ncclCommInitAll(comms.data(), D, devlist.data()));
 
 	// ---- the pool: draws replicated (each device keeps the slice its commands reference), commands + meshlets sharded
 	std::vector<NvMeshDraw> draws(totalDraws);
@@ -233,9 +243,10 @@ int main(int argc, char** argv)
 	{
 		Device& d = devs[r];
 		d.id = r;
-		CHECK_HIP(hipSetDevice(r));
+		d.dev = r % D;
+		CHECK_HIP(hipSetDevice(d.dev));
 		CHECK_HIP(hipStreamCreate(&d.stream));
-		CHECK_NV(nv_create(&d.ctx, r));
+		CHECK_NV(nv_create(&d.ctx, d.dev));
 		CHECK_NV(nv_set_option(d.ctx, NV_OPT_FUSED_COUNT_RESET, 1));
 		nv_shard_range(totalCmd, (uint32_t)r, (uint32_t)N, &d.cmdBegin, &d.cmdEnd);
 		const uint64_t n = d.cmdEnd - d.cmdBegin;
@@ -280,21 +291,42 @@ int main(int argc, char** argv)
 	{
 		for (Device& d : devs)
 		{
-			CHECK_HIP(hipSetDevice(d.id));
+			CHECK_HIP(hipSetDevice(d.dev));
 			CHECK_NV(nv_clustercull(d.ctx, d.stream, &d.cull, 0, d.dcb, d.dccb, d.db, d.mlb, nullptr, nullptr, d.cib, d.ccb));
 			if (keepLocal)
 				CHECK_HIP(hipMemcpyAsync(d.local, d.counts, 24, hipMemcpyDeviceToDevice, d.stream));
 		}
-		CHECK_NCCL(ncclGroupStart());
-		for (Device& d : devs)
-			CHECK_NCCL(ncclAllReduce(d.counts, d.counts, 3, ncclUint64, ncclSum, comms[d.id], d.stream));
-		CHECK_NCCL(ncclGroupEnd());
+		if (!oversubscribed)
+		{
+			CHECK_NCCL(ncclGroupStart());
+			for (Device& d : devs)
+				CHECK_NCCL(ncclAllReduce(d.counts, d.counts, 3, ncclUint64, ncclSum, comms[d.id], d.stream));
+			CHECK_NCCL(ncclGroupEnd());
+		}
+		else
+		{
+			// more ranks than devices: the same sum on the host (functional stand-in for the collective; synchronises every phase)
+			uint64_t sum[3] = { 0, 0, 0 }, one[3];
+			for (Device& d : devs)
+			{
+				CHECK_HIP(hipSetDevice(d.dev));
+				CHECK_HIP(hipStreamSynchronize(d.stream));
+				CHECK_HIP(hipMemcpy(one, d.counts, 24, hipMemcpyDeviceToHost));
+				for (int k = 0; k < 3; ++k)
+					sum[k] += one[k];
+			}
+			for (Device& d : devs)
+			{
+				CHECK_HIP(hipSetDevice(d.dev));
+				CHECK_HIP(hipMemcpy(d.counts, sum, 24, hipMemcpyHostToDevice));
+			}
+		}
 	};
 	auto syncAll = [&]()
 	{
 		for (Device& d : devs)
 		{
-			CHECK_HIP(hipSetDevice(d.id));
+			CHECK_HIP(hipSetDevice(d.dev));
 			CHECK_HIP(hipStreamSynchronize(d.stream));
 		}
 	};
@@ -312,7 +344,7 @@ int main(int argc, char** argv)
 	std::vector<uint64_t> reduced(3 * N), local(3 * N);
 	for (Device& d : devs)
 	{
-		CHECK_HIP(hipSetDevice(d.id));
+		CHECK_HIP(hipSetDevice(d.dev));
 		CHECK_HIP(hipMemcpy(&reduced[3 * d.id], d.counts, 24, hipMemcpyDeviceToHost));
 		CHECK_HIP(hipMemcpy(&local[3 * d.id], d.local, 24, hipMemcpyDeviceToHost));
 		CHECK_NV(nv_status(d.ctx, d.stream));
@@ -327,11 +359,13 @@ int main(int argc, char** argv)
 	}
 	agree = agree && reduced[1] == sumCommands && reduced[2] == sumVisible && sumCommands == totalCmd;
 
-	printf("{\"shard_driver\": \"rccl\", \"devices\": %d, \"meshlets_total\": %llu, \"commands_total\": %llu, \"steps\": %d, \"ms_per_step\": %.5f, "
-	       "\"meshlets_per_s\": %.4e, \"scaling\": \"%s\", \"visible_total\": %llu, \"allreduce\": \"one ncclAllReduce(ncclSum) of 3 x u64 per phase\", "
+	printf("{\"shard_driver\": \"rccl\", \"devices\": %d, \"shards\": %d, \"meshlets_total\": %llu, \"commands_total\": %llu, \"steps\": %d, \"ms_per_step\": %.5f, "
+	       "\"meshlets_per_s\": %.4e, \"scaling\": \"%s\", \"visible_total\": %llu, \"allreduce\": \"%s\", "
 	       "\"counts_agree_on_all_ranks\": %s}\n",
-	       N, (unsigned long long)(totalCmd * 64), (unsigned long long)totalCmd, steps, seconds / steps * 1e3, (double)(totalCmd * 64) * steps / seconds,
-	       totalMeshlets ? "strong" : "weak", (unsigned long long)reduced[2], agree ? "true" : "false");
+	       D, N, (unsigned long long)(totalCmd * 64), (unsigned long long)totalCmd, steps, seconds / steps * 1e3, (double)(totalCmd * 64) * steps / seconds,
+	       totalMeshlets ? "strong" : "weak", (unsigned long long)reduced[2],
+	       oversubscribed ? "host sum per phase (more shards than devices: RCCL refuses a device twice in one communicator)" : "one ncclAllReduce(ncclSum) of 3 x u64 per phase",
+	       agree ? "true" : "false");
 
 	if (!dump.empty())
 	{
@@ -350,7 +384,7 @@ int main(int argc, char** argv)
 		fwrite(draws.data(), sizeof(NvMeshDraw), draws.size(), fs);
 		for (Device& d : devs)
 		{
-			CHECK_HIP(hipSetDevice(d.id));
+			CHECK_HIP(hipSetDevice(d.dev));
 			const uint64_t range[2] = { d.cmdBegin, d.cmdEnd };
 			const uint32_t dr[2] = { d.drawBegin, d.drawCount };
 			fwrite(range, 8, 2, fs);
@@ -383,10 +417,12 @@ int main(int argc, char** argv)
 
 	for (Device& d : devs)
 	{
-		CHECK_HIP(hipSetDevice(d.id));
+		CHECK_HIP(hipSetDevice(d.dev));
 		nv_destroy(d.ctx);
 		CHECK_HIP(hipStreamDestroy(d.stream));
-		ncclCommDestroy(comms[d.id]);
 	}
+	if (!oversubscribed)
+		for (ncclComm_t c : comms)
+			ncclCommDestroy(c);
 	return agree ? 0 : 6;
 }

@@ -1464,7 +1464,7 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 		before += i < tile ? v : 0u;
 		passed += bank ? pf1[j] : pf0[j];
 	}
-	if (tile == numTiles - 1 && a.hostHint) // (one workgroup: the statistic is a tuning hint, its sum need not be fast)
+	if (tile == numTiles - 1 && a.hostHint) // (one workgroup: the statistic is a tuning hint, its sum need not be fast; its mapped-host store at the launch's end costs nothing measurable: round 4, NV_DEBUG_MODE A/B)
 	{
 		__shared__ uint32_t s_passed;
 		if (tid == 0)

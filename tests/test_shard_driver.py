@@ -60,18 +60,22 @@ def read_dump(prefix):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("total", [0, 1_000_000 + 64 * 3])
-def test_cpp_rccl_host_matches_the_oracle(tmp_path, total):
+@pytest.mark.parametrize("total, shards", [(0, 0), (1_000_000 + 64 * 3, 0), (3_000_000 + 64 * 5, 8)])
+def test_cpp_rccl_host_matches_the_oracle(tmp_path, total, shards):
+    """shards = 8: eight ranks on the box's one device (--shards; the counts are then summed on the host, because RCCL refuses a device
+    twice in one communicator) — config 5's sharding, passes and ID rebasing in the C++ host, with shard boundaries inside draws"""
     import oracle
     from niagara_amd import synth
     prefix = str(tmp_path / "dump")
-    cmd = [DRIVER, "--steps", "6", "--warmup", "2", "--dump", prefix] + (["--total-meshlets", str(total)] if total else ["--draws", "1700", "--commands-per-draw", "7"])
+    cmd = ([DRIVER, "--steps", "6", "--warmup", "2", "--dump", prefix] + (["--total-meshlets", str(total)] if total else ["--draws", "1700", "--commands-per-draw", "7"]) +
+           (["--shards", str(shards)] if shards else []))
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert line["counts_agree_on_all_ranks"] is True and line["devices"] >= 1 and line["scaling"] == ("strong" if total else "weak")
     draws, cpd, devs = read_dump(prefix)
-    assert len(devs) == line["devices"]
+    assert len(devs) == line["shards"] == (max(shards, line["devices"]) if shards else line["devices"])
+    assert ("host sum" in line["allreduce"]) == (line["shards"] > line["devices"])
     got_ids, want_ids, visible = [], [], 0
     for d in devs:
         n = d["e"] - d["b"]
@@ -89,3 +93,16 @@ def test_cpp_rccl_host_matches_the_oracle(tmp_path, total):
     assert line["commands_total"] == total_cmd and line["visible_total"] == visible
     for d in devs:
         assert d["reduced"] == (0, total_cmd, visible)
+
+
+@pytest.mark.gpu
+def test_config5_eight_shards_from_the_cpp_host():
+    """BASELINE config 5's shape through the C++ host: 100 M meshlets in eight shards of 12.5 M (on the box's one device; an 8-GPU node
+    runs the same command without --shards and reduces over RCCL).  The pool is too large to dump: the counts must agree on all ranks,
+    cover every command, and see the share of visible meshlets the 3 M-meshlet run of the test above holds against the oracle."""
+    p = subprocess.run([DRIVER, "--shards", "8", "--total-meshlets", "100000000", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert line["shards"] == 8 and line["meshlets_total"] == 100_000_000 and line["commands_total"] == 1_562_500 and line["counts_agree_on_all_ranks"] is True
+    assert 0.01 < line["visible_total"] / line["meshlets_total"] < 0.06
