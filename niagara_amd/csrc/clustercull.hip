@@ -24,6 +24,8 @@
 //     survivors listed), cluster_hiz_kernel with ONE LANE PER SURVIVOR for the occlusion probe, the visibility bits and the
 //     final ballots, then K2.  Inside K1 the probe cost three dependent memory latencies per command with only the
 //     command's survivors active, and the launch ended with the few waves that drew the visible part of the scene.
+#include <type_traits>
+
 #include "cullmath.h"
 #include "args.h"
 
@@ -1550,28 +1552,39 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 			running += p;
 		}
 
-#pragma unroll
-		for (uint32_t j = 0; j < PER_LANE; ++j)
+		// The owner loop is what a dense pass's scatter spends its instructions on (one iteration per command with survivors and wave;
+		// the CU's scalar unit serves all 16 waves' loops): the CLUSTER_LIMIT test of clustercull.comp.glsl:137 is hoisted to one uniform
+		// test per step (the step's last index is `running`), and the owner bit is cleared with one s_bitset0_b64.
+		const bool mayOverflow = running > NV_CLUSTER_LIMIT; // (uniform; `running` already includes this step's survivors)
+		auto emit = [&](auto checked)
 		{
-			uint64_t owners = dbgNoScatter ? 0ull : __ballot(pc[j] != 0);
-			while (owners)
+#pragma unroll
+			for (uint32_t j = 0; j < PER_LANE; ++j)
 			{
-				const int src = __builtin_ctzll(owners);
-				owners &= owners - 1;
-				const uint32_t mlo = __builtin_amdgcn_readlane((uint32_t)m4[j], src);
-				const uint32_t mhi = __builtin_amdgcn_readlane((uint32_t)(m4[j] >> 32), src);
-				const uint32_t off = __builtin_amdgcn_readlane(excl, src);
-				const uint64_t ms = ((uint64_t)mhi << 32) | mlo;
-				if (ms >> lane & 1ull)
+				uint64_t owners = dbgNoScatter ? 0ull : __ballot(pc[j] != 0);
+				while (owners)
 				{
-					uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-					uint32_t index = off + rank;
-					if (index < NV_CLUSTER_LIMIT)
-						a.clusterIndices[index] = (first + c0 + (wave * 64 + src) * PER_LANE + j) | (lane << 24);
+					const int src = __builtin_ctzll(owners);
+					asm("s_bitset0_b64 %0, %1" : "+s"(owners) : "s"(src));
+					const uint32_t mlo = __builtin_amdgcn_readlane((uint32_t)m4[j], src);
+					const uint32_t mhi = __builtin_amdgcn_readlane((uint32_t)(m4[j] >> 32), src);
+					const uint32_t off = __builtin_amdgcn_readlane(excl, src);
+					const uint64_t ms = ((uint64_t)mhi << 32) | mlo;
+					if (ms >> lane & 1ull)
+					{
+						uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+						uint32_t index = off + rank;
+						if (!decltype(checked)::value || index < NV_CLUSTER_LIMIT)
+							a.clusterIndices[index] = (first + c0 + (wave * 64 + src) * PER_LANE + j) | (lane << 24);
+					}
 				}
+				excl += pc[j];
 			}
-			excl += pc[j];
-		}
+		};
+		if (mayOverflow)
+			emit(std::true_type{});
+		else
+			emit(std::false_type{});
 	}
 }
 
