@@ -107,3 +107,99 @@ def test_hip_replays_reference_fixture():
         assert masks.cpu().numpy().tobytes() == z["masks"].tobytes()
     finally:
         ctx.close()
+
+
+def _run_hip(s, cib, cc4, slots):
+    import torch
+    from niagara_amd import pipeline as P
+    ctx = P.Context()
+    try:
+        dev = ctx.device
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+        masks = torch.full((slots * 16,), 0x5a, dtype=torch.uint8, device=dev)
+        totals = torch.zeros(3, dtype=torch.int64, device=dev)
+        ctx.trianglecull(s["globals"], t(s["commands"]), t(s["draws"]), t(s["meshlets"]), t(s["data"]), t(s["vertices"]), t(cib), t(cc4), masks, slots, totals)
+        return masks.cpu().numpy(), totals.cpu().numpy().astype(np.uint64)
+    finally:
+        ctx.close()
+
+
+def _every_meshlet_list(s, repeat=1, holes=0.0, seed=0):
+    """A cluster list naming every meshlet of the scene `repeat` times (the list a fully visible scene produces), optionally with
+    ~0 holes (clustersubmit's padding value in the middle of the list: slots that produce nothing), plus the consumer's grid."""
+    m = s["n"] * 64
+    ids = (np.arange(m, dtype=np.uint32) // 64) | ((np.arange(m, dtype=np.uint32) % 64) << 24)
+    ids = np.tile(ids, repeat)
+    if holes:
+        rng = np.random.default_rng(seed)
+        ids[rng.random(len(ids)) < holes] = 0xffffffff
+    cc4 = np.array([len(ids), 0, 0, 0], np.uint32)
+    cib = np.concatenate([ids, np.zeros(512, np.uint32)])
+    oracle.clustersubmit(cc4, cib)
+    return cib, cc4
+
+
+@pytest.mark.gpu
+def test_hip_malformed_meshlets_read_as_the_oracle_defines():
+    """Counts the packed streams must not trip over: no vertices, no triangles, more triangles than MESH_MAXTRI (the loops stop at
+    96, the totals count the raw byte), index bytes that name a vertex the meshlet does not have (the shader's zero-initialised
+    slot: oracle memset), ~0 slots between live ones."""
+    s = make_triangle_scene(seed=77, n_draws=300, commands_per_draw=4, scene_radius=6.0)
+    ml = s["meshlets"]
+    rng = np.random.default_rng(78)
+    n = len(ml)
+    pick = rng.random(n)
+    safe = np.arange(n) < n - 64  # raised triangle counts read index words past the meshlet's own: keep those inside the buffer
+    ml["triangleCount"][(pick < 0.05)] = 0
+    ml["vertexCount"][(pick >= 0.05) & (pick < 0.10)] //= 3  # indices above the count (index words keep their place only for ...)
+    # ... the meshlets whose reference words shrink with the count would move indexOffset: re-point it by padding dataOffset is not
+    # needed — both sides compute indexOffset from the mutated count and read whatever bytes lie there (masked to 6 bits)
+    ml["triangleCount"][(pick >= 0.10) & (pick < 0.15) & safe] = 200
+    ml["triangleCount"][(pick >= 0.15) & (pick < 0.17) & safe] = 255
+    zero_v = (pick >= 0.17) & (pick < 0.20)
+    ml["vertexCount"][zero_v] = 0
+    cib, cc4 = _every_meshlet_list(s, holes=0.03, seed=79)
+    mo, to = run(oracle.trianglecull, s, cib, cc4)
+    mg, tg = _run_hip(s, cib, cc4, len(mo))
+    assert tg.tolist() == to.tolist()
+    assert mg.tobytes() == mo.tobytes()
+    assert (mo["counts"] >> 16).sum() > 0 and (mo["counts"][cib[:len(mo)] == 0xffffffff] == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("specials", [False, True])
+def test_hip_long_list_several_chunks_per_wave(specials):
+    """More slots than 64 per wave of the launch (8 workgroups x 4 waves per CU): every wave walks several 64-slot chunks, batches
+    end on chunk boundaries, the last wave's run is ragged."""
+    s = make_triangle_scene(seed=91, n_draws=120, commands_per_draw=3, scene_radius=5.0, specials=specials)
+    m = s["n"] * 64
+    repeat = (8 * 4 * 256 * 64 * 2) // m + 1  # > 128 slots per wave on a 256-CU part
+    cib, cc4 = _every_meshlet_list(s, repeat=repeat, holes=0.01, seed=92)
+    mo, to = run(oracle.trianglecull, s, cib, cc4)
+    mg, tg = _run_hip(s, cib, cc4, len(mo))
+    assert tg.tolist() == to.tolist()
+    assert mg.tobytes() == mo.tobytes()
+
+
+@pytest.mark.gpu
+def test_hip_mask_capacity_is_respected():
+    """slots past `maskCapacity` are counted in the totals and not written (meshlet.mesh.glsl has no such bound: the ABI's)"""
+    s = make_triangle_scene(seed=93, n_draws=50, commands_per_draw=2)
+    cib, cc4 = _every_meshlet_list(s)
+    mo, to = run(oracle.trianglecull, s, cib, cc4)
+    cap = len(mo) // 2 + 7
+    mg, tg = _run_hip(s, cib, cc4, len(mo))
+    import torch
+    from niagara_amd import pipeline as P
+    ctx = P.Context()
+    try:
+        dev = ctx.device
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+        masks = torch.full((len(mo) * 16,), 0x5a, dtype=torch.uint8, device=dev)
+        totals = torch.zeros(3, dtype=torch.int64, device=dev)
+        ctx.trianglecull(s["globals"], t(s["commands"]), t(s["draws"]), t(s["meshlets"]), t(s["data"]), t(s["vertices"]), t(cib), t(cc4), masks, cap, totals)
+        got = masks.cpu().numpy()
+        assert got[:cap * 16].tobytes() == mo[:cap].tobytes() and (got[cap * 16:] == 0x5a).all()
+        assert totals.cpu().numpy().astype(np.uint64).tolist() == to.tolist()
+    finally:
+        ctx.close()
