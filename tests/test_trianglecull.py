@@ -151,9 +151,9 @@ def test_hip_malformed_meshlets_read_as_the_oracle_defines():
     pick = rng.random(n)
     safe = np.arange(n) < n - 64  # raised triangle counts read index words past the meshlet's own: keep those inside the buffer
     ml["triangleCount"][(pick < 0.05)] = 0
-    ml["vertexCount"][(pick >= 0.05) & (pick < 0.10)] //= 3  # indices above the count (index words keep their place only for ...)
-    # ... the meshlets whose reference words shrink with the count would move indexOffset: re-point it by padding dataOffset is not
-    # needed — both sides compute indexOffset from the mutated count and read whatever bytes lie there (masked to 6 bits)
+    # fewer vertices than the index bytes name.  (indexOffset follows the mutated count on both sides; whatever bytes lie there are
+    # masked to 6 bits, and the ones at or above the count read the zero slot)
+    ml["vertexCount"][(pick >= 0.05) & (pick < 0.10)] //= 3
     ml["triangleCount"][(pick >= 0.10) & (pick < 0.15) & safe] = 200
     ml["triangleCount"][(pick >= 0.15) & (pick < 0.17) & safe] = 255
     zero_v = (pick >= 0.17) & (pick < 0.20)
