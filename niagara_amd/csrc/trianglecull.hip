@@ -150,7 +150,9 @@ __global__ __launch_bounds__(TC_THREADS) void trianglecull_kernel(TriangleArgs a
 		// ---- the chunk's batches.  A batch [b, e) is the longest run of slots from b whose streams fit (one slot always does).
 		// (Measured and not kept, tools/experiments/trianglecull_pipelined_r4.diff: the loads of batch n + 1 issued before the arithmetic of
 		// batch n — 117 VGPRs, one idle batch of loads behind every chunk, 55.9 us against 52.1; batches of 384 / 576 and 512 / 768: the
-		// instruction count falls and the launch gets slower, 63-68 us, it is the waves' phases that must interleave.)
+		// instruction count falls and the launch gets slower, 63-68 us, it is the waves' phases that must interleave; chunks handed out
+		// through a ticket counter instead of a contiguous run per wave, for the tail: 164-202 us — 4-10 k returning atomics on one
+		// address are the whole launch.)
 		struct Batch
 		{
 			uint32_t b, e, svB, stB, vTotal, tTotal;      // uniform
