@@ -1603,7 +1603,13 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 // visibility-bit update, the `skip` of clusters the early pass already drew, the final ballot and the tile count.
 constexpr int CH_THREADS = 256; // lanes probing
 constexpr int CH_CMDS = 128;    // commands per block (threads 0 .. CH_CMDS - 1 own one each)
-constexpr int CH_U = 8;         // survivors per lane in flight: a round probes CH_THREADS * CH_U of the block's survivors
+#ifndef NV_CH_U
+#define NV_CH_U 4
+#endif
+// survivors per lane in flight: a round probes CH_THREADS * CH_U of the block's survivors.  Round 4 (tools/build_cc_variants.sh, the frame at
+// BASELINE scale): 8 (121 VGPRs, four waves per SIMD) 62.3-64.0 us, 6 / 5: 60.2-61.2, **4 (80 VGPRs, six waves) 58.4-59.4**, 3: 59.4; config 4's
+// short lists do not care (14.6-14.7 us at 8 and at 4)
+constexpr int CH_U = NV_CH_U;
 
 // LDS-only barrier: __syncthreads() also waits for the global loads in flight (vmcnt counts them on gfx9), and the point
 // of this kernel is to keep them in flight across the LDS hand-overs
@@ -1817,18 +1823,21 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 		// ---- one survivor per lane and slot: clustercull.comp.glsl:72-76 (sphere) and :110-123 (probe).  The first round is
 		// not a loop body: at a loop header hipcc merges the wait state of the back edge into it and waits for everything
 		// in flight (the MeshDraw and visibility words) before the first bounds load.
-#define NV_HIZ_ROUND(FIRST, base)                                                                                                                      \
-	do                                                                                                                                                 \
-	{                                                                                                                                                  \
-		const uint32_t rem = total - (base);                                                                                                           \
-		if (rem > 4u * CH_THREADS)                                                                                                                     \
-			hiz_round<8, SOA, FIRST>(a, base, total, tid, cand != 0, d0, d1, s_list, s_taskOffset, s_draw, s_mip, s_visLo, s_visHi);   \
-		else if (rem > 2u * CH_THREADS)                                                                                                                \
-			hiz_round<4, SOA, FIRST>(a, base, total, tid, cand != 0, d0, d1, s_list, s_taskOffset, s_draw, s_mip, s_visLo, s_visHi);   \
-		else if (rem > CH_THREADS)                                                                                                                     \
-			hiz_round<2, SOA, FIRST>(a, base, total, tid, cand != 0, d0, d1, s_list, s_taskOffset, s_draw, s_mip, s_visLo, s_visHi);   \
-		else                                                                                                                                           \
-			hiz_round<1, SOA, FIRST>(a, base, total, tid, cand != 0, d0, d1, s_list, s_taskOffset, s_draw, s_mip, s_visLo, s_visHi);   \
+#define NV_HIZ_ARGS(base) a, base, total, tid, cand != 0, d0, d1, s_list, s_taskOffset, s_draw, s_mip, s_visLo, s_visHi
+#define NV_HIZ_ROUND(FIRST, base)                                                                                  \
+	do                                                                                                             \
+	{                                                                                                              \
+		const uint32_t rem = total - (base);                                                                       \
+		if (CH_U > 4 && rem > 4u * CH_THREADS)                                                                     \
+			hiz_round<CH_U, SOA, FIRST>(NV_HIZ_ARGS(base));                                                        \
+		else if (CH_U >= 4 && rem > 2u * CH_THREADS)                                                               \
+			hiz_round<4, SOA, FIRST>(NV_HIZ_ARGS(base));                                                           \
+		else if (CH_U == 3 && rem > 2u * CH_THREADS)                                                               \
+			hiz_round<3, SOA, FIRST>(NV_HIZ_ARGS(base));                                                           \
+		else if (CH_U >= 2 && rem > CH_THREADS)                                                                    \
+			hiz_round<2, SOA, FIRST>(NV_HIZ_ARGS(base));                                                           \
+		else                                                                                                       \
+			hiz_round<1, SOA, FIRST>(NV_HIZ_ARGS(base));                                                           \
 	} while (0)
 		if (total == 0) // (uniform) nothing survived frustum and cone in this block: the cull kernel has cleared the bits
 			continue;
@@ -1842,6 +1851,7 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 					NV_HIZ_ROUND(false, base);
 		}
 #undef NV_HIZ_ROUND
+#undef NV_HIZ_ARGS
 		NV_LDS_BARRIER();
 
 		// ---- one command per lane: `visible` is final.  clustercull.comp.glsl:97-99 (skip what the early pass drew),
