@@ -1931,6 +1931,8 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 constexpr int CB_THREADS = 256;
 constexpr int CB_CMDS = 128; // commands per block and iteration, at most (lanes 0 .. per - 1 own one each)
 constexpr int CB_U = 4;      // list entries per lane in flight
+// (round 4, frame scale, cull 25.6-25.9 us as built: 96 commands with 5 blocks per CU 25.9-26.2, 96 / 64 commands with 6 blocks — 80 VGPRs, spills — 39-40,
+//  2 entries per lane 26.1-27.7, 8 with 3 blocks 27.6-28.5, 3 blocks per CU 27.0-28.9)
 
 // One round = CB_U list entries per lane, slot-major (slot k of lane t = entry base + k CB_THREADS + t), straight-line: all
 // loads unconditional (slots past the last entry re-read it) and issued together; a slot no lane of the wave holds an entry

@@ -25,6 +25,8 @@ namespace nv
 constexpr int DC_WAVES = 4;
 constexpr int DC_THREADS = DC_WAVES * 64;
 constexpr int DC_BATCH = 2;                          // draws per lane of the decide kernel
+// (round 4, tools/build_variant.sh, config 2 with the fused reset / the frame's two drawcull passes: 2 draws per lane x 4 waves as built 14.4 / 21-22 + 24 us;
+//  4 x 4: 15.4-15.5 / 22 + 25; 1 x 4: 14.9 / 22-26 + 25; 8 x 4: 17.5 / 24 + 28; 2 x 8: 19.3 / 25.5 + 26; 4 x 8: 21.5 / 27 + 28; 2 x 2: 17.1 / 27 + 29)
 constexpr uint32_t DC_TILE = DC_THREADS * DC_BATCH;   // draws per workgroup of the decide kernel
 // LDS-staged coarse pyramid levels for the late pass's HiZ probes (north_star: "LDS-staged HiZ tiles"): implemented,
 // measured, and compiled into the experiments build only — 1 M draws with HiZ took 31.4 us with the tail of a 2048^2 pyramid
@@ -161,10 +163,17 @@ NV_DEV DrawResult decide_post(const DrawArgs& a, const DrawPre& pre, bool visibl
 				for (uint32_t i = 1; i < NV_MAX_LODS; ++i)
 					err[i] = *reinterpret_cast<const float*>(mesh + 48 + 20 * i + 16);
 			}
+			// "the last i in [1, lodCount) with err[i] < threshold" = the highest set bit of the comparisons' mask under the count's mask.  As the
+			// loop reads (`if (i < lodCount && err[i] < threshold) lodIndex = i`) hipcc ANDs the two compares on the scalar unit into VCC and
+			// selects on it — seven s_and_b64 vcc / v_cndmask pairs at ~23 cycles each on this chip (a VCC written by the scalar unit stalls the
+			// vector instruction that reads it: tools/experiments/valu_classes.hip `vcc`) against three vector instructions per LOD here.
+			uint32_t below = 1u; // bit 0: LOD 0 is always a candidate
 #pragma unroll
 			for (uint32_t i = 1; i < NV_MAX_LODS; ++i)
-				if (i < lodCount && err[i] < threshold)
-					lodIndex = i;
+				below |= err[i] < threshold ? 1u << i : 0u;
+			const uint32_t counted = lodCount < NV_MAX_LODS ? lodCount : NV_MAX_LODS; // (i < lodCount for every i of the loop once lodCount >= 8)
+			below &= (1u << counted) - 1u | 1u;
+			lodIndex = 31u - (uint32_t)__builtin_clz(below);
 		}
 		res.lodWord = lodIndex | 0x100u;
 		if (TASK)

@@ -207,7 +207,9 @@ __global__ __launch_bounds__(1024) void vcc_kernel(float* out, uint64_t* cycles,
 {
 	float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
 	float b = 1.0000001f;
-	uint64_t sm = 0x5555555555555555ull;
+	uint64_t sm = 0x5555555555555555ull, sm2 = 0;
+	float sf = 1.0000001f, sf2 = 0;
+	asm volatile("" : "+s"(sm2), "+s"(sf2), "+s"(sf));
 	const uint64_t t0 = __builtin_readcyclecounter();
 	for (int i = 0; i < iters; ++i)
 	{
@@ -226,6 +228,25 @@ __global__ __launch_bounds__(1024) void vcc_kernel(float* out, uint64_t* cycles,
 				asm volatile("s_mov_b64 vcc, %9\n v_cndmask_b32 %0, %0, %8, vcc\n s_mov_b64 vcc, %9\n v_cndmask_b32 %1, %1, %8, vcc\n s_mov_b64 vcc, %9\n v_cndmask_b32 %2, %2, %8, vcc\n"
 				             "s_mov_b64 vcc, %9\n v_cndmask_b32 %3, %3, %8, vcc\n s_mov_b64 vcc, %9\n v_cndmask_b32 %4, %4, %8, vcc\n s_mov_b64 vcc, %9\n v_cndmask_b32 %5, %5, %8, vcc\n"
 				             "s_mov_b64 vcc, %9\n v_cndmask_b32 %6, %6, %8, vcc\n s_mov_b64 vcc, %9\n v_cndmask_b32 %7, %7, %8, vcc\n" : REGS8 : "v"(b), "s"(sm) : "vcc");
+			else if (FORM == 4) // a scalar-written SGPR pair (not VCC) as the select's mask: 8 x (s_mov, cndmask)
+				asm volatile("s_mov_b64 %10, %9\n v_cndmask_b32 %0, %0, %8, %10\n s_mov_b64 %10, %9\n v_cndmask_b32 %1, %1, %8, %10\n s_mov_b64 %10, %9\n v_cndmask_b32 %2, %2, %8, %10\n"
+				             "s_mov_b64 %10, %9\n v_cndmask_b32 %3, %3, %8, %10\n s_mov_b64 %10, %9\n v_cndmask_b32 %4, %4, %8, %10\n s_mov_b64 %10, %9\n v_cndmask_b32 %5, %5, %8, %10\n"
+				             "s_mov_b64 %10, %9\n v_cndmask_b32 %6, %6, %8, %10\n s_mov_b64 %10, %9\n v_cndmask_b32 %7, %7, %8, %10\n" : REGS8 : "v"(b), "s"(sm), "s"(sm2));
+			else if (FORM == 5) // a scalar-written SGPR as an arithmetic operand: 8 x (s_mov_b32, v_mul)
+				asm volatile("s_mov_b32 %10, %9\n v_mul_f32 %0, %10, %0\n s_mov_b32 %10, %9\n v_mul_f32 %1, %10, %1\n s_mov_b32 %10, %9\n v_mul_f32 %2, %10, %2\n"
+				             "s_mov_b32 %10, %9\n v_mul_f32 %3, %10, %3\n s_mov_b32 %10, %9\n v_mul_f32 %4, %10, %4\n s_mov_b32 %10, %9\n v_mul_f32 %5, %10, %5\n"
+				             "s_mov_b32 %10, %9\n v_mul_f32 %6, %10, %6\n s_mov_b32 %10, %9\n v_mul_f32 %7, %10, %7\n" : REGS8 : "v"(b), "s"(sf), "s"(sf2));
+			else if (FORM == 6) // VCC from the scalar unit, a multiply, then the select: 8 x (s_mov, mul, cndmask) — does one instruction of distance hide it?
+				asm volatile("s_mov_b64 vcc, %9\n v_mul_f32 %1, %1, %8\n v_cndmask_b32 %0, %0, %8, vcc\n s_mov_b64 vcc, %9\n v_mul_f32 %2, %2, %8\n v_cndmask_b32 %1, %1, %8, vcc\n"
+				             "s_mov_b64 vcc, %9\n v_mul_f32 %3, %3, %8\n v_cndmask_b32 %2, %2, %8, vcc\n s_mov_b64 vcc, %9\n v_mul_f32 %4, %4, %8\n v_cndmask_b32 %3, %3, %8, vcc\n"
+				             "s_mov_b64 vcc, %9\n v_mul_f32 %5, %5, %8\n v_cndmask_b32 %4, %4, %8, vcc\n s_mov_b64 vcc, %9\n v_mul_f32 %6, %6, %8\n v_cndmask_b32 %5, %5, %8, vcc\n"
+				             "s_mov_b64 vcc, %9\n v_mul_f32 %7, %7, %8\n v_cndmask_b32 %6, %6, %8, vcc\n s_mov_b64 vcc, %9\n v_mul_f32 %0, %0, %8\n v_cndmask_b32 %7, %7, %8, vcc\n" : REGS8 : "v"(b), "s"(sm) : "vcc");
+			else if (FORM == 7) // a compare into an SGPR pair, the scalar unit ANDs it into another pair, the select reads that: 8 x (cmp, s_and, cndmask)
+				asm volatile("v_cmp_lt_f32 %10, %8, %0\n s_and_b64 %10, %10, %9\n v_cndmask_b32 %0, %0, %8, %10\n v_cmp_lt_f32 %10, %8, %1\n s_and_b64 %10, %10, %9\n v_cndmask_b32 %1, %1, %8, %10\n"
+				             "v_cmp_lt_f32 %10, %8, %2\n s_and_b64 %10, %10, %9\n v_cndmask_b32 %2, %2, %8, %10\n v_cmp_lt_f32 %10, %8, %3\n s_and_b64 %10, %10, %9\n v_cndmask_b32 %3, %3, %8, %10\n"
+				             "v_cmp_lt_f32 %10, %8, %4\n s_and_b64 %10, %10, %9\n v_cndmask_b32 %4, %4, %8, %10\n v_cmp_lt_f32 %10, %8, %5\n s_and_b64 %10, %10, %9\n v_cndmask_b32 %5, %5, %8, %10\n"
+				             "v_cmp_lt_f32 %10, %8, %6\n s_and_b64 %10, %10, %9\n v_cndmask_b32 %6, %6, %8, %10\n v_cmp_lt_f32 %10, %8, %7\n s_and_b64 %10, %10, %9\n v_cndmask_b32 %7, %7, %8, %10\n"
+				             : REGS8 : "v"(b), "s"(sm), "s"(sm2) : "scc");
 			else // selects on VCC with a multiply between them: 8 x (cndmask, mul) = 16 instructions
 				asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_mul_f32 %1, %1, %8\n v_cndmask_b32 %2, %2, %8, vcc\n v_mul_f32 %3, %3, %8\n v_cndmask_b32 %4, %4, %8, vcc\n v_mul_f32 %5, %5, %8\n"
 				             "v_cndmask_b32 %6, %6, %8, vcc\n v_mul_f32 %7, %7, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_mul_f32 %0, %0, %8\n v_cndmask_b32 %3, %3, %8, vcc\n v_mul_f32 %2, %2, %8\n"
@@ -386,6 +407,10 @@ int main(int argc, char** argv)
 		time_kernel(vcc_kernel<1>, "v_cmp + 4 x v_cndmask vcc (per group of 5)", 16.0, out, cyc);
 		time_kernel(vcc_kernel<2>, "s_mov vcc + v_cndmask vcc (per pair)", 64.0, out, cyc);
 		time_kernel(vcc_kernel<3>, "v_cndmask vcc + v_mul (per pair)", 64.0, out, cyc);
+		time_kernel(vcc_kernel<4>, "s_mov sgpr pair + v_cndmask on it (per pair)", 64.0, out, cyc);
+		time_kernel(vcc_kernel<5>, "s_mov sgpr + v_mul reading it (per pair)", 64.0, out, cyc);
+		time_kernel(vcc_kernel<6>, "s_mov vcc + v_mul + v_cndmask vcc (per group of 3)", 64.0, out, cyc);
+		time_kernel(vcc_kernel<7>, "v_cmp -> sgpr, s_and, v_cndmask on it (per group of 3)", 64.0, out, cyc);
 	}
 	if (argc < 2 || !strcmp(argv[1], "exhaustive"))
 	{
