@@ -1603,6 +1603,8 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 // visibility-bit update, the `skip` of clusters the early pass already drew, the final ballot and the tile count.
 constexpr int CH_THREADS = 256; // lanes probing
 constexpr int CH_CMDS = 128;    // commands per block (threads 0 .. CH_CMDS - 1 own one each)
+// (round 4, frame scale, experiments flavour, lanes x commands x blocks per sub-list: 256 x 128 x 4 as built 59.7 us; 256 x 64 x 4 / 8: 61.4-64.4; 512 x 128 x 2 / 4:
+//  67.6-69.2; 512 x 256 x 2 / 3: 60.7-62.6; 128 x 64 x 8 / 12: 63.5-66.6; 128 x 128 x 6 / 8: 71.5-72.5; blocks per sub-list 4 / 5 / 6 / 7 / 8 / 12 at 256 x 128: 59.6 / 61.8 / 61.2 / 62.7 / 60.3 / 60.1)
 #ifndef NV_CH_U
 #define NV_CH_U 4
 #endif
