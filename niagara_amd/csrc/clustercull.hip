@@ -1624,9 +1624,38 @@ constexpr int CH_U = NV_CH_U;
 // One round: U survivors per lane, straight-line — every load is unconditional (slots past the block's last survivor re-read
 // it, inactive probes fetch clamped texels) so that hipcc can count its waits and all U bounds, then all 4 U texels, are in
 // flight together.  The first round also hands the MeshDraws over through LDS, behind the bounds loads.
+// Experiments build, NV_DEBUG_MODE bit 28: where a wave of the stage spends its cycles (tools/experiments/hiz_timeline.py).  Phase sums per wave:
+// 0 list / draws / compaction of a chunk, 1 a round's bounds (issue to arrival), 2 its probes' arithmetic (the texel loads issued behind each),
+// 3 the texels (the wait that is left), 4 comparisons and LDS atomics, 5 a chunk's per-command epilogue; the stamped build waits for ALL loads at
+// the phase boundaries, which the product does not.
+struct HizTimes
+{
+	bool on;
+	uint64_t prev;
+	uint64_t acc[6];
+	uint32_t rounds;
+};
+#ifdef NV_EXPERIMENTS
+#define NV_HIZ_T(T, i, drain)                                                  \
+	do                                                                         \
+	{                                                                          \
+		if ((T).on)                                                            \
+		{                                                                      \
+			if (drain)                                                         \
+				asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    \
+			const uint64_t now = __builtin_readcyclecounter();                 \
+			(T).acc[i] += now - (T).prev;                                      \
+			(T).prev = now;                                                    \
+		}                                                                      \
+	} while (0)
+#else
+#define NV_HIZ_T(T, i, drain) do { } while (0)
+#endif
+
 template <int U, bool SOA, bool FIRST>
 NV_DEV void hiz_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint32_t tid, bool ownsDraw, const float4& d0, const float4& d1,
-                      const uint16_t* s_list, const uint32_t* s_taskOffset, float4 (*s_draw)[2], const MipRecord* s_mip, uint32_t* s_visLo, uint32_t* s_visHi)
+                      const uint16_t* s_list, const uint32_t* s_taskOffset, float4 (*s_draw)[2], const MipRecord* s_mip, uint32_t* s_visLo, uint32_t* s_visHi,
+                      HizTimes& T)
 {
 	const float* __restrict__ texels = a.pyr.d_base;
 	uint32_t e[U];
@@ -1651,6 +1680,7 @@ NV_DEV void hiz_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint3
 		}
 		NV_LDS_BARRIER();
 	}
+	NV_HIZ_T(T, 1, true);
 	float depth[U];
 	uint32_t use[U];
 	float t00[U], t10[U], t01[U], t11[U];
@@ -1680,6 +1710,8 @@ NV_DEV void hiz_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint3
 		t01[k] = texels[p.o01 & zero];
 		t11[k] = texels[p.o11 & zero];
 	}
+	NV_HIZ_T(T, 2, false);
+	NV_HIZ_T(T, 3, true);
 #pragma unroll
 	for (int k = 0; k < U; ++k)
 	{
@@ -1691,6 +1723,8 @@ NV_DEV void hiz_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint3
 			atomicAnd(bit < 32u ? &s_visLo[owner] : &s_visHi[owner], ~(1u << (bit & 31u)));
 		}
 	}
+	NV_HIZ_T(T, 4, true);
+	T.rounds += 1u;
 }
 
 template <bool SOA, bool BITS>
@@ -1705,6 +1739,11 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	HizTimes T = { NV_DBG(a, 268435456u) && a.probeOut != nullptr, 0, { 0, 0, 0, 0, 0, 0 }, 0 }; // bit 28 (experiments): phase stamps
+#ifdef NV_EXPERIMENTS
+	const uint64_t tEntry = T.on ? __builtin_readcyclecounter() : 0;
+	T.prev = tEntry;
+#endif
 	{
 		// per-level records for the probes (cullmath.h MipRecord), built from the scalar kernel arguments with constant indices
 		uint32_t off = 0;
@@ -1825,7 +1864,7 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 		// ---- one survivor per lane and slot: clustercull.comp.glsl:72-76 (sphere) and :110-123 (probe).  The first round is
 		// not a loop body: at a loop header hipcc merges the wait state of the back edge into it and waits for everything
 		// in flight (the MeshDraw and visibility words) before the first bounds load.
-#define NV_HIZ_ARGS(base) a, base, total, tid, cand != 0, d0, d1, s_list, s_taskOffset, s_draw, s_mip, s_visLo, s_visHi
+#define NV_HIZ_ARGS(base) a, base, total, tid, cand != 0, d0, d1, s_list, s_taskOffset, s_draw, s_mip, s_visLo, s_visHi, T
 #define NV_HIZ_ROUND(FIRST, base)                                                                                  \
 	do                                                                                                             \
 	{                                                                                                              \
@@ -1843,6 +1882,7 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 	} while (0)
 		if (total == 0) // (uniform) nothing survived frustum and cone in this block: the cull kernel has cleared the bits
 			continue;
+		NV_HIZ_T(T, 0, false);
 		if (!NV_DBG(a, 8388608u)) // bit 23 (experiments): no probes
 		{
 			NV_HIZ_ROUND(true, 0u);
@@ -1907,7 +1947,18 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 		}
 		if (m) // the listed commands come in no particular order: one add per command
 			atomicAdd(&a.tileCounts->counts[bank][(idx / T2) * CC_COUNT_STRIDE], (uint32_t)__builtin_popcountll(m));
+		NV_HIZ_T(T, 5, false);
 	}
+#ifdef NV_EXPERIMENTS
+	if (T.on && lane == 0)
+	{
+		unsigned long long* out = reinterpret_cast<unsigned long long*>(a.probeOut) + (size_t)(blockIdx.x * (CH_THREADS / 64) + wave) * 8u;
+		for (int i = 0; i < 6; ++i)
+			out[i] = T.acc[i];
+		out[6] = __builtin_readcyclecounter() - tEntry;
+		out[7] = T.rounds;
+	}
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -887,7 +887,7 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	a.countsSink = reinterpret_cast<unsigned long long*>(ctx->countsSink);
 #ifdef NV_EXPERIMENTS
 	a.debugMode = ctx->debugMode;
-	if (ctx->debugMode & 8u)
+	if (ctx->debugMode & (8u | 268435456u)) // bit 3: the cull launch's wave stamps; bit 28: the occlusion stage's phase sums
 	{
 		if (!ctx->timing)
 			(void)scratch_alloc(&ctx->timing, (size_t)persistent_grid(ctx, 8) * 4 * 8 * sizeof(unsigned long long)); // (room for any NV_OPT_CULL_WORKGROUPS_PER_CU)

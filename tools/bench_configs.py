@@ -276,6 +276,27 @@ def config4(ctx, iters, size=4096, n_draws=15625, cpd=10, copies=4):
                 late_pass_frac=algo / pass_us / 1e3 / HBM, meshlets_per_s=m / (pass_us * 1e-6))
 
 
+def hiz_phase_sums(ctx, waves=4096):
+    """experiments build, NV_DEBUG_MODE bit 28: per-wave cycle sums of cluster_hiz_kernel's phases (clustercull.hip HizTimes) of the last late pass"""
+    import ctypes as C
+    from niagara_amd._lib import lib
+    out = np.zeros((6144, 8), dtype=np.uint64)
+    lib.nv_debug_read_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    if lib.nv_debug_read_timing(ctx.h, out.ctypes.data_as(C.c_void_p), 6144):
+        return None
+    t = out[:waves].astype(np.float64)
+    t = t[t[:, 6] > 0]
+    names = ("chunk_setup", "bounds_wait", "probe_arithmetic", "texel_wait", "finish_atomics", "epilogue")
+    tot = t[:, 6]
+    r = {"waves": int(len(t)), "rounds_per_wave_mean": float(t[:, 7].mean()), "lifetime_cycles_mean": float(tot.mean()), "lifetime_cycles_p95": float(np.percentile(tot, 95)),
+         "lifetime_cycles_max": float(tot.max())}
+    for i, n in enumerate(names):
+        r[n + "_share"] = float(t[:, i].sum() / tot.sum())
+        r[n + "_cycles_per_round"] = float(t[:, i].sum() / max(1.0, t[:, 7].sum()))
+    r["unaccounted_share"] = float(1.0 - t[:, :6].sum() / tot.sum())
+    return r
+
+
 def frame_scene(n_draws, lod0, size):
     """the frame benchmark's scene: niagara's draw generator over 64 meshes x 4 LODs, a seeded meshlet pool, a synthetic depth
     target; flags as niagara ships them with every culling feature on"""
@@ -418,6 +439,7 @@ def config_frame(ctx, iters, n_draws=1_000_000, lod0=2200, size=4096, copies=3, 
     ctx.profile(False)
     kernel_variants = ctx.profile_variants()  # which forms the host's per-launch choices resolved to in the frames of the breakdown
     breakdown = {n + "_us": acc[n] / n_b * 1e3 for n in names}
+    hiz_phases = hiz_phase_sums(ctx) if int(os.environ.get("NV_DEBUG_MODE", "0")) & 268435456 else None  # experiments build, bit 28
 
     # ---- parity: one more frame on the next copy with every buffer of both phases read back, against the oracle after the same
     # number of frames on that copy (errors of the timed frames would sit in its visibility state)
@@ -461,7 +483,7 @@ def config_frame(ctx, iters, n_draws=1_000_000, lod0=2200, size=4096, copies=3, 
     tested = e["tested"] + l["tested"]
     out = dict(config="frame: 1M draws, early cull -> pyramid -> late cull at BASELINE scale" + (" (fused: 11 launches)" if fused else " (reference dispatch sequence: 19 launches)"),
                draws=n_draws, lod0_meshlets=lod0, depth=size, scene_copies_rotated=copies, frames_timed=iters, frame_us=frame_us, **breakdown,
-               sum_of_kernels_us=sum(breakdown.values()), kernel_variants=kernel_variants,
+               sum_of_kernels_us=sum(breakdown.values()), kernel_variants=kernel_variants, **({"hiz_phases": hiz_phases} if hiz_phases else {}),
                early=dict(task_commands=int(e["count4"][0]), meshlets_tested=e["tested"], visible=int(e["cc4"][0])),
                late=dict(task_commands=int(l["count4"][0]), meshlets_tested=l["tested"], visible=int(l["cc4"][0]), draws_visible=int(l["dvb"].sum())),
                algorithmic_bytes=algo, algorithmic_bytes_by_pass=bytes_, achieved_GBs=algo / frame_us / 1e3, frac=algo / frame_us / 1e3 / HBM,
