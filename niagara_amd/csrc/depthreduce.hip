@@ -220,10 +220,16 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(ChainArgs a)
 	const uint32_t col0 = blockIdx.x * 256u + lane * 4u; // source column of this lane
 	const uint32_t row0 = blockIdx.y * 32u + wave * 8u;  // first source row of this wave
 
+	// the depth target is read once: non-temporal loads, which leave the caches to the pyramid the late passes probe (round 4: the two launches
+	// 29.7-29.8 -> 27.7-27.9 us by events, the frame 202.4-203.2 -> 198.0-200.2 us — the passes behind the pyramid find more of their data in the L2)
+	typedef float v4f __attribute__((ext_vector_type(4)));
 	float4 v[8];
 #pragma unroll
 	for (int r = 0; r < 8; ++r)
-		v[r] = *reinterpret_cast<const float4*>(a.src + (size_t)(row0 + r) * a.sw + col0);
+	{
+		const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(a.src + (size_t)(row0 + r) * a.sw + col0));
+		v[r] = make_float4(t.x, t.y, t.z, t.w);
+	}
 
 	// level L: 2 x 4 per lane
 	float q[4][2];
