@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(ChainArgs a)
 		float* dst = a.base + a.mipOffset[L] + (size_t)(row0 / 2) * lw + col0 / 2;
 #pragma unroll
 		for (int i = 0; i < 4; ++i)
-			*reinterpret_cast<float2*>(dst + (size_t)i * lw) = make_float2(q[i][0], q[i][1]);
+			*reinterpret_cast<float2*>(dst + (size_t)i * lw) = make_float2(q[i][0], q[i][1]); // (cacheable: stored non-temporal, level 0 costs the late pass's occlusion stage 6 us — 58.7 -> 65.1 at frame scale)
 	}
 	if (a.numLevels < 2)
 		return;
