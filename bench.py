@@ -205,13 +205,16 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    for s in streams:
-        s.synchronize()
+    if world > 1:
+        for s in streams:
+            s.synchronize()
     t_passes = time.perf_counter()
     drain(args.steps)  # every pass's reduction completes inside the timed region
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    collective_wait = time.perf_counter() - t_passes  # what the job waited for collectives after its last pass had finished
+    # what the job waited for collectives after its last pass had finished (N = 1: no collective, and no separate wait for the passes either —
+    # the closing device synchronisation is the contract's bracket; a stream synchronisation in front of it was one more driver call per region)
+    collective_wait = time.perf_counter() - t_passes if world > 1 else 0.0
     s_last = (args.steps - 1) % S
     last_counts = reds[s_last].last(passes_of(s_last, args.steps))
     visible_by_stream = [int(c[0].item()) for c in ccbs[:S]]
