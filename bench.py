@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--aos", action="store_true", help="read the 24-B AoS meshlets in place (no SoA mirror)")
     ap.add_argument("--counts-batch", type=int, default=8, help="N > 1: passes whose counts share one all-reduce (1 = one collective per pass)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for functional tests)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="take every N > 1 branch also with ONE rank (process group, warm-up all-reduce, the batched asynchronous counts all-reduce, barrier, "
+                         "MAX over the ranks, per-rank oracle check + flag all-reduce): the sharded path over RCCL on a one-GPU box (VERDICT r4 item 2)")
     ap.add_argument("--shared-device", action="store_true", help="functional test only: all ranks use cuda:0 (needs --backend gloo)")
     ap.add_argument("--streams", type=int, default=1,
                     help="streams of the timed region: 1 (default) = strictly one pass after the other; > 1 issues the steps round-robin on that many HIP streams "
@@ -119,7 +122,16 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # `sharded`: the N > 1 code path.  --force-sharded takes it with one rank too (under torch.distributed.run --nproc-per-node 1, or
+    # stand-alone: the rendezvous variables then default to this host and a free port)
+    sharded = world > 1 or args.force_sharded
+    if args.force_sharded and "MASTER_ADDR" not in os.environ:
+        import socket
+        s0 = socket.socket()
+        s0.bind(("127.0.0.1", 0))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s0.getsockname()[1]), RANK="0", WORLD_SIZE="1")
+        s0.close()
+    if sharded:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -139,7 +151,7 @@ def main():
     count4 = synth.count4_for(n_cmd)
 
     S = max(1, args.streams)
-    OS = max(0, args.overlap_streams) if world == 1 else 0
+    OS = max(0, args.overlap_streams) if not sharded else 0
     ctxs = [P.Context(local_rank) for _ in range(max(S, OS, 1))]
     ctx = ctxs[0]
     for c in ctxs[1:]:
@@ -165,7 +177,7 @@ def main():
     # N > 1: the passes' counts are summed over the ranks; batched, asynchronous, written by the scatter launch (shard.CountsReducer,
     # one per stream: a stream's reducer sees that stream's passes)
     B = max(1, args.counts_batch)
-    reds = [shard.CountsReducer(ctxs[s], dev, B, stream=streams[s] if S > 1 else None) for s in range(S)]
+    reds = [shard.CountsReducer(ctxs[s], dev, B, stream=streams[s] if S > 1 else None, force_collective=args.force_sharded) for s in range(S)]
     if not args.aos:
         ctx.upload_meshlets(mlb, copies * n_meshlets)
     torch.cuda.synchronize()
@@ -195,7 +207,7 @@ def main():
         step(i)
     drain(args.warmup)
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
         torch.cuda.synchronize()
 
@@ -205,7 +217,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    if world > 1:
+    if sharded:
         for s in streams:
             s.synchronize()
     t_passes = time.perf_counter()
@@ -214,7 +226,7 @@ def main():
     elapsed = time.perf_counter() - t0
     # what the job waited for collectives after its last pass had finished (N = 1: no collective, and no separate wait for the passes either —
     # the closing device synchronisation is the contract's bracket; a stream synchronisation in front of it was one more driver call per region)
-    collective_wait = time.perf_counter() - t_passes if world > 1 else 0.0
+    collective_wait = time.perf_counter() - t_passes if sharded else 0.0
     s_last = (args.steps - 1) % S
     last_counts = reds[s_last].last(passes_of(s_last, args.steps))
     visible_by_stream = [int(c[0].item()) for c in ccbs[:S]]
@@ -222,7 +234,7 @@ def main():
     # ---- roofline leg: the same passes again with the library's HIP events bracketing each kernel on the launch stream
     # (nv_profile_*), one pass after the other on ONE stream — the mode `value` is measured in when --streams is 1.  It is a
     # separate loop because an event record is itself a barrier packet: three records per pass cost ~10 us per pass.
-    single = shard.CountsReducer(ctx, dev, B)
+    single = shard.CountsReducer(ctx, dev, B, force_collective=args.force_sharded)
     serial_calls = [ctx.bind_clustercull(None, cd, 0, dcbs[c], dccb, db, mlb, None, None, cib, ccb) for c in range(copies)]
 
     def serial_step(i):
@@ -284,7 +296,7 @@ def main():
         for c in ctxs[:OS]:
             c.set_option(P.NV_OPT_SCATTER_WAVES, scatter_waves)
 
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed, collective_wait], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, collective_wait = float(t[0].item()), float(t[1].item())
@@ -331,8 +343,9 @@ def main():
                        "streams": S, "scatter_waves_per_workgroup": scatter_waves,
                        "regime": "one pass after the other on one stream" if S == 1 else "steps issued round-robin on %d HIP streams (independent passes in flight)" % S,
                        "input_copies_rotated": copies, "count_reset": "explicit launch" if args.explicit_reset else "fused (NV_OPT_FUSED_COUNT_RESET)", "meshlet_layout": "AoS24" if args.aos else "SoA12",
+                       "force_sharded": bool(args.force_sharded), "backend": args.backend if sharded else None,
                        "visible_rank0": visible, "visible_per_stream": visible_by_stream, "visible_total": total_visible, "sharding": "commands x%d" % world,
-                       "counts_allreduce": ("none (N=1)" if world == 1 else "one async all-reduce of [%d, 3] int64 per %d passes, rows written by the scatter launch" % (B, B))},
+                       "counts_allreduce": ("none (N=1)" if not sharded else "one async all-reduce of [%d, 3] int64 per %d passes, rows written by the scatter launch" % (B, B))},
             "collective_wait_ms": collective_wait * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_measured_in_run": False, "traffic_source": traffic_note,
@@ -354,8 +367,13 @@ def main():
     # CPU baseline runs on rank 0's host cores after the other ranks' checks have finished (they share the host): at N = 1 over the
     # whole batch, at N > 1 over rank 0's shard — a bounded sample of the same workload, reported as a rate.
     if not args.no_cpu_baseline:
-        ok, detail = oracle_check(args, cd, draws, meshlets, cmd_b, cmd_e, visible, visible_ids) if world > 1 else (True, "")
-        if world > 1:
+        ok, detail = True, ""
+        if sharded:
+            try:  # (a rank that fails INSIDE the check must still reach the all-reduce: the others would wait for it until the rendezvous times out)
+                ok, detail = oracle_check(args, cd, draws, meshlets, cmd_b, cmd_e, visible, visible_ids)
+            except Exception as exc:  # noqa: BLE001
+                ok, detail = False, "oracle check raised %s: %s" % (type(exc).__name__, exc)
+        if sharded:
             flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.SUM)
             agreeing = int(flag.item())
@@ -368,13 +386,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, cd, draws, meshlets, cmd_b, cmd_e, visible, visible_ids, world)
             out["parity"] = "bit-identical"
             out["parity_checked"] = ("visible-ID list and count of the benchmarked pass against the CPU oracle: " +
-                                     ("the whole batch" if world == 1 else "every rank on its own shard, %d of %d ranks agree" % (world, world)))
+                                     ("the whole batch" if not sharded else "every rank on its own shard, %d of %d ranks agree" % (world, world)))
+    elif rank == 0:
+        out["parity"] = "not checked (--no-cpu-baseline)"
     if rank == 0:
         print(json.dumps(out), flush=True)
 
     for c in ctxs:
         c.close()
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -218,8 +218,12 @@ int main(int argc, char** argv)
 	const int D = wantDevices > 0 && wantDevices <= visible ? wantDevices : visible;
 	// --shards S > devices: S ranks dealt round-robin over the D devices — the sharding, the per-rank passes and the ID rebasing of an
 	// S-GPU node on fewer GPUs (config 5's eight shards on a one-GPU box).  RCCL refuses the same device twice in one communicator
-	// (ncclCommInitAll: "duplicate GPU"), so the phase's counts are then summed on the host instead of by ncclAllReduce; with one rank per
-	// device (the default) nothing changes.
+	// (ncclCommInitAll: "duplicate GPU"), so the communicator always has ONE rank per device and the ranks that share a device are
+	// summed into the device's first rank on the host before the collective (and handed the result after it): the communicator set-up,
+	// the grouped ncclAllReduce over `comms` and everything up to it are the SAME statements in both modes — on an 8-GPU node the only
+	// difference is that ncclCommInitAll's device list and the group loop have eight entries instead of one.
+	if (wantShards > 0 && wantShards < D)
+		fprintf(stderr, "shard_driver: --shards %d is fewer than the %d devices in use: ignored (one rank per device; use --devices %d)\n", wantShards, D, wantShards);
 	const int N = wantShards > D ? wantShards : D;
 	const bool oversubscribed = N > D;
 	const uint64_t totalCmd = totalMeshlets ? totalMeshlets / 64 : (uint64_t)drawsPerDevice * cpd * N;
@@ -230,8 +234,7 @@ int main(int argc, char** argv)
 	for (int r = 0; r < D; ++r)
 		devlist[r] = r;
 	std::vector<ncclComm_t> comms(D);
-	if (!oversubscribed)
-		CHECK_NCCL(ncclCommInitAll(comms.data(), D, devlist.data()));
+	CHECK_NCCL(ncclCommInitAll(comms.data(), D, devlist.data()));
 
 	// ---- the pool: draws replicated (each device keeps the slice its commands reference), commands + meshlets sharded
 	std::vector<NvMeshDraw> draws(totalDraws);
@@ -296,29 +299,36 @@ int main(int argc, char** argv)
 			if (keepLocal)
 				CHECK_HIP(hipMemcpyAsync(d.local, d.counts, 24, hipMemcpyDeviceToDevice, d.stream));
 		}
-		if (!oversubscribed)
+		if (oversubscribed)
 		{
-			CHECK_NCCL(ncclGroupStart());
-			for (Device& d : devs)
-				CHECK_NCCL(ncclAllReduce(d.counts, d.counts, 3, ncclUint64, ncclSum, comms[d.id], d.stream));
-			CHECK_NCCL(ncclGroupEnd());
-		}
-		else
-		{
-			// more ranks than devices: the same sum on the host (functional stand-in for the collective; synchronises every phase)
-			uint64_t sum[3] = { 0, 0, 0 }, one[3];
-			for (Device& d : devs)
+			// more ranks than devices: the ranks of one device are summed into its first rank (rank id < D) on the host — functional
+			// stand-in for the extra communicator ranks RCCL refuses; synchronises every phase
+			for (int dv = 0; dv < D; ++dv)
 			{
-				CHECK_HIP(hipSetDevice(d.dev));
-				CHECK_HIP(hipStreamSynchronize(d.stream));
-				CHECK_HIP(hipMemcpy(one, d.counts, 24, hipMemcpyDeviceToHost));
-				for (int k = 0; k < 3; ++k)
-					sum[k] += one[k];
+				uint64_t sum[3] = { 0, 0, 0 }, one[3];
+				CHECK_HIP(hipSetDevice(dv));
+				for (int r = dv; r < N; r += D)
+				{
+					CHECK_HIP(hipStreamSynchronize(devs[r].stream));
+					CHECK_HIP(hipMemcpy(one, devs[r].counts, 24, hipMemcpyDeviceToHost));
+					for (int k = 0; k < 3; ++k)
+						sum[k] += one[k];
+				}
+				CHECK_HIP(hipMemcpy(devs[dv].counts, sum, 24, hipMemcpyHostToDevice));
 			}
-			for (Device& d : devs)
+		}
+		// ONE ncclAllReduce(ncclSum) of 3 x u64 per device and phase, grouped (one call per rank of the communicator, all from this process)
+		CHECK_NCCL(ncclGroupStart());
+		for (int dv = 0; dv < D; ++dv)
+			CHECK_NCCL(ncclAllReduce(devs[dv].counts, devs[dv].counts, 3, ncclUint64, ncclSum, comms[dv], devs[dv].stream));
+		CHECK_NCCL(ncclGroupEnd());
+		if (oversubscribed)
+		{
+			for (int r = D; r < N; ++r) // the device's other ranks receive what its first rank holds
 			{
-				CHECK_HIP(hipSetDevice(d.dev));
-				CHECK_HIP(hipMemcpy(d.counts, sum, 24, hipMemcpyHostToDevice));
+				CHECK_HIP(hipSetDevice(devs[r].dev));
+				CHECK_HIP(hipStreamSynchronize(devs[r % D].stream));
+				CHECK_HIP(hipMemcpyAsync(devs[r].counts, devs[r % D].counts, 24, hipMemcpyDeviceToDevice, devs[r].stream));
 			}
 		}
 	};
@@ -360,11 +370,13 @@ int main(int argc, char** argv)
 	agree = agree && reduced[1] == sumCommands && reduced[2] == sumVisible && sumCommands == totalCmd;
 
 	printf("{\"shard_driver\": \"rccl\", \"devices\": %d, \"shards\": %d, \"meshlets_total\": %llu, \"commands_total\": %llu, \"steps\": %d, \"ms_per_step\": %.5f, "
-	       "\"meshlets_per_s\": %.4e, \"scaling\": \"%s\", \"visible_total\": %llu, \"allreduce\": \"%s\", "
+	       "\"meshlets_per_s\": %.4e, \"timing\": \"%s\", \"scaling\": \"%s\", \"visible_total\": %llu, \"allreduce\": \"%s\", "
 	       "\"counts_agree_on_all_ranks\": %s}\n",
 	       D, N, (unsigned long long)(totalCmd * 64), (unsigned long long)totalCmd, steps, seconds / steps * 1e3, (double)(totalCmd * 64) * steps / seconds,
+	       oversubscribed ? "host-synchronised every phase (ranks sharing a device): not comparable with one rank per device" : "asynchronous: passes and collectives queued on the devices' streams",
 	       totalMeshlets ? "strong" : "weak", (unsigned long long)reduced[2],
-	       oversubscribed ? "host sum per phase (more shards than devices: RCCL refuses a device twice in one communicator)" : "one ncclAllReduce(ncclSum) of 3 x u64 per phase",
+	       oversubscribed ? "one ncclAllReduce(ncclSum) of 3 x u64 per DEVICE and phase; the ranks sharing a device are summed on the host first (RCCL refuses a device twice in one communicator)"
+	                      : "one ncclAllReduce(ncclSum) of 3 x u64 per phase",
 	       agree ? "true" : "false");
 
 	if (!dump.empty())
@@ -421,8 +433,7 @@ int main(int argc, char** argv)
 		nv_destroy(d.ctx);
 		CHECK_HIP(hipStreamDestroy(d.stream));
 	}
-	if (!oversubscribed)
-		for (ncclComm_t c : comms)
-			ncclCommDestroy(c);
+	for (ncclComm_t c : comms)
+		ncclCommDestroy(c);
 	return agree ? 0 : 6;
 }

@@ -51,7 +51,7 @@ class CountsReducer:
     and do not read a block between before_pass and drain — rows not yet rewritten still hold the previous use's sums.
     """
 
-    def __init__(self, ctx, device, batch=8, stream=None):
+    def __init__(self, ctx, device, batch=8, stream=None, force_collective=False):
         import contextlib
         import torch
         import torch.distributed as dist
@@ -60,6 +60,9 @@ class CountsReducer:
         # waits are issued on it
         self._on = (lambda: torch.cuda.stream(stream)) if stream is not None else contextlib.nullcontext
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # force_collective (bench.py --force-sharded): issue the all-reduces also in a process group of ONE rank — the sharded path
+        # (asynchronous batched all-reduce on device tensors, its stream ordering, the waits) executed over RCCL on a one-GPU box
+        self.collective = self.world > 1 or (bool(force_collective) and dist.is_available() and dist.is_initialized())
         self.blocks = [torch.zeros((self.B, 3), dtype=torch.int64, device=device) for _ in range(2)]
         self.pending = [None, None]
         # the rows' addresses, marshalled once: before_pass runs once per pass, and a pass is ~30 us
@@ -70,7 +73,7 @@ class CountsReducer:
 
     def before_pass(self, i):
         blk, row = (i // self.B) % 2, i % self.B
-        if self.world == 1:  # nothing to sum: the scatter launch still leaves the pass's counts in its row, so last() holds for any world size
+        if not self.collective:  # nothing to sum: the scatter launch still leaves the pass's counts in its row, so last() holds for any world size
             self._sink(self.ctx.h, self._rows[blk][row])
             return
         if row == 0:
@@ -81,14 +84,14 @@ class CountsReducer:
         self._sink(self.ctx.h, self._rows[blk][row])
 
     def after_pass(self, i):
-        if self.world > 1 and i % self.B == self.B - 1:
+        if self.collective and i % self.B == self.B - 1:
             blk = (i // self.B) % 2
             with self._on():
                 self.pending[blk] = self.dist.all_reduce(self.blocks[blk], async_op=True)
 
     def drain(self, n_steps):
         """reduces the rows of a batch the loop left unfinished, then waits for everything in flight"""
-        if self.world == 1:
+        if not self.collective:
             return
         with self._on():
             if n_steps % self.B:

@@ -71,6 +71,47 @@ def test_bench_two_ranks_on_one_device(batch, streams, total):
         assert rec["parity"] == "bit-identical" and "2 of 2 ranks" in rec["parity_checked"] and rec["cpu_baseline"]["value"] > 0
 
 
+@pytest.mark.parametrize("batch, streams, launcher", [(1, 1, "run"), (3, 1, "run"), (8, 1, "run"), (8, 2, "run"), (3, 2, "run"), (8, 1, "alone")])
+def test_bench_forced_sharded_over_rccl(batch, streams, launcher):
+    """the sharded Python path over RCCL before the driver's 8-GPU run.  `torch.distributed.run --nproc-per-node 1
+    bench.py --gpus 1 --force-sharded` (backend nccl = RCCL) takes every N > 1 branch with one rank: process group + warm-up
+    all-reduce, CountsReducer's asynchronous batched all-reduce on the device rows the scatter launch writes (its stream ordering and
+    waits — under gloo those collectives are host-synchronous), barrier, MAX over the ranks, per-rank oracle check + flag all-reduce.
+    The reduced counts must be the pass's own and the visible-ID list the oracle's.  launcher "alone": plain `python bench.py
+    --force-sharded` (the rendezvous variables default to this host)."""
+    import argparse
+    import oracle
+    sys.path.insert(0, ROOT)
+    import bench
+    from niagara_amd import synth
+    draws, cpd, steps = 3000, 10, 19  # (19: a partial last batch for every batch size but 1)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--backend", "nccl", "--steps", str(steps), "--warmup", "3", "--counts-batch", str(batch),
+            "--streams", str(streams), "--draws", str(draws), "--cpu-seconds", "0.2"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if launcher == "run":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
+        for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    cfg = rec["config"]
+    assert rec["n_gpus"] == 1 and cfg["force_sharded"] is True and cfg["backend"] == "nccl" and cfg["streams"] == streams
+    assert "async all-reduce" in cfg["counts_allreduce"] and rec["throughput_overlapped"] is None and "collective_wait_ms" in rec
+    args = argparse.Namespace(draws=draws, commands_per_draw=cpd, total_meshlets=0)
+    d, meshlets, cd, (b, e), _ = bench.make_inputs(args, 0, 1)
+    commands = bench.make_commands(b, e, cpd)
+    cib, cc4 = np.zeros(len(commands) * 64, np.uint32), np.zeros(4, np.uint32)
+    oracle.clustercull(cd, 0, commands, synth.count4_for(e - b), d, meshlets, None, None, cib, cc4, threads=oracle.max_threads())
+    # the all-reduced count (one rank: the sum is the pass's own) = what the pass left in its count word = the oracle's
+    assert cfg["visible_total"] == cfg["visible_rank0"] == int(cc4[0]) > 0 and len(set(cfg["visible_per_stream"])) == 1
+    assert rec["parity"] == "bit-identical" and "1 of 1 ranks" in rec["parity_checked"] and rec["cpu_baseline"]["value"] > 0
+
+
 def test_config5_eight_ranks_100m_meshlets(tmp_path):
     """BASELINE config 5 end to end with the HIP kernels: `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 --total-meshlets
     100000000` (gloo, the eight ranks sharing the box's one device — on an 8-GPU node the same command with the default backend is the

@@ -62,8 +62,9 @@ def read_dump(prefix):
 @pytest.mark.gpu
 @pytest.mark.parametrize("total, shards", [(0, 0), (1_000_000 + 64 * 3, 0), (3_000_000 + 64 * 5, 8)])
 def test_cpp_rccl_host_matches_the_oracle(tmp_path, total, shards):
-    """shards = 8: eight ranks on the box's one device (--shards; the counts are then summed on the host, because RCCL refuses a device
-    twice in one communicator) — config 5's sharding, passes and ID rebasing in the C++ host, with shard boundaries inside draws"""
+    """shards = 8: eight ranks on the box's one device (--shards; RCCL refuses a device twice in one communicator, so the ranks sharing a
+    device are summed on the host into the device's communicator rank and the SAME grouped ncclAllReduce runs as with one rank per device)
+    — config 5's sharding, passes and ID rebasing in the C++ host, with shard boundaries inside draws"""
     import oracle
     from niagara_amd import synth
     prefix = str(tmp_path / "dump")
@@ -75,7 +76,9 @@ def test_cpp_rccl_host_matches_the_oracle(tmp_path, total, shards):
     assert line["counts_agree_on_all_ranks"] is True and line["devices"] >= 1 and line["scaling"] == ("strong" if total else "weak")
     draws, cpd, devs = read_dump(prefix)
     assert len(devs) == line["shards"] == (max(shards, line["devices"]) if shards else line["devices"])
-    assert ("host sum" in line["allreduce"]) == (line["shards"] > line["devices"])
+    # the grouped ncclAllReduce runs in both modes (one communicator rank per device); ranks sharing a device are pre-summed on the host
+    assert "ncclAllReduce" in line["allreduce"] and ("summed on the host first" in line["allreduce"]) == (line["shards"] > line["devices"])
+    assert line["timing"].startswith("host-synchronised" if line["shards"] > line["devices"] else "asynchronous")
     got_ids, want_ids, visible = [], [], 0
     for d in devs:
         n = d["e"] - d["b"]
