@@ -60,6 +60,7 @@ def parse():
                          "(independent passes in flight) and says so in the line")
     ap.add_argument("--overlap-streams", type=int, default=3, help="streams of the `throughput_overlapped` side leg (N = 1 only; 0 = skip it)")
     ap.add_argument("--scatter-waves", type=int, default=0, help="NV_OPT_SCATTER_WAVES (4, 8 or 16) of the timed region; 0 = 16 with one stream, 8 with several")
+    ap.add_argument("--no-contract-chain", action="store_true", help="skip the `contract_chain` side field (N = 1 with the CPU baseline only)")
     ap.add_argument("--dump-ids", default="", help="directory: every rank saves the visible-ID list of its last profiled pass, rebased to pool-wide command "
                                                    "indices (shard.to_global_ids), as ids_<rank>.npy — tests/test_distributed_gpu.py concatenates them")
     ap.add_argument("--explicit-reset", action="store_true",
@@ -389,6 +390,11 @@ def main():
                                      ("the whole batch" if not sharded else "every rank on its own shard, %d of %d ranks agree" % (world, world)))
     elif rank == 0:
         out["parity"] = "not checked (--no-cpu-baseline)"
+    # ---- side field (N = 1): BASELINE.json configs[2] as literally worded — "cone + frustum cull + LOD select" — i.e. the reference's
+    # chain drawcull<0,1> (LOD select) -> tasksubmit -> clustercull<0> -> clustersubmit (src/niagara.cpp:1530-1611), timed in this
+    # process after everything above, with its own parity check of every buffer of the chain.  Never `value`.
+    if rank == 0 and not sharded and not args.no_cpu_baseline and not args.no_contract_chain:
+        out["contract_chain"] = contract_chain(local_rank)
     if rank == 0:
         print(json.dumps(out), flush=True)
 
@@ -396,6 +402,26 @@ def main():
         c.close()
     if sharded:
         dist.destroy_process_group()
+
+
+def contract_chain(device_index, n_draws=125000, iters=100):
+    """config 3B at BASELINE configs[2]'s scale (tools/bench_configs.py config3b, ~10 M meshlets tested after LOD select): drawcull<0,1> over
+    `n_draws` draws of 64 meshes x 4 LODs -> tasksubmit -> clustercull<0> -> clustersubmit with the two fusion options (count reset and
+    submit words inside the passes: 4 launches per phase), one phase after the other on one stream; every buffer of the chain is held
+    against the CPU oracle (a difference is a non-zero exit) — oracle/ only as the checker."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs
+    from niagara_amd import pipeline as P
+    ctx = P.Context(device_index)
+    try:
+        r = bench_configs.config3b(ctx, iters, n_draws=n_draws, fused=True)
+    finally:
+        ctx.close()
+    return {"what": "BASELINE configs[2] with LOD select: " + r["config"], "draws": r["draws"], "task_commands": r["task_commands"],
+            "meshlets_tested": r["meshlets_tested"], "visible": r["visible"], "us_per_phase": r["step_us"], "meshlets_per_s": r["meshlets_per_s"],
+            "drawcull_us": r["drawcull_us"], "cluster_cull_us": r["cluster_cull_us"], "cluster_scatter_us": r["cluster_scatter_us"],
+            "options": "NV_OPT_FUSED_COUNT_RESET + NV_OPT_FUSED_SUBMIT (4 launches per phase)", "regime": "one phase after the other on one stream, %d phases" % iters,
+            "parity": r["parity"], "parity_checked": "task commands + count words, visible-ID list + count + submit padding, drawVisibility against the CPU oracle"}
 
 
 def pmc_traffic(n_meshlets, args):

@@ -28,6 +28,7 @@
 
 #include "cullmath.h"
 #include "args.h"
+#include "filtermath.h"
 
 namespace nv
 {
@@ -364,64 +365,16 @@ constexpr int CC_DB = 3;         // ring slots of the exact pass (r2 sweep on 3A
 // fail that comparison and fall through.  If any valid lane of the wave is not certainly out, the wave runs the
 // exact path for all lanes — results are identical to the unfiltered kernel (tests/test_gpu_parity.py compares both
 // against the oracle, including adversarial meshlets placed on the planes).
-struct FilterDraw
-{
-	float m[9];  // M, row-major
-	float b[3];
-	float aK, bK; // 4 K u alpha, 4 K u beta (+ an absolute floor)
-	float aR;     // 2^-20 |scale|: covers the roundings of radius * scale, which the filter folds into its threshold
-	float scale;
-	float coneK;  // certified cone test: its margin is T * coneK (see certified_visible)
-	float is127;  // 1 / (127 scale): takes M = scale V R back to V R and the int8 axis to [-1, 1] in one factor
-};
-
+// FilterDraw, the constants and the derivation itself live in filtermath.h, which also compiles for the host: tests/test_cert_margins.py
+// holds the margins it produces against the reference arithmetic on the CPU, context.hip takes filterK and the view norms from it.
 // filterK = 4 K u S (rounded up), S = max(1, |f0| + |f1|, |f2| + |f3|) of the frustum coefficients: the margins above
 // assume |f| <= 1; the host scales them for other coefficients and passes 0 (no filter, no certified test) for
-// non-finite or absurd ones (fill_cluster_args).
+// non-finite or absurd ones (filter_k, fill_cluster_args).
 NV_DEV FilterDraw make_filter(const NvCullData& cd, const DrawUniform& u, float filterK, float Vn, float V3n, float sumV)
 {
-	const float x = u.q.x, y = u.q.y, z = u.q.z, w = u.qw, s = u.scale;
-	// R = (1 - 2|q_xyz|^2) I + 2 q q^T + 2 w [q]x  (valid for any q, unit or not) — same map as rotateQuat
-	float R[9];
-	R[0] = 1.0f - 2.0f * (y * y + z * z);
-	R[1] = 2.0f * (x * y - w * z);
-	R[2] = 2.0f * (x * z + w * y);
-	R[3] = 2.0f * (x * y + w * z);
-	R[4] = 1.0f - 2.0f * (x * x + z * z);
-	R[5] = 2.0f * (y * z - w * x);
-	R[6] = 2.0f * (x * z - w * y);
-	R[7] = 2.0f * (y * z + w * x);
-	R[8] = 1.0f - 2.0f * (x * x + y * y);
-	FilterDraw f;
-	const float* V = cd.view; // column-major: V(r,k) = V[4k + r]
-#pragma unroll
-	for (int r = 0; r < 3; ++r)
-	{
-#pragma unroll
-		for (int c = 0; c < 3; ++c)
-			f.m[3 * r + c] = s * (V[r] * R[c] + V[4 + r] * R[3 + c] + V[8 + r] * R[6 + c]);
-		f.b[r] = V[r] * u.pos.x + V[4 + r] * u.pos.y + V[8 + r] * u.pos.z + V[12 + r];
-	}
-	const float Qa = __builtin_fabsf(x) + __builtin_fabsf(y) + __builtin_fabsf(z);
-	const float rotAbs = 1.0f + 2.0f * Qa * (Qa + __builtin_fabsf(w));
 	// (Vn, V3n = the row norms of the view matrix's linear part and of its translation, sumV = the sum of its twelve entries:
-	// the host's, ClusterArgs::viewRowNorm ..., computed with the operations that stood here)
-	const float pn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(u.pos.x), __builtin_fabsf(u.pos.y)), __builtin_fabsf(u.pos.z));
-	const float alpha = Vn * __builtin_fabsf(s) * rotAbs;
-	const float beta = Vn * pn + V3n;
-	// The analysis assumes finite inputs and no overflow / harmful underflow in either evaluation.  fmaxf drops NaNs, so
-	// non-finite draw or view fields are caught by a sum that is 0 or NaN, and magnitudes outside a generous range
-	// (every intermediate of both chains, including the certified cone test's products, then stays far from the fp32
-	// limits) make the margin infinite: nothing is certain for such a draw and the reference arithmetic decides.
-	const float poison = 0.0f * ((((x + y) + (z + w)) + (s + ((u.pos.x + u.pos.y) + u.pos.z))) + sumV); // 0, or NaN
-	const bool sane = alpha <= 1e12f && beta <= 1e12f && __builtin_fabsf(s) >= 1e-15f;
-	f.aK = filterK * alpha;
-	f.bK = sane ? (filterK * beta + 1e-30f) + poison : __builtin_inff();
-	f.aR = 9.5367431640625e-7f * __builtin_fabsf(s);
-	f.scale = s;
-	f.coneK = 2.02f * (Vn * rotAbs) + 1.0f;
-	f.is127 = (1.0f / s) * 0.00787401574803149606f;
-	return f;
+	// the host's, ClusterArgs::viewRowNorm ..., filter_view_norms)
+	return filter_make(cd.view, u.q.x, u.q.y, u.q.z, u.qw, u.scale, u.pos.x, u.pos.y, u.pos.z, filterK, Vn, V3n, sumV);
 }
 
 // Wave-uniform copy of one draw's filter.  M, aK, aR and scale live in SGPRs; the addends of the four FMA chains are
@@ -616,7 +569,7 @@ NV_DEV bool certified_visible(const NvCullData& cd, const CertUniform& f, uint32
 		const float wz = __builtin_fmaf(f.m[6], kx, __builtin_fmaf(f.m[7], ky, f.m[8] * kz));
 		const float lhs = __builtin_fmaf(cx, wx, __builtin_fmaf(cy, wy, cz * wz)) * f.is127;
 		const float len = __builtin_amdgcn_sqrtf(__builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, cz * cz)));
-		const float rhs = __builtin_fmaf(kc * 0.00787401574803149606f, len, f.scale * rad);
+		const float rhs = __builtin_fmaf(kc * INV_127, len, f.scale * rad);
 		const float D = lhs - rhs;
 		const float Tc = T * f.coneK;
 		const uint64_t cullM = __ballot(D > Tc), keepM = __ballot(D < -Tc);

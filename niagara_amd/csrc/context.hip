@@ -14,6 +14,7 @@
 #include "../../include/niagara_vis.h"
 #include "cullmath.h"
 #include "args.h"
+#include "filtermath.h"
 
 namespace nv
 {
@@ -834,36 +835,13 @@ static int fill_cluster_args(nv_context* ctx, nv::ClusterArgs& a, const NvCullDa
 		a.genBlocksMagic = nv_division_magic(a.genBlocks);
 		a.tilesMagic = nv_division_magic(a.scatterTiles);
 	}
-	// Margin scale of the conservative filter / certified test (clustercull.hip make_filter): 4 K u S with K = 48,
-	// u = 2^-24 and S = max(1, |f0| + |f1|, |f2| + |f3|) — the error analysis is written for unit-length plane
-	// coefficients (|f| <= 1); other finite coefficients scale the margins, non-finite or absurd ones (or near / far
-	// planes that are not finite) switch both off and every command runs the reference arithmetic.
-	{
-		const float* f = cull->frustum;
-		const float s01 = fabsf(f[0]) + fabsf(f[1]), s23 = fabsf(f[2]) + fabsf(f[3]);
-		float S = 1.0f;
-		S = s01 > S ? s01 : S;
-		S = s23 > S ? s23 : S;
-		const bool finite = s01 <= 1e3f && s23 <= 1e3f && fabsf(cull->znear) <= 1e30f && fabsf(cull->zfar) <= 1e30f; // false on NaN
-		a.filterK = finite ? 4.0f * 48.0f * 5.9604644775390625e-8f * 1.001f * S : 0.0f;
-	}
-	{
-		// the view-only terms of clustercull.hip make_filter, in its operations and order (fp32, no contraction: this file is compiled
-		// with -ffp-contract=off like the kernels)
-		const float* V = cull->view; // column-major: V(r,k) = V[4k + r]
-		float Vn = 0.0f, V3n = 0.0f;
-		for (int r = 0; r < 3; ++r)
-		{
-			Vn = fmaxf(Vn, fabsf(V[r]) + fabsf(V[4 + r]) + fabsf(V[8 + r]));
-			V3n = fmaxf(V3n, fabsf(V[12 + r]));
-		}
-		float sumV = 0.0f;
-		for (int i = 0; i < 15; ++i)
-			sumV += (i & 3) == 3 ? 0.0f : V[i];
-		a.viewRowNorm = Vn;
-		a.viewTransNorm = V3n;
-		a.viewSum = sumV;
-	}
+	// Margin scale of the conservative filter / certified test and the view-only terms of its per-draw derivation: filtermath.h
+	// (filter_k: 4 K u S with K = 48, u = 2^-24, S = max(1, |f0| + |f1|, |f2| + |f3|) — the error analysis is written for unit-length plane
+	// coefficients; other finite coefficients scale the margins, non-finite or absurd ones, or near / far planes that are not finite,
+	// switch both off and every command runs the reference arithmetic.  fp32, no contraction: this file is compiled with
+	// -ffp-contract=off like the kernels).
+	a.filterK = nv::filter_k(cull->frustum, cull->znear, cull->zfar);
+	nv::filter_view_norms(cull->view, &a.viewRowNorm, &a.viewTransNorm, &a.viewSum);
 	a.hostHint = ctx->hintDevice;
 	return NV_OK;
 }
