@@ -121,6 +121,7 @@ struct ClusterArgs
 	const NvMeshlet* __restrict__ meshlets; // AoS (used when soaBounds == nullptr)
 	const uint2* __restrict__ soaBounds;
 	const uint32_t* __restrict__ soaCones;
+	const float* __restrict__ poolBounds; // {3 x the largest |centre component|, the largest |radius|} of the mirrored pool (nv_upload_meshlets); set whenever soaBounds is
 	uint32_t* __restrict__ mvb;
 	uint32_t* __restrict__ clusterIndices;
 	uint32_t* __restrict__ clusterCount4;

@@ -370,11 +370,11 @@ constexpr int CC_DB = 3;         // ring slots of the exact pass (r2 sweep on 3A
 // filterK = 4 K u S (rounded up), S = max(1, |f0| + |f1|, |f2| + |f3|) of the frustum coefficients: the margins above
 // assume |f| <= 1; the host scales them for other coefficients and passes 0 (no filter, no certified test) for
 // non-finite or absurd ones (filter_k, fill_cluster_args).
-NV_DEV FilterDraw make_filter(const NvCullData& cd, const DrawUniform& u, float filterK, float Vn, float V3n, float sumV)
+NV_DEV FilterDraw make_filter(const NvCullData& cd, const DrawUniform& u, float filterK, float Vn, float V3n, float sumV, float vmax3, float rmax)
 {
 	// (Vn, V3n = the row norms of the view matrix's linear part and of its translation, sumV = the sum of its twelve entries:
-	// the host's, ClusterArgs::viewRowNorm ..., filter_view_norms)
-	return filter_make(cd.view, u.q.x, u.q.y, u.q.z, u.qw, u.scale, u.pos.x, u.pos.y, u.pos.z, filterK, Vn, V3n, sumV);
+	// the host's, ClusterArgs::viewRowNorm ..., filter_view_norms; vmax3, rmax = the registered pool's bounds, ClusterArgs::poolBounds)
+	return filter_make(cd.view, u.q.x, u.q.y, u.q.z, u.qw, u.scale, u.pos.x, u.pos.y, u.pos.z, filterK, Vn, V3n, sumV, vmax3, rmax);
 }
 
 // Wave-uniform copy of one draw's filter.  M, aK, aR and scale live in SGPRs; the addends of the four FMA chains are
@@ -382,8 +382,8 @@ NV_DEV FilterDraw make_filter(const NvCullData& cd, const DrawUniform& u, float 
 struct FilterUniform
 {
 	float m[9];
-	float aK, aR, scale;
-	float b0, b1, b2, bK; // VGPR-resident
+	float scale;
+	float b0, b1, b2, tK; // VGPR-resident
 };
 
 NV_DEV float pin_vgpr(float x)
@@ -396,11 +396,12 @@ NV_DEV float pin_vgpr(float x)
 }
 
 // true for lanes whose sphere is certainly outside the frustum (see above); never true on NaN.
-// 23 VALU instructions per 64 meshlets: 9 + 5 mixed-precision FMAs straight from the packed halfs, 8 for the plane
+// 19 VALU instructions per 64 meshlets (round 5; 23 before): 9 + 1 mixed-precision FMAs straight from the packed halfs, 8 for the plane
 // distances and their minimum, one compare.  The threshold carries the radius:  every predicate of the reference reads
 // g > -r (or z + r > znear, z - r < zfar; unit-length plane coefficients), so  min(g_i) < -(r + T)  proves all of them
 // false at once;  T = bK + aK (|vx| + |vy| + |vz|) + aR |radius|  over-estimates 4E (sum >= max) plus the roundings of
-// radius * scale and of the sums with r.
+// radius * scale and of the sums with r — and the filter uses tK >= T, the same expression at the registered pool's largest
+// |centre component| and |radius| (filtermath.h filter_make): one value per draw, no per-meshlet arithmetic for the margin.
 NV_DEV bool certainly_outside(const NvCullData& cd, const FilterUniform& f, uint32_t b0, uint32_t b1)
 {
 	const float vx = half_bits_to_float(b0 & 0xffffu), vy = half_bits_to_float(b0 >> 16), vz = half_bits_to_float(b1 & 0xffffu);
@@ -408,11 +409,7 @@ NV_DEV bool certainly_outside(const NvCullData& cd, const FilterUniform& f, uint
 	const float cx = __builtin_fmaf(f.m[0], vx, __builtin_fmaf(f.m[1], vy, __builtin_fmaf(f.m[2], vz, f.b0)));
 	const float cy = __builtin_fmaf(f.m[3], vx, __builtin_fmaf(f.m[4], vy, __builtin_fmaf(f.m[5], vz, f.b1)));
 	const float cz = __builtin_fmaf(f.m[6], vx, __builtin_fmaf(f.m[7], vy, __builtin_fmaf(f.m[8], vz, f.b2)));
-	float T = __builtin_fmaf(f.aK, __builtin_fabsf(vx), f.bK);
-	T = __builtin_fmaf(f.aK, __builtin_fabsf(vy), T);
-	T = __builtin_fmaf(f.aK, __builtin_fabsf(vz), T);
-	T = __builtin_fmaf(f.aR, __builtin_fabsf(rad), T);
-	const float thr = __builtin_fmaf(f.scale, rad, T);
+	const float thr = __builtin_fmaf(f.scale, rad, f.tK);
 	const float g1 = __builtin_fmaf(cz, cd.frustum[1], -(__builtin_fabsf(cx) * cd.frustum[0]));
 	const float g2 = __builtin_fmaf(cz, cd.frustum[3], -(__builtin_fabsf(cy) * cd.frustum[2]));
 	const float gn = cz - cd.znear;
@@ -456,13 +453,11 @@ NV_DEV FilterUniform segment_filter(const SegmentRegs& r, uint32_t c)
 #pragma unroll
 	for (int i = 0; i < 9; ++i)
 		f.m[i] = readlane_f(r.f.m[i], c);
-	f.aK = readlane_f(r.f.aK, c);
-	f.aR = readlane_f(r.f.aR, c);
 	f.scale = readlane_f(r.f.scale, c);
 	f.b0 = pin_vgpr(readlane_f(r.f.b[0], c));
 	f.b1 = pin_vgpr(readlane_f(r.f.b[1], c));
 	f.b2 = pin_vgpr(readlane_f(r.f.b[2], c));
-	f.bK = pin_vgpr(readlane_f(r.f.bK, c));
+	f.tK = pin_vgpr(readlane_f(r.f.tK, c));
 	return f;
 }
 
@@ -846,6 +841,15 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 	if (!NV_DBG(a, 262144u)) // bit 18 (experiments)
 		__builtin_amdgcn_s_setprio(3);
 	const uint32_t gen = a.genBlocks ? div_launch_constant(blockIdx.x, a.genBlocks, a.genBlocksMagic) : 0u; // (workgroups are numbered generation-major)
+	// the registered pool's bounds for the filter's per-draw margin (filtermath.h filter_make): two scalar loads next to the count word's,
+	// consumed by the lane-parallel filter derivation long after.  No mirror (AoS in place): nothing is known, nothing is certain.
+	float poolVmax3 = __builtin_inff(), poolRmax = __builtin_inff();
+	if (SOA)
+	{
+		k_f32p pb = (k_f32p)(uintptr_t)a.poolBounds;
+		poolVmax3 = pb[0];
+		poolRmax = pb[1];
+	}
 	const uint32_t numCmds = indirect_command_count(a);
 	// (nv_taskcull's payload form has its own word: no scatter launch follows it that would refresh the filter statistic in word 1, so
 	// its count must not become the denominator of nv_clustercull's next filter / direct choice — ADVICE r3)
@@ -911,7 +915,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				r.d0 = d[0];
 				r.d1 = d[1];
 			}
-			r.f = make_filter(a.cd, lane_draw(r), a.filterK, a.viewRowNorm, a.viewTransNorm, a.viewSum); // lane-parallel: one filter per command of the segment
+			r.f = make_filter(a.cd, lane_draw(r), a.filterK, a.viewRowNorm, a.viewTransNorm, a.viewSum, poolVmax3, poolRmax); // lane-parallel: one filter per command of the segment
 		}
 		NV_STAMP(1);
 
@@ -933,7 +937,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 		{
 			r.d0 = make_float4(__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w));
 			r.d1 = make_float4(__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z), __uint_as_float(g1.w));
-			r.f = make_filter(a.cd, lane_draw(r), a.filterK, a.viewRowNorm, a.viewTransNorm, a.viewSum);
+			r.f = make_filter(a.cd, lane_draw(r), a.filterK, a.viewRowNorm, a.viewTransNorm, a.viewSum, poolVmax3, poolRmax);
 		};
 
 		const bool useFilter = a.filterK > 0.0f && !NV_DBG(a, 32u);   // filterK 0: coefficients outside the proven range (host); bit 5 (experiments): every valid command goes to the exact pass
@@ -1995,7 +1999,7 @@ NV_DEV void bits_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint
 			u.scale = q0.w;
 			u.q = { q1.x, q1.y, q1.z };
 			u.qw = q1.w;
-			const FilterDraw f = make_filter(a.cd, u, a.filterK, a.viewRowNorm, a.viewTransNorm, a.viewSum);
+			const FilterDraw f = make_filter(a.cd, u, a.filterK, a.viewRowNorm, a.viewTransNorm, a.viewSum, 0.0f, 0.0f); // (tK unused: the certified test keeps the per-meshlet margin)
 			s_draw[tid][0] = q0;
 			s_draw[tid][1] = q1;
 			s_cert[tid][0] = make_float4(f.m[0], f.m[1], f.m[2], f.b[0]);
@@ -2408,6 +2412,54 @@ __global__ __launch_bounds__(CC_THREADS) void probe_kernel(ClusterArgs a)
 
 // ---------------------------------------------------------------------------------------------------------------
 // SoA mirror of the 12 cull bytes (nv_upload_meshlets)
+// The registered pool's largest |centre component| and |radius| (fp16 bit patterns without the sign: ordered like the magnitudes for finite
+// values; infinities and NaNs sort above every finite value), for the filter's per-draw margin (filtermath.h filter_make): one grid-stride
+// sweep over the mirror's bounds at upload time, one atomicMax pair per workgroup, then pool_bounds_finish turns the two words into
+// {3 Vmax, Rmax} as floats (inf for a pool that holds a non-finite record).
+__global__ __launch_bounds__(256) void pool_bounds_kernel(const uint2* __restrict__ bounds, uint32_t count, uint32_t* __restrict__ maxBits)
+{
+	__shared__ uint32_t s_v[4], s_r[4];
+	uint32_t mv = 0, mr = 0;
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u)
+	{
+		const uint2 b = bounds[i];
+		const uint32_t x = b.x & 0x7fffu, y = (b.x >> 16) & 0x7fffu, z = b.y & 0x7fffu, r = (b.y >> 16) & 0x7fffu;
+		mv = mv > x ? mv : x;
+		mv = mv > y ? mv : y;
+		mv = mv > z ? mv : z;
+		mr = mr > r ? mr : r;
+	}
+	for (int o = 32; o; o >>= 1)
+	{
+		const uint32_t ov = (uint32_t)__shfl_xor((int)mv, o, 64), orr = (uint32_t)__shfl_xor((int)mr, o, 64);
+		mv = mv > ov ? mv : ov;
+		mr = mr > orr ? mr : orr;
+	}
+	if ((threadIdx.x & 63u) == 0)
+	{
+		s_v[threadIdx.x >> 6] = mv;
+		s_r[threadIdx.x >> 6] = mr;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		for (int w = 1; w < 4; ++w)
+		{
+			mv = mv > s_v[w] ? mv : s_v[w];
+			mr = mr > s_r[w] ? mr : s_r[w];
+		}
+		atomicMax(maxBits, mv);
+		atomicMax(maxBits + 1, mr);
+	}
+}
+
+__global__ void pool_bounds_finish(const uint32_t* __restrict__ maxBits, float* __restrict__ out2)
+{
+	const uint32_t v = maxBits[0], r = maxBits[1];
+	out2[0] = v >= 0x7c00u ? __builtin_inff() : 3.0f * half_bits_to_float(v); // (3 x an 11-bit significand: exact)
+	out2[1] = r >= 0x7c00u ? __builtin_inff() : half_bits_to_float(r);
+}
+
 __global__ __launch_bounds__(256) void soa_split_kernel(const NvMeshlet* __restrict__ meshlets, uint32_t count, uint32_t padded,
                                                        uint2* __restrict__ bounds, uint32_t* __restrict__ cones)
 {
@@ -2576,9 +2628,14 @@ int launch_probe(hipStream_t stream, const ClusterArgs& a, bool soa, uint32_t gr
 	return (int)hipGetLastError();
 }
 
-int launch_soa_split(hipStream_t stream, const NvMeshlet* meshlets, uint32_t count, uint32_t padded, uint2* bounds, uint32_t* cones)
+// poolWords: 2 x u32 scratch + 2 x float result (ClusterArgs::poolBounds points at the floats)
+int launch_soa_split(hipStream_t stream, const NvMeshlet* meshlets, uint32_t count, uint32_t padded, uint2* bounds, uint32_t* cones, uint32_t* poolWords)
 {
 	hipLaunchKernelGGL(soa_split_kernel, dim3((padded + 255) / 256), dim3(256), 0, stream, meshlets, count, padded, bounds, cones);
+	(void)hipMemsetAsync(poolWords, 0, 2 * sizeof(uint32_t), stream);
+	const uint32_t blocks = (count + 255) / 256 < 2048u ? ((count + 255) / 256 ? (count + 255) / 256 : 1u) : 2048u;
+	hipLaunchKernelGGL(pool_bounds_kernel, dim3(blocks), dim3(256), 0, stream, bounds, count, poolWords);
+	hipLaunchKernelGGL(pool_bounds_finish, dim3(1), dim3(1), 0, stream, poolWords, reinterpret_cast<float*>(poolWords + 2));
 	return (int)hipGetLastError();
 }
 

@@ -30,7 +30,7 @@ size_t clustercull_list_bytes();
 uint32_t clustercull_list_stride();
 int launch_taskcull(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t gridBlocks);
 int launch_probe(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
-int launch_soa_split(hipStream_t, const NvMeshlet*, uint32_t count, uint32_t padded, uint2* bounds, uint32_t* cones);
+int launch_soa_split(hipStream_t, const NvMeshlet*, uint32_t count, uint32_t padded, uint2* bounds, uint32_t* cones, uint32_t* poolWords);
 int launch_drawcull(hipStream_t, const DrawArgs&, int late, int task);
 int launch_draw_split(hipStream_t, const NvMeshDraw*, const NvMesh*, uint32_t meshCount, uint32_t first, uint32_t count, float4* world, uint2* scaleMesh, uint32_t* postPass);
 size_t drawcull_result_bytes(uint32_t drawCount);
@@ -64,6 +64,7 @@ struct nv_scene
 	uint32_t mirroredCount;
 	uint2* soaBounds;
 	uint32_t* soaCones;
+	uint32_t* poolWords; // 2 x u32 (largest |centre component| / |radius| as fp16 bits) + 2 x float {3 Vmax, Rmax}: clustercull.hip pool_bounds_kernel
 	uint32_t soaCapacity;
 	// SoA mirror of the MeshDraw fields a draw decision reads (nv_upload_draws)
 	const NvMeshDraw* drawsFrom;
@@ -293,6 +294,8 @@ void scene_release(nv_scene* sc)
 		scratch_free(sc->soaBounds);
 	if (sc->soaCones)
 		scratch_free(sc->soaCones);
+	if (sc->poolWords)
+		scratch_free(sc->poolWords);
 	if (sc->soaWorld)
 		scratch_free(sc->soaWorld);
 	if (sc->soaScaleMesh)
@@ -643,7 +646,9 @@ int nv_upload_meshlets(nv_context* ctx, void* stream, const NvMeshlet* d_meshlet
 			return NV_ENOMEM;
 		ctx->scene->soaCapacity = padded;
 	}
-	int rc = nv::launch_soa_split((hipStream_t)stream, d_meshlets, meshletCount, padded, ctx->scene->soaBounds, ctx->scene->soaCones);
+	if (!ctx->scene->poolWords && scratch_alloc(&ctx->scene->poolWords, 4 * sizeof(uint32_t)) != hipSuccess)
+		return NV_ENOMEM;
+	int rc = nv::launch_soa_split((hipStream_t)stream, d_meshlets, meshletCount, padded, ctx->scene->soaBounds, ctx->scene->soaCones, ctx->scene->poolWords);
 	if (rc)
 		return rc;
 	ctx->scene->mirroredFrom = d_meshlets;
@@ -817,6 +822,7 @@ static int fill_cluster_args(nv_context* ctx, nv::ClusterArgs& a, const NvCullDa
 	const bool soa = ctx->scene->mirroredFrom == d_meshlets && ctx->scene->soaBounds;
 	a.soaBounds = soa ? ctx->scene->soaBounds : nullptr;
 	a.soaCones = soa ? ctx->scene->soaCones : nullptr;
+	a.poolBounds = soa ? reinterpret_cast<const float*>(ctx->scene->poolWords + 2) : nullptr;
 	a.mvb = d_meshletVisibility;
 	a.masks = ctx->masks;
 	a.candList = ctx->candList;

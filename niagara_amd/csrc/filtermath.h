@@ -40,6 +40,7 @@ struct FilterDraw
 	float b[3];  // V p + V3
 	float aK, bK; // 4 K u S alpha, 4 K u S beta (+ the absolute floor; inf / NaN when nothing is certain)
 	float aR;     // 2^-20 |scale|
+	float tK;     // bK + aK 3 Vmax + aR Rmax >= T of every meshlet of the pool: the FILTER's margin, one value per draw (see filter_make)
 	float scale;
 	float coneK;  // the certified cone test's margin is T * coneK
 	float is127;  // 1 / (127 scale): takes M = scale V R back to V R and the int8 axis to [-1, 1] in one factor
@@ -75,8 +76,15 @@ NV_FM void filter_view_norms(const float* V, float* Vn_, float* V3n_, float* sum
 	*sumV_ = sumV;
 }
 
-// one draw's filter: q = (x, y, z, w), s = scale, p = position; (Vn, V3n, sumV) = filter_view_norms(V)
-NV_FM FilterDraw filter_make(const float* V, float x, float y, float z, float w, float s, float px, float py, float pz, float filterK, float Vn, float V3n, float sumV)
+// one draw's filter: q = (x, y, z, w), s = scale, p = position; (Vn, V3n, sumV) = filter_view_norms(V).
+// vmax3 >= |vx| + |vy| + |vz| and rmax >= |radius| for EVERY meshlet the pass can touch (3 x the largest |centre component| and the largest
+// |radius| of the registered pool, found once by nv_upload_meshlets; inf / NaN when the pool holds a non-finite record): the filter pass uses
+// tK = bK + aK vmax3 + aR rmax >= T = bK + aK (|vx| + |vy| + |vz|) + aR |radius| as its margin — per draw instead of per meshlet, four
+// FMAs less per meshlet in the stream (round 5).  tK only ever ENLARGES the margin (by < 4 % where beta dominates alpha, the usual
+// case: positions are much larger than a mesh's own extent), so every "certainly outside" stays certain; the three fp32 roundings of its
+// evaluation are relative 2^-24 against the analysis' > 2x slack.  The certified test (pass B) keeps the per-meshlet T.
+NV_FM FilterDraw filter_make(const float* V, float x, float y, float z, float w, float s, float px, float py, float pz, float filterK, float Vn, float V3n, float sumV,
+                             float vmax3, float rmax)
 {
 	// R = (1 - 2|q_xyz|^2) I + 2 q q^T + 2 w [q]x  (valid for any q, unit or not) — same map as rotateQuat
 	float R[9];
@@ -112,6 +120,7 @@ NV_FM FilterDraw filter_make(const float* V, float x, float y, float z, float w,
 	f.aK = filterK * alpha;
 	f.bK = sane ? (filterK * beta + FILTER_FLOOR) + poison : __builtin_inff();
 	f.aR = FILTER_RADIUS_U * __builtin_fabsf(s);
+	f.tK = __builtin_fmaf(f.aR, rmax, __builtin_fmaf(f.aK, vmax3, f.bK));
 	f.scale = s;
 	f.coneK = CONE_K_SLOPE * (Vn * rotAbs) + CONE_K_OFFSET;
 	f.is127 = (1.0f / s) * INV_127;

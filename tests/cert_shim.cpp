@@ -20,15 +20,15 @@ float shim_filter_k(const float frustum[4], float znear, float zfar) { return nv
 void shim_view_norms(const float view[16], float out[3]) { nv::filter_view_norms(view, &out[0], &out[1], &out[2]); }
 
 // draws: n x {position.xyz, scale, orientation.xyzw} (the first 32 bytes of a MeshDraw, stride in floats); out: n x 19 floats
-// {m[9], b[3], aK, bK, aR, scale, coneK, is127} (19th = is127)
-void shim_make_filters(const float view[16], const float* draws, unsigned stride, unsigned n, float filterK, float* out)
+// {m[9], b[3], aK, bK, aR, scale, coneK, is127, tK}
+void shim_make_filters(const float view[16], const float* draws, unsigned stride, unsigned n, float filterK, float vmax3, float rmax, float* out)
 {
 	float Vn, V3n, sumV;
 	nv::filter_view_norms(view, &Vn, &V3n, &sumV);
 	for (unsigned i = 0; i < n; ++i)
 	{
 		const float* d = draws + (size_t)i * stride;
-		const nv::FilterDraw f = nv::filter_make(view, d[4], d[5], d[6], d[7], d[3], d[0], d[1], d[2], filterK, Vn, V3n, sumV);
+		const nv::FilterDraw f = nv::filter_make(view, d[4], d[5], d[6], d[7], d[3], d[0], d[1], d[2], filterK, Vn, V3n, sumV, vmax3, rmax);
 		float* o = out + (size_t)i * 19;
 		for (int k = 0; k < 9; ++k)
 			o[k] = f.m[k];
@@ -40,7 +40,7 @@ void shim_make_filters(const float view[16], const float* draws, unsigned stride
 		o[15] = f.scale;
 		o[16] = f.coneK;
 		o[17] = f.is127;
-		o[18] = 0.0f;
+		o[18] = f.tK;
 	}
 }
 }

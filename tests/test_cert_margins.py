@@ -35,18 +35,27 @@ def shim(tmp_path_factory):
     lib = C.CDLL(so)
     lib.shim_filter_k.restype = C.c_float
     lib.shim_filter_k.argtypes = [C.c_void_p, C.c_float, C.c_float]
-    lib.shim_make_filters.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_float, C.c_void_p]
+    lib.shim_make_filters.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_float, C.c_float, C.c_float, C.c_void_p]
     return lib
 
 
-def filters_of(shim, cd, draws):
+def pool_bounds(meshlets):
+    """{3 x the largest |centre component|, the largest |radius|} of a pool, as clustercull.hip pool_bounds_kernel / pool_bounds_finish find them"""
+    c = meshlets["center"].view(np.uint16) & 0x7fff
+    r = meshlets["radius"].view(np.uint16) & 0x7fff
+    v, rr = int(c.max(initial=0)), int(r.max(initial=0))
+    to_f = lambda bits: f32(np.inf) if bits >= 0x7c00 else f32(np.uint16(bits).view(np.float16))  # noqa: E731
+    return f32(3.0) * to_f(v), to_f(rr)
+
+
+def filters_of(shim, cd, draws, vmax3=np.inf, rmax=np.inf):
     """(filterK, FilterDraw rows [n, 19]) exactly as fill_cluster_args / make_filter derive them"""
     fr = np.ascontiguousarray(cd["frustum"][0], f32)
     k = shim.shim_filter_k(fr.ctypes.data, float(cd["znear"][0]), float(cd["zfar"][0]))
     view = np.ascontiguousarray(cd["view"][0], f32)
     out = np.zeros((len(draws), 19), f32)
     d = np.ascontiguousarray(draws)
-    shim.shim_make_filters(view.ctypes.data, d.ctypes.data, d.dtype.itemsize // 4, len(d), C.c_float(k), out.ctypes.data)
+    shim.shim_make_filters(view.ctypes.data, d.ctypes.data, d.dtype.itemsize // 4, len(d), C.c_float(k), C.c_float(vmax3), C.c_float(rmax), out.ctypes.data)
     return k, out
 
 
@@ -113,14 +122,14 @@ def test_margins_cover_the_distance_to_the_reference(shim, case):
     draws, meshlets, commands, cd = scene(radius, scale_mul, qmul, cam, camq, n_draws=400, cpd=2, seed=11)
     n = len(commands)
     probe = oracle.probe_cluster_scalars(cd, commands, draws, meshlets)  # (n, 64, 16): the reference arithmetic's intermediates
-    filterK, F = filters_of(shim, cd, draws)
+    filterK, F = filters_of(shim, cd, draws, *pool_bounds(meshlets))
     assert filterK > 0
     d = commands["drawId"]
     ml = meshlets[commands["taskOffset"][:, None] + np.arange(64, dtype=np.uint32)[None, :]]
     v = ml["center"].view(np.float16).astype(f32)  # (n, 64, 3)
     rad = ml["radius"].view(np.float16).astype(f32)
     Fd = F[d][:, None, :] + 0 * rad[..., None]     # (n, 64, 19)
-    m, b, aK, bK, aR, scale, coneK, is127 = Fd[..., 0:9], Fd[..., 9:12], Fd[..., 12], Fd[..., 13], Fd[..., 14], Fd[..., 15], Fd[..., 16], Fd[..., 17]
+    m, b, aK, bK, aR, scale, coneK, is127, tK = Fd[..., 0:9], Fd[..., 9:12], Fd[..., 12], Fd[..., 13], Fd[..., 14], Fd[..., 15], Fd[..., 16], Fd[..., 17], Fd[..., 18]
     # certainly_outside / certified_visible (clustercull.hip), FMA = fp64 product-sum rounded to fp32
     c = np.stack([fma64(m[..., 3 * r], v[..., 0], fma64(m[..., 3 * r + 1], v[..., 1], fma64(m[..., 3 * r + 2], v[..., 2], b[..., r]))) for r in range(3)], axis=-1)
     T = fma64(aK, np.abs(v[..., 0]), bK)
@@ -140,6 +149,12 @@ def test_margins_cover_the_distance_to_the_reference(shim, case):
     g = np.minimum(np.minimum(g1, g2), np.minimum(c[..., 2] - znear, zfar - c[..., 2]))
     out_m, in_m, vis_ref = g < -thr_hi, g > -thr_lo, probe[..., 14] != 0
     assert not (ok & out_m & vis_ref).any() and not (ok & in_m & ~vis_ref).any(), name
+    # the filter pass (certainly_outside) uses the per-draw margin tK = T at the pool's largest |centre component| and |radius|: never
+    # smaller than a meshlet's own T by more than its three roundings, so it can only decide LESS; and it must still decide nearly everything
+    assert np.isfinite(tK).all() and (tK.astype(np.float64) >= T.astype(np.float64) * (1.0 - 2.0 ** -21))[ok].all(), name
+    out_f = g < -fma64(scale, rad, tK)
+    assert not (ok & out_f & vis_ref).any(), name
+    assert (ok & out_f).sum() >= 0.97 * (ok & out_m).sum(), "%s: the pool-wide margin gives up %d of %d certain rejections" % (name, (ok & out_m & ~out_f).sum(), (ok & out_m).sum())
     assert (ok & (out_m | in_m)).mean() > 0.9  # the margins must not be so wide that nothing is decided
     # cone
     k, kc = ml["cone_axis"].astype(f32), ml["cone_cutoff"].astype(f32)
@@ -195,10 +210,17 @@ def test_unsound_inputs_make_nothing_certain(shim):
     draws["position"][4, 0] = 1e20
     draws["scale"][5] = 1e14
     cd = host.build_cull_data(draw_count=8, cullingEnabled=1, clusterBackfaceEnabled=1)
-    _, F = filters_of(shim, cd, draws)
+    _, F = filters_of(shim, cd, draws, 3.0, 0.1)
     for i in range(6):
         assert not np.isfinite(F[i, 13]) or not np.isfinite(F[i, 12]), i  # bK (or aK) poisons T
-    assert np.isfinite(F[6:, :18]).all()
+    assert not np.isfinite(F[:6, 18]).any() and np.isfinite(F[6:, :19]).all()
+    # a pool with a non-finite centre or radius: no finite filter margin for any draw
+    m = synth.make_meshlets(256, seed=1)
+    assert all(np.isfinite(x) for x in pool_bounds(m))
+    m["center"].view(np.uint16)[17, 1] = 0x7c00
+    assert not np.isfinite(pool_bounds(m)[0])
+    _, F = filters_of(shim, cd, draws, *pool_bounds(m))
+    assert not np.isfinite(F[:, 18]).any()
     bad_view = cd.copy()
     bad_view["view"][0][5] = np.nan
     _, F = filters_of(shim, bad_view, draws)
