@@ -347,7 +347,10 @@ constexpr uint32_t CC_CHUNK_LATE = NV_CC_CHUNK_LATE;
 // workgroups' start-up chains is served sooner.  The host picks per launch from the command count of the PREVIOUS
 // clustercull (the kernel leaves it in a mapped host word; frame coherence; a wrong guess only costs speed).
 constexpr uint32_t CC_SHALLOW_COMMANDS = 500000;
-constexpr int CC_DB = 3;         // ring slots of the exact pass (r2 sweep on 3A: 6 slots 30.2 us / step, 3 slots 29.3; pass B is
+#ifndef NV_CC_DB
+#define NV_CC_DB 3
+#endif
+constexpr int CC_DB = NV_CC_DB;         // ring slots of the exact pass (r2 sweep on 3A: 6 slots 30.2 us / step, 3 slots 29.3; pass B is
                                  // short in the sparse case and a deep ring is mostly redundant loads at its end)
 
 // ---- conservative frustum filter (exactness-preserving early-out)
@@ -970,12 +973,13 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 			uint64_t candMask = 0;
 			FilterUniform fd = {};
 
-			auto issueA = [&](SlotA& slot, uint32_t c, uint64_t order)
+			// `full` = the command in lane c has 64 meshlets (the usual case: no per-lane clamp of the offsets).  The filter loop passes the
+			// bit from a per-round nibble of fullMask (one 64-bit shift per four commands instead of one per command: the loop is bound by
+			// scalar and vector ISSUE, and of its ~30 scalar instructions per command a third were 64-bit mask tests and index clamps — round 5).
+			auto issueA = [&](SlotA& slot, uint32_t c, bool full, uint64_t order)
 			{
-				uint32_t off8, offw = 0;
-				if (fullMask >> c & 1ull)
-					off8 = __builtin_amdgcn_readlane(base8, c) + lane8;
-				else
+				uint32_t off8 = __builtin_amdgcn_readlane(base8, c) + lane8, offw = 0;
+				if (!full) // (one rarely taken branch; an if / else here became two flag tests per command)
 				{
 					const uint32_t tc = __builtin_amdgcn_readlane(r.taskCount, c);
 					off8 = __builtin_amdgcn_readlane(base8, c) + (lane < tc ? lane8 : 0u);
@@ -1014,7 +1018,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				SlotA ring[CC_DA];
 #pragma unroll
 				for (int k = 0; k < CC_DA; ++k)
-					issueA(ring[k], (uint32_t)k < cnt ? k : cnt - 1, 0); // clamped: redundant but unconditional loads
+					issueA(ring[k], k, (fullMask >> k & 1ull) != 0, 0); // lanes >= cnt hold an empty command (meshlet 0): redundant but unconditional, in-range loads
 				NV_COUNTED_WAIT("s_waitcnt vmcnt(%2) ; nv_ready %0 %1" : "+v"(g0), "+v"(g1) : "i"(CC_DA * (BITS_A ? 2 : 1)) : "memory"); // the gather
 				gather_finish();
 				NV_STAMP(2);
@@ -1037,25 +1041,35 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 					// One straight body per command (pass A is bound by scalar and vector ISSUE, not by memory): the filter
 					// runs on all 64 lanes of every slot — clamped loads make that harmless for partial, dummy and
 					// out-of-range commands — and validity is applied to the ballot with scalar mask arithmetic.
+					// the round's bits of the three per-command masks, as nibbles: the commands of this round (change, full) and of the next
+					// one, whose loads this round issues (lanes >= cnt hold empty commands — meshlet 0, in range — so the index of a load
+					// needs no clamp, only the wrap at the end of a full segment: (i + CC_DA) & 63 re-reads the segment's first commands)
+					const uint32_t nextBase = (i + CC_DA) & 63u;
+					const uint32_t chgN = (uint32_t)(changeMask >> i), fullN = (uint32_t)(fullMask >> i), fullNext = (uint32_t)(fullMask >> nextBase);
+					uint32_t candN = 0;
 #pragma unroll
 					for (int k = 0; k < CC_DA; ++k)
 					{
 						const uint32_t c = i + k;
 						ringA_wait<BITS_A, CC_DA - 1>(ring[k]);
 						const uint32_t b0 = (uint32_t)ring[k].bounds, b1 = (uint32_t)(ring[k].bounds >> 32);
-						if (changeMask >> c & 1ull) // first command of a draw within this segment
+						if (chgN & (1u << k)) // first command of a draw within this segment
+						{
 							fd = segment_filter(r, c);
-						uint64_t cand = useFilter ? ~__ballot(certainly_outside(a.cd, fd, b0, b1)) : ~0ull;
-						if (!(fullMask >> c & 1ull)) // partial, dummy (taskCount 0) or past the wave's last command (lanes >= cnt hold 0)
+							if (!useFilter) // (uniform, loop-invariant; here instead of per command) an infinite margin: nothing is certainly outside
+								fd.tK = __builtin_inff();
+						}
+						uint64_t cand = ~__ballot(certainly_outside(a.cd, fd, b0, b1));
+						if (!(fullN & (1u << k))) // partial, dummy (taskCount 0) or past the wave's last command (lanes >= cnt hold 0)
 							cand &= (1ull << (uint32_t)__builtin_amdgcn_readlane(r.taskCount, c)) - 1ull;
 						if (BITS_A) // early pass: only last frame's visible clusters (clustercull.comp.glsl:91-92)
 							cand &= __ballot((ring[k].mvbWord >> ((lane + (uint32_t)__builtin_amdgcn_readlane(r.meshletVisibilityOffset, c)) & 31u) & 1u) != 0);
 						if (streamOnly)
 							cand = 0;
-						if (cand)
-							candMask |= 1ull << c;
-						issueA(ring[k], c + CC_DA < cnt ? c + CC_DA : cnt - 1, cand);
+						candN |= cand ? 1u << k : 0u;
+						issueA(ring[k], nextBase + k, (fullNext & (1u << k)) != 0, cand);
 					}
+					candMask |= (uint64_t)candN << i;
 				}
 				ring_drain();
 #pragma unroll
