@@ -1078,6 +1078,8 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				passedFilter += (uint32_t)__builtin_popcountll(candMask);
 			}
 			NV_STAMP(3);
+			if (dbgTime && lane == 0 && NV_DBG(a, 134217728u)) // bit 27 (experiments): slot 2 = the segment's candidate count instead of the ring-filled stamp (tools/experiments/passb_cost.py)
+				stamps[2] = (unsigned long long)__builtin_popcountll(candMask);
 
 			// ---- pass B: the commands that can have survivors, bounds + cone.  (Measured and dropped: raising a wave to the
 			// top priority for pass B, because it is on the launch's critical path — late pass 44.8 -> 48.8 us, early pass

@@ -200,7 +200,9 @@ def scan_counts(name, lines):
             if body.startswith(VMEM):
                 for r in st:
                     st[r] = min(CAP, st[r] + 1)
-                if kind == "asm" and body.startswith(("global_load", "buffer_load", "flat_load")):
+                if kind == "asm" and body.startswith(("global_load", "buffer_load", "flat_load")) and not body.startswith("global_load_lds"):
+                    # (LDS-DMA — prefetch_candidate — has no VGPR destination: its first operand is the address; it still counts as a
+                    #  younger VMEM operation above)
                     for r in vgprs(body.split(None, 1)[1].split(",")[0]):
                         st[r] = 0
             elif "nv_ready" not in t and re.search(r"s_waitcnt\b.*vmcnt\((\d+)\)", body):
@@ -248,7 +250,11 @@ def scan_inflight(name, lines):
                 continue
             body = t.split(";")[0]
             if kind == "asm":
-                if body.startswith(("global_load", "buffer_load", "flat_load")):
+                if body.startswith("global_load_lds"): # LDS-DMA: reads its address VGPR, writes LDS — nothing goes in flight
+                    touched = vgprs(body) & st
+                    if touched:
+                        problems[(no, t)] = touched
+                elif body.startswith(("global_load", "buffer_load", "flat_load")):
                     ops = body.split(None, 1)[1].split(",")
                     st |= vgprs(ops[0])
                     touched = vgprs(",".join(ops[1:])) & st
