@@ -28,6 +28,7 @@
 #include <stdint.h>
 
 #include "../../include/niagara_vis.h"
+#include "dealing.h"
 
 // Tuning experiments (wave stamps, partial passes, alternative dealing ...) exist only in a separate build
 // (-DNV_EXPERIMENTS -> libniagara_vis_exp.so, tools/): the product library carries no switch that could change a result
@@ -140,6 +141,7 @@ struct ClusterArgs
 	uint32_t cullWavesMagic;  // d = waves of the cull launch (grid x 4)
 	uint32_t genBlocks, genBlocksMagic; // d = workgroups per generation of the cull launch (grid / generations)
 	uint32_t tilesMagic;      // d = scatterTiles
+	DealPlan plan;            // the cull launch's dealing for the command count the host expects (dealing.h); used iff the count word agrees
 	float filterK;         // 4 K u S of the conservative filter / certified test (clustercull.hip make_filter); 0 = both off
 	// what make_filter derives from the view matrix alone, done once on the host in the same fp32 operations (context.hip view_norms):
 	// every wave computed these ~40 instructions in its prologue, and an instruction there costs what 1 / 25 per command costs (§4.1)

@@ -29,6 +29,7 @@
 #include "cullmath.h"
 #include "args.h"
 #include "filtermath.h"
+#include "dealing.h"
 
 namespace nv
 {
@@ -373,11 +374,12 @@ constexpr int CC_DB = NV_CC_DB;         // ring slots of the exact pass (r2 swee
 // filterK = 4 K u S (rounded up), S = max(1, |f0| + |f1|, |f2| + |f3|) of the frustum coefficients: the margins above
 // assume |f| <= 1; the host scales them for other coefficients and passes 0 (no filter, no certified test) for
 // non-finite or absurd ones (filter_k, fill_cluster_args).
+template <bool WITH_IS127 = true>
 NV_DEV FilterDraw make_filter(const NvCullData& cd, const DrawUniform& u, float filterK, float Vn, float V3n, float sumV, float vmax3, float rmax)
 {
 	// (Vn, V3n = the row norms of the view matrix's linear part and of its translation, sumV = the sum of its twelve entries:
 	// the host's, ClusterArgs::viewRowNorm ..., filter_view_norms; vmax3, rmax = the registered pool's bounds, ClusterArgs::poolBounds)
-	return filter_make(cd.view, u.q.x, u.q.y, u.q.z, u.qw, u.scale, u.pos.x, u.pos.y, u.pos.z, filterK, Vn, V3n, sumV, vmax3, rmax);
+	return filter_make<WITH_IS127>(cd.view, u.q.x, u.q.y, u.q.z, u.qw, u.scale, u.pos.x, u.pos.y, u.pos.z, filterK, Vn, V3n, sumV, vmax3, rmax);
 }
 
 // Wave-uniform copy of one draw's filter.  M, aK, aR and scale live in SGPRs; the addends of the four FMA chains are
@@ -734,8 +736,8 @@ NV_DEV uint32_t div_launch_constant(uint32_t n, uint32_t d, uint32_t magic)
 
 NV_DEV uint32_t scatter_tile_commands(uint32_t numCmds, uint32_t tiles, uint32_t tilesMagic)
 {
-	uint32_t T = (div_launch_constant(numCmds + tiles - 1, tiles, tilesMagic) + CC_THREADS - 1) / CC_THREADS * CC_THREADS;
-	return T ? T : CC_THREADS;
+	static_assert(DEAL_TILE_THREADS == CC_THREADS, "dealing.h");
+	return deal_tile_commands(numCmds, tiles, tilesMagic);
 }
 
 // wave w's c-th command (c counts through the wave's chunks in order)
@@ -762,50 +764,26 @@ NV_DEV bool __all_quad_same(uint32_t v, uint32_t ref)
 // of the six resident workgroups per CU.  Returns the number of chunks of this wave; *chunkOf = index of its lane-th
 // chunk, or the plain round-robin when the pass is not weighted (other grid shapes, tiny passes, or more than 64
 // chunks per wave — where a start-up delay of a few commands no longer matters).
-NV_DEV uint32_t make_dealing(uint32_t numChunks, uint32_t wave, uint32_t lane, uint32_t generations, uint32_t gen, bool weighted, uint32_t scalePercent,
-                             uint32_t wavesMagic, uint32_t genBlocks, uint32_t* chunkOf, bool* isWeighted)
+// The part that depends only on the pass's command count and the launch shape is a PLAN (dealing.h deal_plan): the host derives it for the
+// previous launch's count and passes it with the arguments, a wave whose count word says otherwise derives it itself (round 5: ~150 scalar
+// instructions off every wave's start-up path).  What is left per wave: its own rounds, its chunk count and the lane-parallel chunk table.
+NV_DEV uint32_t deal_wave(const DealPlan& p, uint32_t W, uint32_t w, uint32_t lane, uint32_t gen, uint32_t genWaves, uint32_t* chunkOf)
 {
-	const uint32_t W = gridDim.x * CC_WAVES;
-	const uint32_t w = blockIdx.x * CC_WAVES + wave;
-	*chunkOf = lane * W + w;
-	*isWeighted = false;
-	const uint32_t perWaveChunks = div_launch_constant(numChunks, W, wavesMagic);
-	const uint32_t even = perWaveChunks + (w < numChunks - perWaveChunks * W ? 1u : 0u);
-	if (!weighted || generations != 6u || genBlocks * 6u != gridDim.x || perWaveChunks < 4u || perWaveChunks >= 60u)
-		return even;
-	const uint32_t genWaves = genBlocks * CC_WAVES;
-	// delays in 1/16 command: { 0, 0.5, 2.4, 4.2, 7.1, 13.1 }, mean 4.55
-	const int delay16[6] = { 0, 8, 38, 67, 114, 210 };
-	const int perWave16 = (int)div_launch_constant(numChunks * (CC_CHUNK * 16u), W, wavesMagic); // numChunks < 2^22 / CC_CHUNK: no overflow, and < 2^39 / W
-	uint32_t roundsOf[6], weightedTotal = 0;
-#pragma unroll
-	for (int k = 0; k < 6; ++k)
+	if (!p.weighted)
 	{
-		// (the nominal scale is a constant per generation; any other one divides)
-		const int adjust16 = scalePercent == 100u ? 73 - delay16[k] : ((int)scalePercent * (73 - delay16[k])) / 100;
-		const int target16 = perWave16 + adjust16 - (int)(CC_CHUNK * 16u); // keep one even round for the remainder
-		roundsOf[k] = target16 > 0 ? (uint32_t)target16 / (CC_CHUNK * 16u) : 0u;
-		weightedTotal += roundsOf[k] * genWaves;
+		*chunkOf = lane * W + w;
+		return p.perWaveChunks + (w < p.evenRem ? 1u : 0u);
 	}
 	const uint32_t g = gen < 6u ? gen : 5u;
-	const uint32_t rounds = roundsOf[0] * (g == 0) + roundsOf[1] * (g == 1) + roundsOf[2] * (g == 2) + roundsOf[3] * (g == 3) + roundsOf[4] * (g == 4) + roundsOf[5] * (g == 5);
-	if (weightedTotal > numChunks) // cannot happen (floors of targets that sum to less than the total); stay safe
-		return even;
-	const uint32_t rest = numChunks - weightedTotal;
-	const uint32_t restPerWave = div_launch_constant(rest, W, wavesMagic);
-	// the lane-parallel table holds 64 chunks; decided for the whole grid at once (every wave must take the same branch)
-	if (roundsOf[0] + restPerWave + 1u > 64u)
-		return even;
-	const uint32_t mine = rounds + restPerWave + (w < rest - restPerWave * W ? 1u : 0u);
-	// lane j: round j of the weighted part (chunks of earlier rounds = genWaves * sum over generations of min(j, roundsOf)),
+	const uint32_t rounds = p.rounds[0] * (g == 0) + p.rounds[1] * (g == 1) + p.rounds[2] * (g == 2) + p.rounds[3] * (g == 3) + p.rounds[4] * (g == 4) + p.rounds[5] * (g == 5);
+	// lane j: round j of the weighted part (chunks of earlier rounds = genWaves * sum over generations of min(j, rounds)),
 	// then the even remainder
 	uint32_t before = 0;
 #pragma unroll
 	for (int k = 0; k < 6; ++k)
-		before += lane < roundsOf[k] ? lane : roundsOf[k];
-	*chunkOf = lane < rounds ? before * genWaves + w : weightedTotal + w + (lane - rounds) * W;
-	*isWeighted = true;
-	return mine;
+		before += lane < p.rounds[k] ? lane : p.rounds[k];
+	*chunkOf = lane < rounds ? before * genWaves + w : p.weightedTotal + w + (lane - rounds) * W;
+	return rounds + p.restPerWave + (w < p.restRem ? 1u : 0u);
 }
 
 // DIRECT (SoA mirror only): no pass A — every valid command goes straight to pass B, bounds and cone read once.  The
@@ -859,12 +837,24 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 	if (a.hostHint && blockIdx.x == 0 && threadIdx.x == 0)
 		__hip_atomic_store(a.hostHint + (a.payloadCounts ? 4 : 0), numCmds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	constexpr uint32_t CH = LATE ? CC_CHUNK_LATE : CC_CHUNK;
-	const uint32_t numChunks = (numCmds + CH - 1) / CH;
-	uint32_t chunkOf;
+	// (late pass: even dealing — the weights are calibrated on the early pass, and the extra state costs the late variants two resident workgroups per CU)
+	const bool weightedWanted = !LATE && !NV_DBG(a, 32768u); // bit 15 (experiments): even dealing
+	const uint32_t planFlags = (weightedWanted ? DEAL_WEIGHTED_WANTED : 0u) | CH << 8;
+	uint32_t chunkOf, myChunks, tileMul31, numTiles;
 	bool dealtWeighted;
-	const uint32_t myChunks = make_dealing(numChunks, wave, lane, a.generations, gen, !LATE && !NV_DBG(a, 32768u), a.dealScale, a.cullWavesMagic, a.genBlocks, &chunkOf, &dealtWeighted); // (late pass: even — the weights are calibrated on the early pass, and the extra state costs the late variants two resident workgroups per CU) // bit 15 (experiments): even dealing
+	{
+		// (the plan's words merge here and die in deal_wave; with a deal_wave call per branch instead, the experiments build's early variants ran out of VGPRs)
+		DealPlan plan;
+		if (numCmds == a.plan.cmds && planFlags == a.plan.flags && !NV_DBG(a, 1073741824u)) // the host's guess holds (bit 30, experiments: never)
+			plan = a.plan;
+		else
+			plan = deal_plan(numCmds, CH, weightedWanted, gridDim.x * CC_WAVES, a.cullWavesMagic, a.generations, a.genBlocks, gridDim.x, a.dealScale, a.scatterTiles, a.tilesMagic);
+		myChunks = deal_wave(plan, gridDim.x * CC_WAVES, w, lane, gen, a.genBlocks * CC_WAVES, &chunkOf);
+		dealtWeighted = plan.weighted != 0;
+		tileMul31 = plan.tileMul31;
+		numTiles = plan.numTiles;
+	}
 	const uint32_t myCmds = myChunks * CH; // the last chunk of the pass may run past numCmds: guarded below
-	const uint32_t T2 = scatter_tile_commands(numCmds, a.scatterTiles, a.tilesMagic);
 	const uint32_t bank = load_uniform_u32(&a.tileCounts->parity) & 1u;
 	if (w == 0 && lane == 0)
 	{
@@ -940,7 +930,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 		{
 			r.d0 = make_float4(__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w));
 			r.d1 = make_float4(__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z), __uint_as_float(g1.w));
-			r.f = make_filter(a.cd, lane_draw(r), a.filterK, a.viewRowNorm, a.viewTransNorm, a.viewSum, poolVmax3, poolRmax);
+			r.f = make_filter<false>(a.cd, lane_draw(r), a.filterK, a.viewRowNorm, a.viewTransNorm, a.viewSum, poolVmax3, poolRmax); // (is127: in front of pass B)
 		};
 
 		const bool useFilter = a.filterK > 0.0f && !NV_DBG(a, 32u);   // filterK 0: coefficients outside the proven range (host); bit 5 (experiments): every valid command goes to the exact pass
@@ -1090,6 +1080,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				uint32_t curDraw = ~0u, certDraw = ~0u;
 				DrawUniform du = {};
 				CertUniform cf = {};
+				r.f.is127 = filter_is127(r.f.scale); // lane-parallel, for the certified cone test: only segments that have a candidate pay the division
 				const bool certFinal = useCert && !(LATE && a.cd.clusterOcclusionEnabled == 1); // (HiZ decides after frustum and cone)
 				uint64_t pending = candMask; // commands not yet issued into the ring
 				uint32_t cIssued[CC_DB];
@@ -1300,7 +1291,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 		{
 			const bool live = lane < cnt && myIdx < numCmds;
 			const uint64_t m = live ? ((uint64_t)maskHi << 32) | maskLo : 0ull;
-			const uint32_t tileOf = live ? myIdx / T2 : ~0u;
+			const uint32_t tileOf = live ? deal_tile_of(myIdx, tileMul31) : ~0u;
 			uint32_t pc = (uint32_t)__builtin_popcountll(m);
 			const uint32_t tile0 = quad_first_u32(tileOf);
 			const bool quadUniform = __all_quad_same(tileOf, tile0);
@@ -1319,8 +1310,9 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 	// counters' lines (word 1 of a line; the scatter kernel sums them)
 	if (lane == 0 && passedFilter && !(!LATE && !DEFER && a.payloadCounts != nullptr)) // (payloads: no scatter launch follows that would sum and clear them)
 	{
-		const uint32_t numTiles = (numCmds + T2 - 1) / T2;
-		atomicAdd(&a.tileCounts->counts[bank][(w % (numTiles ? numTiles : 1u)) * CC_COUNT_STRIDE + 1], passedFilter);
+		// (any of the lines of the tiles that hold commands — the scatter launch sums them all: the largest power of two of them, a mask instead of a remainder)
+		const uint32_t spread = numTiles ? (1u << (31 - __builtin_clz(numTiles))) - 1u : 0u;
+		atomicAdd(&a.tileCounts->counts[bank][(w & spread) * CC_COUNT_STRIDE + 1], passedFilter);
 	}
 	NV_STAMP(5);
 	if (dbgTime && lane == 0)
@@ -2512,8 +2504,15 @@ static void launch_cc(hipStream_t stream, const ClusterArgs& a, uint32_t gridBlo
 
 // any grid size (pure map); shallow = use the 4-deep filter ring (early pass over the SoA mirror only); direct = no filter
 // pass (SoA mirror only; the host's guess from the previous launch's statistic — a wrong guess only costs speed)
-int launch_cluster_mask(hipStream_t stream, const ClusterArgs& a, int late, bool soa, uint32_t maskBlocks, bool shallow, bool direct)
+// expectedCmds: the host's guess of the indirect command count (the previous launch's, or the explicit override): the dealing plan travels
+// with the arguments for it (dealing.h); 0 = no guess
+int launch_cluster_mask(hipStream_t stream, const ClusterArgs& args, int late, bool soa, uint32_t maskBlocks, bool shallow, bool direct, uint32_t expectedCmds)
 {
+	ClusterArgs a = args;
+	a.plan = deal_plan(expectedCmds, late ? CC_CHUNK_LATE : CC_CHUNK, !late, maskBlocks * CC_WAVES, a.cullWavesMagic, a.generations, a.genBlocks, maskBlocks, a.dealScale,
+	                   a.scatterTiles, a.tilesMagic);
+	if (expectedCmds == 0)
+		a.plan.flags = ~0u; // (no plan: an empty pass derives its own, which costs nothing)
 	if (soa && direct && a.filterK > 0.0f)
 	{
 		if (late)

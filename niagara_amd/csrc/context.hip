@@ -19,7 +19,7 @@
 namespace nv
 {
 
-int launch_cluster_mask(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t maskBlocks, bool shallow, bool direct);
+int launch_cluster_mask(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t maskBlocks, bool shallow, bool direct, uint32_t expectedCmds);
 bool clustercull_prefers_shallow(uint32_t previousCommandCount);
 bool clustercull_prefers_direct(uint32_t previousCommandCount, uint32_t previousPassedFilter, uint32_t percent);
 int launch_cluster_scatter(hipStream_t, const ClusterArgs&, uint32_t scatterBlocks, uint32_t waves);
@@ -904,7 +904,8 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	if (laneForm)
 		rc = nv::launch_cluster_bits(s, a, a.soaBounds != nullptr, persistent_grid(ctx, ctx->bitsBlocksPerCU));
 	else
-		rc = nv::launch_cluster_mask(s, a, twoStage ? 0 : late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), shallow, direct);
+		rc = nv::launch_cluster_mask(s, a, twoStage ? 0 : late, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), shallow, direct,
+		                             a.commandCountOverride ? a.commandCountOverride : (ctx->hintHost ? ctx->hintHost[0] : 0u));
 	count_cull_variant(ctx, a, laneForm, bits, late && !twoStage, shallow, direct); // (the two-stage late pass launches the early form)
 	ctx->variants[NV_VARIANT_HIZ_STAGE] += twoStage ? 1u : 0u;
 	hipEvent_t e1 = prof_mark(ctx, s);
@@ -970,7 +971,8 @@ int nv_taskcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 		if (bitsForm)
 			rc = nv::launch_cluster_bits(s, a, a.soaBounds != nullptr, persistent_grid(ctx, ctx->bitsBlocksPerCU));
 		else
-			rc = nv::launch_cluster_mask(s, a, 0, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), shallow, direct);
+			rc = nv::launch_cluster_mask(s, a, 0, a.soaBounds != nullptr, persistent_grid(ctx, ctx->ccBlocksPerCU), shallow, direct,
+			                             a.commandCountOverride ? a.commandCountOverride : (ctx->hintHost ? ctx->hintHost[4] : 0u));
 		count_cull_variant(ctx, a, bitsForm, cull->clusterOcclusionEnabled == 1 && cull->postPass == 0, false, shallow, direct);
 		return rc;
 	}

@@ -83,28 +83,37 @@ NV_FM void filter_view_norms(const float* V, float* Vn_, float* V3n_, float* sum
 // FMAs less per meshlet in the stream (round 5).  tK only ever ENLARGES the margin (by < 4 % where beta dominates alpha, the usual
 // case: positions are much larger than a mesh's own extent), so every "certainly outside" stays certain; the three fp32 roundings of its
 // evaluation are relative 2^-24 against the analysis' > 2x slack.  The certified test (pass B) keeps the per-meshlet T.
+// 1 / (127 scale), the one IEEE division of the derivation (~12 instructions): only the certified cone test reads it, so the cull kernel derives it
+// when a segment has a candidate at all (filter_make<false> + filter_is127 in front of pass B) instead of on every wave's start-up path.
+NV_FM float filter_is127(float s) { return (1.0f / s) * INV_127; }
+
+template <bool WITH_IS127 = true>
 NV_FM FilterDraw filter_make(const float* V, float x, float y, float z, float w, float s, float px, float py, float pz, float filterK, float Vn, float V3n, float sumV,
                              float vmax3, float rmax)
 {
-	// R = (1 - 2|q_xyz|^2) I + 2 q q^T + 2 w [q]x  (valid for any q, unit or not) — same map as rotateQuat
+	// R = (1 - 2|q_xyz|^2) I + 2 q q^T + 2 w [q]x  (valid for any q, unit or not) — same map as rotateQuat.
+	// Written with explicit fused multiply-adds (round 5): the derivation runs once per wave in front of its first filter result, on the launch's
+	// start-up path, where an instruction costs what 1 / 25 of an instruction per command costs in the stream; every FMA is one rounding where
+	// the un-fused pair had two, so the approximation's chains only get shorter than the <= 8 roundings the analysis allows them.
+	const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
 	float R[9];
-	R[0] = 1.0f - 2.0f * (y * y + z * z);
-	R[1] = 2.0f * (x * y - w * z);
-	R[2] = 2.0f * (x * z + w * y);
-	R[3] = 2.0f * (x * y + w * z);
-	R[4] = 1.0f - 2.0f * (x * x + z * z);
-	R[5] = 2.0f * (y * z - w * x);
-	R[6] = 2.0f * (x * z - w * y);
-	R[7] = 2.0f * (y * z + w * x);
-	R[8] = 1.0f - 2.0f * (x * x + y * y);
+	R[0] = __builtin_fmaf(-2.0f, yy + zz, 1.0f);
+	R[1] = 2.0f * __builtin_fmaf(-w, z, xy);
+	R[2] = 2.0f * __builtin_fmaf(w, y, xz);
+	R[3] = 2.0f * __builtin_fmaf(w, z, xy);
+	R[4] = __builtin_fmaf(-2.0f, xx + zz, 1.0f);
+	R[5] = 2.0f * __builtin_fmaf(-w, x, yz);
+	R[6] = 2.0f * __builtin_fmaf(-w, y, xz);
+	R[7] = 2.0f * __builtin_fmaf(w, x, yz);
+	R[8] = __builtin_fmaf(-2.0f, xx + yy, 1.0f);
 	FilterDraw f;
 #pragma unroll
 	for (int r = 0; r < 3; ++r)
 	{
 #pragma unroll
 		for (int c = 0; c < 3; ++c)
-			f.m[3 * r + c] = s * (V[r] * R[c] + V[4 + r] * R[3 + c] + V[8 + r] * R[6 + c]);
-		f.b[r] = V[r] * px + V[4 + r] * py + V[8 + r] * pz + V[12 + r];
+			f.m[3 * r + c] = s * __builtin_fmaf(V[8 + r], R[6 + c], __builtin_fmaf(V[4 + r], R[3 + c], V[r] * R[c]));
+		f.b[r] = __builtin_fmaf(V[8 + r], pz, __builtin_fmaf(V[4 + r], py, __builtin_fmaf(V[r], px, V[12 + r])));
 	}
 	const float Qa = __builtin_fabsf(x) + __builtin_fabsf(y) + __builtin_fabsf(z);
 	const float rotAbs = 1.0f + 2.0f * Qa * (Qa + __builtin_fabsf(w));
@@ -123,7 +132,7 @@ NV_FM FilterDraw filter_make(const float* V, float x, float y, float z, float w,
 	f.tK = __builtin_fmaf(f.aR, rmax, __builtin_fmaf(f.aK, vmax3, f.bK));
 	f.scale = s;
 	f.coneK = CONE_K_SLOPE * (Vn * rotAbs) + CONE_K_OFFSET;
-	f.is127 = (1.0f / s) * INV_127;
+	f.is127 = WITH_IS127 ? filter_is127(s) : 0.0f;
 	return f;
 }
 
