@@ -767,6 +767,18 @@ NV_DEV bool __all_quad_same(uint32_t v, uint32_t ref)
 // The part that depends only on the pass's command count and the launch shape is a PLAN (dealing.h deal_plan): the host derives it for the
 // previous launch's count and passes it with the arguments, a wave whose count word says otherwise derives it itself (round 5: ~150 scalar
 // instructions off every wave's start-up path).  What is left per wave: its own rounds, its chunk count and the lane-parallel chunk table.
+// the chunk of this lane's command in segment s (<= 3: the table holds 64 chunks) of a wave that deals from its table (deal_wave)
+NV_DEV uint32_t segment_chunk(uint32_t chunkOf, uint32_t s)
+{
+	switch (s)
+	{
+	case 0: return dpp_move_u32<0x00>(chunkOf); // quad_perm:[0,0,0,0]
+	case 1: return dpp_move_u32<0x55>(chunkOf);
+	case 2: return dpp_move_u32<0xAA>(chunkOf);
+	default: return dpp_move_u32<0xFF>(chunkOf);
+	}
+}
+
 NV_DEV uint32_t deal_wave(const DealPlan& p, uint32_t W, uint32_t w, uint32_t lane, uint32_t gen, uint32_t genWaves, uint32_t* chunkOf)
 {
 	if (!p.weighted)
@@ -776,13 +788,17 @@ NV_DEV uint32_t deal_wave(const DealPlan& p, uint32_t W, uint32_t w, uint32_t la
 	}
 	const uint32_t g = gen < 6u ? gen : 5u;
 	const uint32_t rounds = p.rounds[0] * (g == 0) + p.rounds[1] * (g == 1) + p.rounds[2] * (g == 2) + p.rounds[3] * (g == 3) + p.rounds[4] * (g == 4) + p.rounds[5] * (g == 5);
-	// lane j: round j of the weighted part (chunks of earlier rounds = genWaves * sum over generations of min(j, rounds)),
-	// then the even remainder
+	// table entry j: round j of the weighted part (chunks of earlier rounds = genWaves * sum over generations of min(j, rounds)), then the even
+	// remainder.  Entry j lives in lane ((j & 15) << 2) | (j >> 4): the lanes of a segment's quad q all want entry 16 s + q (s = the segment's
+	// number, four commands per chunk), which is lane s of their own quad — one DPP quad broadcast (segment_chunk) where a table in lane order
+	// needed a ds_bpermute_b32 round trip through LDS on every wave's start-up path.
+	static_assert(CC_CHUNK == 4, "the chunk table's quad layout");
+	const uint32_t j = (lane >> 2) + 16u * (lane & 3u);
 	uint32_t before = 0;
 #pragma unroll
 	for (int k = 0; k < 6; ++k)
-		before += lane < p.rounds[k] ? lane : p.rounds[k];
-	*chunkOf = lane < rounds ? before * genWaves + w : p.weightedTotal + w + (lane - rounds) * W;
+		before += j < p.rounds[k] ? j : p.rounds[k];
+	*chunkOf = j < rounds ? before * genWaves + w : p.weightedTotal + w + (j - rounds) * W;
 	return rounds + p.restPerWave + (w < p.restRem ? 1u : 0u);
 }
 
@@ -888,7 +904,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 
 		// lane l holds the wave's (seg + l)-th command and (below) the MeshDraw it points at
 		const uint32_t cidx = (seg + lane) / CH;
-		const uint32_t chunk = dealtWeighted ? (uint32_t)__shfl(chunkOf, cidx & 63u, 64) : cidx * (gridDim.x * CC_WAVES) + w;
+		const uint32_t chunk = dealtWeighted ? segment_chunk(chunkOf, seg >> 6) : cidx * (gridDim.x * CC_WAVES) + w;
 		const uint32_t myIdx = chunk * CH + (seg + lane) % CH;
 		SegmentRegs r = {};
 		if (lane < cnt && myIdx < numCmds)
