@@ -779,8 +779,9 @@ NV_DEV uint32_t segment_chunk(uint32_t chunkOf, uint32_t s)
 	}
 }
 
-NV_DEV uint32_t deal_wave(const DealPlan& p, uint32_t W, uint32_t w, uint32_t lane, uint32_t gen, uint32_t genWaves, uint32_t* chunkOf)
+NV_DEV uint32_t deal_wave(const DealPlan& p, uint32_t w, uint32_t lane, uint32_t gen, uint32_t genWaves, uint32_t* chunkOf)
 {
+	const uint32_t W = p.waves;
 	if (!p.weighted)
 	{
 		*chunkOf = lane * W + w;
@@ -838,16 +839,41 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 	if (!NV_DBG(a, 262144u)) // bit 18 (experiments)
 		__builtin_amdgcn_s_setprio(3);
 	const uint32_t gen = a.genBlocks ? div_launch_constant(blockIdx.x, a.genBlocks, a.genBlocksMagic) : 0u; // (workgroups are numbered generation-major)
-	// the registered pool's bounds for the filter's per-draw margin (filtermath.h filter_make): two scalar loads next to the count word's,
-	// consumed by the lane-parallel filter derivation long after.  No mirror (AoS in place): nothing is known, nothing is certain.
+	// The three words of device memory every wave needs before it can ask for its commands — the indirect count, the pass's bank of tile counters,
+	// the registered pool's bounds for the filter's per-draw margin (filtermath.h filter_make; no mirror: nothing is known, nothing is certain) —
+	// requested together and waited for ONCE (round 5).  Left to hipcc each became a load at its first use with an s_waitcnt lgkmcnt(0) of its
+	// own: two or three L2 round trips in a row on every wave's start-up path, where the launch is most sensitive.
 	float poolVmax3 = __builtin_inff(), poolRmax = __builtin_inff();
+	uint32_t rawGroups, bankWord;
+#ifdef NV_PLAIN_LOADS
+	bankWord = load_uniform_u32(&a.tileCounts->parity);
+	rawGroups = load_uniform_u32(a.count4 + 1);
 	if (SOA)
 	{
 		k_f32p pb = (k_f32p)(uintptr_t)a.poolBounds;
 		poolVmax3 = pb[0];
 		poolRmax = pb[1];
 	}
-	const uint32_t numCmds = indirect_command_count(a);
+#else
+	if (SOA)
+	{
+		uint64_t pool;
+		asm volatile("s_nop 4\n\ts_load_dword %0, %3, 0x4\n\ts_load_dword %1, %4, 0x0\n\ts_load_dwordx2 %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
+		             : "=&s"(rawGroups), "=&s"(bankWord), "=&s"(pool)
+		             : "s"(a.count4), "s"(&a.tileCounts->parity), "s"(a.poolBounds)
+		             : "memory");
+		poolVmax3 = __uint_as_float((uint32_t)pool);
+		poolRmax = __uint_as_float((uint32_t)(pool >> 32));
+	}
+	else
+		asm volatile("s_nop 4\n\ts_load_dword %0, %2, 0x4\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+		             : "=&s"(rawGroups), "=&s"(bankWord)
+		             : "s"(a.count4), "s"(&a.tileCounts->parity)
+		             : "memory");
+#endif
+	// vkCmdDispatchIndirect(dccb, 4): see indirect_command_count
+	const uint32_t numCmds = a.commandCountOverride ? a.commandCountOverride : (rawGroups < 65535u ? rawGroups : 65535u) * 64u;
+	const uint32_t bank = bankWord & 1u;
 	// (nv_taskcull's payload form has its own word: no scatter launch follows it that would refresh the filter statistic in word 1, so
 	// its count must not become the denominator of nv_clustercull's next filter / direct choice — ADVICE r3)
 	if (a.hostHint && blockIdx.x == 0 && threadIdx.x == 0)
@@ -856,7 +882,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 	// (late pass: even dealing — the weights are calibrated on the early pass, and the extra state costs the late variants two resident workgroups per CU)
 	const bool weightedWanted = !LATE && !NV_DBG(a, 32768u); // bit 15 (experiments): even dealing
 	const uint32_t planFlags = (weightedWanted ? DEAL_WEIGHTED_WANTED : 0u) | CH << 8;
-	uint32_t chunkOf, myChunks, tileMul31, numTiles;
+	uint32_t chunkOf, myChunks, tileMul31, numTiles, gridWaves;
 	bool dealtWeighted;
 	{
 		// (the plan's words merge here and die in deal_wave; with a deal_wave call per branch instead, the experiments build's early variants ran out of VGPRs)
@@ -865,13 +891,13 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 			plan = a.plan;
 		else
 			plan = deal_plan(numCmds, CH, weightedWanted, gridDim.x * CC_WAVES, a.cullWavesMagic, a.generations, a.genBlocks, gridDim.x, a.dealScale, a.scatterTiles, a.tilesMagic);
-		myChunks = deal_wave(plan, gridDim.x * CC_WAVES, w, lane, gen, a.genBlocks * CC_WAVES, &chunkOf);
+		myChunks = deal_wave(plan, w, lane, gen, a.genBlocks * CC_WAVES, &chunkOf);
+		gridWaves = plan.waves;
 		dealtWeighted = plan.weighted != 0;
 		tileMul31 = plan.tileMul31;
 		numTiles = plan.numTiles;
 	}
 	const uint32_t myCmds = myChunks * CH; // the last chunk of the pass may run past numCmds: guarded below
-	const uint32_t bank = load_uniform_u32(&a.tileCounts->parity) & 1u;
 	if (w == 0 && lane == 0)
 	{
 		a.tileCounts->k2parity = bank;
@@ -904,7 +930,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 
 		// lane l holds the wave's (seg + l)-th command and (below) the MeshDraw it points at
 		const uint32_t cidx = (seg + lane) / CH;
-		const uint32_t chunk = dealtWeighted ? segment_chunk(chunkOf, seg >> 6) : cidx * (gridDim.x * CC_WAVES) + w;
+		const uint32_t chunk = dealtWeighted ? segment_chunk(chunkOf, seg >> 6) : cidx * gridWaves + w;
 		const uint32_t myIdx = chunk * CH + (seg + lane) % CH;
 		SegmentRegs r = {};
 		if (lane < cnt && myIdx < numCmds)
@@ -931,6 +957,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 		// SOA path: the MeshDraw gather is issued uncounted, AHEAD of the filter ring's first loads, and waited for
 		// behind them (counted), so the dependent chain is commands -> {draws, first bounds} instead of
 		// commands -> draws -> filters -> first bounds.
+		const bool useFilter = a.filterK > 0.0f && !NV_DBG(a, 32u);   // filterK 0: coefficients outside the proven range (host); bit 5 (experiments): every valid command goes to the exact pass
 		u32x4 g0 = {}, g1 = {};
 		auto gather_issue = [&]()
 		{
@@ -947,9 +974,10 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 			r.d0 = make_float4(__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w));
 			r.d1 = make_float4(__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z), __uint_as_float(g1.w));
 			r.f = make_filter<false>(a.cd, lane_draw(r), a.filterK, a.viewRowNorm, a.viewTransNorm, a.viewSum, poolVmax3, poolRmax); // (is127: in front of pass B)
+			if (!useFilter) // an infinite margin: nothing is certainly outside.  (Here, lane-parallel once per segment: as a test where the filter loop
+				r.f.tK = __builtin_inff(); // broadcasts a draw's filter, hipcc materialised the uniform flag with two vector instructions per COMMAND)
 		};
 
-		const bool useFilter = a.filterK > 0.0f && !NV_DBG(a, 32u);   // filterK 0: coefficients outside the proven range (host); bit 5 (experiments): every valid command goes to the exact pass
 		const bool useCert = a.filterK > 0.0f && !NV_DBG(a, 1048576u); // bit 20 (experiments): pass B with the reference arithmetic only
 		const bool streamOnly = NV_DBG(a, 64u); // bit 6 (experiments): no arithmetic at all
 		const bool updateBits = LATE && a.cd.clusterOcclusionEnabled == 1;
@@ -1062,8 +1090,6 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 						if (chgN & (1u << k)) // first command of a draw within this segment
 						{
 							fd = segment_filter(r, c);
-							if (!useFilter) // (uniform, loop-invariant; here instead of per command) an infinite margin: nothing is certainly outside
-								fd.tK = __builtin_inff();
 						}
 						uint64_t cand = ~__ballot(certainly_outside(a.cd, fd, b0, b1));
 						if (!(fullN & (1u << k))) // partial, dummy (taskCount 0) or past the wave's last command (lanes >= cnt hold 0)

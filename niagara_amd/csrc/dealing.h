@@ -36,6 +36,7 @@ struct DealPlan
 	uint32_t tileMul31;     // a command's tile = mulhi((index >> 8) << 1, tileMul31): tileCmds is a multiple of 256, so index / tileCmds = (index >> 8) / d with
 	                        // d = tileCmds >> 8, and m = floor(2^31 / d) + 1 gives floor(n / d) = floor(n m / 2^31) for n < 2^31 / d (n < 2^24 here, d <= 2^16)
 	uint32_t numTiles;      // scatter tiles that hold commands: ceil(cmds / tileCmds)
+	uint32_t waves;         // W = waves of the launch (the grid is a scalar load away — the dispatch packet — for a wave that has the plan in its arguments)
 };
 
 constexpr uint32_t DEAL_WEIGHTED_WANTED = 1u;
@@ -80,6 +81,7 @@ NV_DP DealPlan deal_plan(uint32_t numCmds, uint32_t chunk, bool weightedWanted, 
 	p.cmds = numCmds;
 	p.flags = (weightedWanted ? DEAL_WEIGHTED_WANTED : 0u) | chunk << 8;
 	p.weighted = 0;
+	p.waves = W;
 	const uint32_t numChunks = (numCmds + chunk - 1u) / chunk;
 	p.perWaveChunks = deal_div(numChunks, W, wavesMagic);
 	p.evenRem = numChunks - p.perWaveChunks * W;
