@@ -112,6 +112,10 @@ struct nv_context
 	// command count of the previous clustercull launch, written by its kernel into mapped host memory (tuning hint)
 	volatile uint32_t* hintHost;
 	uint32_t* hintDevice;
+	// the command buffer the last nv_drawcull(task) of this context wrote: a cluster pass over it runs on the commands of draws the draw-level cull
+	// already found visible — nothing for the conservative filter to remove — so, while no launch has left a filter statistic yet (a fresh
+	// context's first frames: the hint words lag the launches that fill them), such a pass takes the direct / lane forms instead of the filter form
+	const void* taskCommandsFrom;
 	uint32_t fusedReset;
 	uint32_t fusedSubmit;
 	uint64_t* countsSink; // nv_set_counts_sink
@@ -779,7 +783,10 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 			}
 #endif
 	if (task)
+	{
 		ctx->variants[a.taskList ? NV_VARIANT_TASK_LIST : NV_VARIANT_TASK_PER_DRAW] += 1u;
+		ctx->taskCommandsFrom = d_commands;
+	}
 	hipEvent_t e0 = prof_mark(ctx, (hipStream_t)stream);
 	rc = nv::launch_drawcull((hipStream_t)stream, a, late, task);
 	prof_push(ctx, NV_PROF_DRAWCULL, e0, prof_mark(ctx, (hipStream_t)stream));
@@ -887,6 +894,8 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	// mapped host words the previous launches left: [0] command count, [1] commands their filter did not (or would not
 	// have) finished — possibly a launch or two behind, which only matters for speed
 	bool direct = ctx->hintHost && nv::clustercull_prefers_direct(ctx->hintHost[0], ctx->hintHost[1], ctx->directPercent);
+	if (!(ctx->hintHost && ctx->hintHost[0] != 0) && d_commands == ctx->taskCommandsFrom) // no statistic yet: by where the commands come from
+		direct = true;
 	if (ctx->forceDirect >= 0)
 		direct = ctx->forceDirect != 0;
 	// Late pass with HiZ = three launches: the cull kernel in its early form (frustum + cone ballots), the occlusion probe
@@ -964,6 +973,8 @@ int nv_taskcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 		if (ctx->forceShallow >= 0)
 			shallow = ctx->forceShallow != 0;
 		bool direct = ctx->hintHost && nv::clustercull_prefers_direct(ctx->hintHost[0], ctx->hintHost[1], ctx->directPercent);
+		if (!(ctx->hintHost && ctx->hintHost[0] != 0) && d_commands == ctx->taskCommandsFrom) // (as in nv_clustercull)
+			direct = true;
 		if (ctx->forceDirect >= 0)
 			direct = ctx->forceDirect != 0;
 		const bool poolInCache = a.soaBounds != nullptr && (uint64_t)ctx->scene->mirroredCount * 12u <= (48ull << 20);
