@@ -8,7 +8,7 @@ import sys
 
 import numpy as np
 
-os.environ["NV_DEBUG_MODE"] = str(8 | 134217728)
+os.environ["NV_DEBUG_MODE"] = str(8 | 134217728 | int(os.environ.get("NV_DEBUG_MODE", "0")))  # (further bits from the caller: 4096 = pass-B loads only, 1048576 = reference arithmetic only)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 
