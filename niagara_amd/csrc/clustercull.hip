@@ -407,6 +407,11 @@ NV_DEV float pin_vgpr(float x)
 // false at once;  T = bK + aK (|vx| + |vy| + |vz|) + aR |radius|  over-estimates 4E (sum >= max) plus the roundings of
 // radius * scale and of the sums with r — and the filter uses tK >= T, the same expression at the registered pool's largest
 // |centre component| and |radius| (filtermath.h filter_make): one value per draw, no per-meshlet arithmetic for the margin.
+// FOLD (round 5, the early pass): the x and y rows of f arrive pre-multiplied by the side planes' coefficients (SegmentRegs::fold: f.m[0..2], f.b0 carry
+// frustum[0], f.m[3..5], f.b1 carry frustum[2]), so a side plane's distance is one FMA instead of a multiply and an FMA — 17 instead of 19 instructions
+// per 64 meshlets in a loop that is bound by vector issue.  One more rounding per entry of two of the three chains (relative u each, against the > 2x the
+// margin's K = 48 leaves over the ~21 roundings it counts); tests/test_cert_margins.py holds this very form against the reference in its emulation.
+template <bool FOLD>
 NV_DEV bool certainly_outside(const NvCullData& cd, const FilterUniform& f, uint32_t b0, uint32_t b1)
 {
 	const float vx = half_bits_to_float(b0 & 0xffffu), vy = half_bits_to_float(b0 >> 16), vz = half_bits_to_float(b1 & 0xffffu);
@@ -415,8 +420,8 @@ NV_DEV bool certainly_outside(const NvCullData& cd, const FilterUniform& f, uint
 	const float cy = __builtin_fmaf(f.m[3], vx, __builtin_fmaf(f.m[4], vy, __builtin_fmaf(f.m[5], vz, f.b1)));
 	const float cz = __builtin_fmaf(f.m[6], vx, __builtin_fmaf(f.m[7], vy, __builtin_fmaf(f.m[8], vz, f.b2)));
 	const float thr = __builtin_fmaf(f.scale, rad, f.tK);
-	const float g1 = __builtin_fmaf(cz, cd.frustum[1], -(__builtin_fabsf(cx) * cd.frustum[0]));
-	const float g2 = __builtin_fmaf(cz, cd.frustum[3], -(__builtin_fabsf(cy) * cd.frustum[2]));
+	const float g1 = FOLD ? __builtin_fmaf(cz, cd.frustum[1], -__builtin_fabsf(cx)) : __builtin_fmaf(cz, cd.frustum[1], -(__builtin_fabsf(cx) * cd.frustum[0]));
+	const float g2 = FOLD ? __builtin_fmaf(cz, cd.frustum[3], -__builtin_fabsf(cy)) : __builtin_fmaf(cz, cd.frustum[3], -(__builtin_fabsf(cy) * cd.frustum[2]));
 	const float gn = cz - cd.znear;
 	const float gf = cd.zfar - cz;
 	const float g = __builtin_fminf(__builtin_fminf(g1, g2), __builtin_fminf(gn, gf)); // minNum: a NaN distance is ignored, as a false compare was
@@ -431,6 +436,7 @@ struct SegmentRegs
 	uint32_t drawId, taskOffset, taskCount, lateDrawVisibility, meshletVisibilityOffset;
 	float4 d0, d1; // position.xyz, scale | orientation.xyzw of draws[drawId]
 	FilterDraw f;  // the frustum filter of that draw, derived lane-parallel (64 draws per ~130 VALU instructions)
+	float fold[8]; // FOLD (the early pass): f.m[0..2], f.b[0] times frustum[0] | f.m[3..5], f.b[1] times frustum[2] — what the filter loop broadcasts for its x / y rows
 };
 
 NV_DEV NvMeshTaskCommand segment_command(const SegmentRegs& r, uint32_t c)
@@ -452,15 +458,20 @@ NV_DEV uint32_t writelane_u32(uint32_t vec, uint32_t val, uint32_t c)
 
 NV_DEV float readlane_f(float v, uint32_t c) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), c)); }
 
+template <bool FOLD>
 NV_DEV FilterUniform segment_filter(const SegmentRegs& r, uint32_t c)
 {
 	FilterUniform f;
 #pragma unroll
-	for (int i = 0; i < 9; ++i)
-		f.m[i] = readlane_f(r.f.m[i], c);
+	for (int i = 0; i < 3; ++i)
+	{
+		f.m[i] = readlane_f(FOLD ? r.fold[i] : r.f.m[i], c);
+		f.m[3 + i] = readlane_f(FOLD ? r.fold[4 + i] : r.f.m[3 + i], c);
+		f.m[6 + i] = readlane_f(r.f.m[6 + i], c);
+	}
 	f.scale = readlane_f(r.f.scale, c);
-	f.b0 = pin_vgpr(readlane_f(r.f.b[0], c));
-	f.b1 = pin_vgpr(readlane_f(r.f.b[1], c));
+	f.b0 = pin_vgpr(readlane_f(FOLD ? r.fold[3] : r.f.b[0], c));
+	f.b1 = pin_vgpr(readlane_f(FOLD ? r.fold[7] : r.f.b[1], c));
 	f.b2 = pin_vgpr(readlane_f(r.f.b[2], c));
 	f.tK = pin_vgpr(readlane_f(r.f.tK, c));
 	return f;
@@ -957,6 +968,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 		// SOA path: the MeshDraw gather is issued uncounted, AHEAD of the filter ring's first loads, and waited for
 		// behind them (counted), so the dependent chain is commands -> {draws, first bounds} instead of
 		// commands -> draws -> filters -> first bounds.
+		constexpr bool FOLD_A = !LATE; // (the late variants have no eight VGPRs to spare under the six-workgroup bound)
 		const bool useFilter = a.filterK > 0.0f && !NV_DBG(a, 32u);   // filterK 0: coefficients outside the proven range (host); bit 5 (experiments): every valid command goes to the exact pass
 		u32x4 g0 = {}, g1 = {};
 		auto gather_issue = [&]()
@@ -974,6 +986,17 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 			r.d0 = make_float4(__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w));
 			r.d1 = make_float4(__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z), __uint_as_float(g1.w));
 			r.f = make_filter<false>(a.cd, lane_draw(r), a.filterK, a.viewRowNorm, a.viewTransNorm, a.viewSum, poolVmax3, poolRmax); // (is127: in front of pass B)
+			if (FOLD_A)
+			{
+#pragma unroll
+				for (int i = 0; i < 3; ++i)
+				{
+					r.fold[i] = a.cd.frustum[0] * r.f.m[i];
+					r.fold[4 + i] = a.cd.frustum[2] * r.f.m[3 + i];
+				}
+				r.fold[3] = a.cd.frustum[0] * r.f.b[0];
+				r.fold[7] = a.cd.frustum[2] * r.f.b[1];
+			}
 			if (!useFilter) // an infinite margin: nothing is certainly outside.  (Here, lane-parallel once per segment: as a test where the filter loop
 				r.f.tK = __builtin_inff(); // broadcasts a draw's filter, hipcc materialised the uniform flag with two vector instructions per COMMAND)
 		};
@@ -1089,9 +1112,9 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 						const uint32_t b0 = (uint32_t)ring[k].bounds, b1 = (uint32_t)(ring[k].bounds >> 32);
 						if (chgN & (1u << k)) // first command of a draw within this segment
 						{
-							fd = segment_filter(r, c);
+							fd = segment_filter<FOLD_A>(r, c);
 						}
-						uint64_t cand = ~__ballot(certainly_outside(a.cd, fd, b0, b1));
+						uint64_t cand = ~__ballot(certainly_outside<FOLD_A>(a.cd, fd, b0, b1));
 						if (!(fullN & (1u << k))) // partial, dummy (taskCount 0) or past the wave's last command (lanes >= cnt hold 0)
 							cand &= (1ull << (uint32_t)__builtin_amdgcn_readlane(r.taskCount, c)) - 1ull;
 						if (BITS_A) // early pass: only last frame's visible clusters (clustercull.comp.glsl:91-92)

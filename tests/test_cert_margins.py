@@ -154,6 +154,23 @@ def test_margins_cover_the_distance_to_the_reference(shim, case):
     assert np.isfinite(tK).all() and (tK.astype(np.float64) >= T.astype(np.float64) * (1.0 - 2.0 ** -21))[ok].all(), name
     out_f = g < -fma64(scale, rad, tK)
     assert not (ok & out_f & vis_ref).any(), name
+    # ... and in the form the early pass's filter loop evaluates (clustercull.hip certainly_outside<FOLD>): the x / y rows of M and b pre-multiplied by the side
+    # planes' coefficients (one fp32 rounding per entry), a side plane's distance one FMA  cz f1 - |f0 cx|
+    ms, bs = m.copy(), b.copy()
+    ms[..., 0:3] = (fr[0] * m[..., 0:3]).astype(f32)
+    ms[..., 3:6] = (fr[2] * m[..., 3:6]).astype(f32)
+    bs[..., 0] = (fr[0] * b[..., 0]).astype(f32)
+    bs[..., 1] = (fr[2] * b[..., 1]).astype(f32)
+    cs = np.stack([fma64(ms[..., 3 * r], v[..., 0], fma64(ms[..., 3 * r + 1], v[..., 1], fma64(ms[..., 3 * r + 2], v[..., 2], bs[..., r]))) for r in range(3)], axis=-1)
+    g1s = fma64(cs[..., 2], fr[1], -np.abs(cs[..., 0]))
+    g2s = fma64(cs[..., 2], fr[3], -np.abs(cs[..., 1]))
+    gs = np.minimum(np.minimum(g1s, g2s), np.minimum(cs[..., 2] - znear, zfar - cs[..., 2]))
+    out_fold = gs < -fma64(scale, rad, tK)
+    assert not (ok & out_fold & vis_ref).any(), name
+    assert (ok & out_fold).sum() >= 0.97 * (ok & out_m).sum(), name
+    # the folded distances stay within a small part of the margin of the unfolded ones (what one more rounding per entry may cost)
+    drift = np.where(ok, np.maximum(np.abs(g1s.astype(np.float64) - g1), np.abs(g2s.astype(np.float64) - g2)) / T.astype(np.float64), 0.0)
+    assert drift.max() < 0.05, "%s: folding the plane coefficients moves a distance by %.3f of T" % (name, drift.max())
     assert (ok & out_f).sum() >= 0.97 * (ok & out_m).sum(), "%s: the pool-wide margin gives up %d of %d certain rejections" % (name, (ok & out_m & ~out_f).sum(), (ok & out_m).sum())
     assert (ok & (out_m | in_m)).mean() > 0.9  # the margins must not be so wide that nothing is decided
     # cone
