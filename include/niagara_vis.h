@@ -390,6 +390,9 @@ typedef struct NvTriangleMask
 int nv_meshlet_bounds(nv_context* ctx, void* stream, const NvVertex* d_vertices, const uint32_t* d_meshletData, NvMeshlet* d_meshlets,
                       uint32_t meshletCount, float* d_bounds8);
 
+/* Buffer sizes: d_meshletData must hold at least one word and d_vertices at least one record even when every slot of d_clusterIndices is ~0 —
+ * the lanes of a pass that have no vertex / triangle to fetch read element 0 of both (unconditional loads: no branch between a load and its
+ * use), which the reference's mesh shader never touches for an empty slot. */
 int nv_trianglecull(nv_context* ctx, void* stream, const NvGlobals* globals, const NvMeshTaskCommand* d_commands,
                     const NvMeshDraw* d_draws, const NvMeshlet* d_meshlets, const uint32_t* d_meshletData,
                     const NvVertex* d_vertices, const uint32_t* d_clusterIndices, const uint32_t* d_clusterCount4,

@@ -47,6 +47,18 @@ namespace nv
 // LDS round trip of ~100 cycles per step, six steps per scan, on the dependent chain of every scatter launch and of every iteration of the
 // lane kernels (round 4).  A lane whose DPP source is outside its row, masked by row_mask or inactive keeps `old` = 0, i.e. adds
 // nothing.  Every call site runs with all 64 lanes active (a scan over a partial wave would also have been wrong with the shuffles).
+//  row_bcast:15 / row_bcast:31 / wave_shr:1 exist on GFX9-family wave64 parts only (gfx950 is one): another ARCH must not compile
+// these silently into something else.  And the helpers need ALL 64 lanes active (wave_sum_u32 reads lane 63; an inactive DPP source adds
+// nothing): the experiments build traps on a partial exec mask.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "args.h: the DPP scans are written for GFX9-family wave64 targets (gfx950)"
+#endif
+#ifdef NV_EXPERIMENTS
+#define NV_ASSERT_FULL_EXEC() do { if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap(); } while (0)
+#else
+#define NV_ASSERT_FULL_EXEC() do { } while (0)
+#endif
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_pull_u32(uint32_t v)
 {
@@ -55,6 +67,7 @@ __device__ __forceinline__ uint32_t dpp_pull_u32(uint32_t v)
 
 __device__ __forceinline__ uint32_t wave_scan_inclusive_u32(uint32_t v)
 {
+	NV_ASSERT_FULL_EXEC();
 	v += dpp_pull_u32<0x111, 0xf>(v); // row_shr:1
 	v += dpp_pull_u32<0x112, 0xf>(v); // row_shr:2
 	v += dpp_pull_u32<0x114, 0xf>(v); // row_shr:4

@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <new>
+#include <algorithm>
 #include <vector>
 #include <stdlib.h>
 #include <stdint.h>
@@ -123,6 +124,7 @@ struct nv_context
 	int profiling;
 	std::vector<ProfRecord>* prof;
 	float* timing; // NV_DEBUG_MODE bit 3: 8 x u64 stamps per wave of the last clustercull
+	size_t timingWaves; // its room, in waves
 	uint32_t variants[NV_VARIANT_SLOTS]; // nv_profile_variants: launches per kernel variant since the last read
 };
 
@@ -880,8 +882,16 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	a.debugMode = ctx->debugMode;
 	if (ctx->debugMode & (8u | 268435456u)) // bit 3: the cull launch's wave stamps; bit 28: the occlusion stage's phase sums
 	{
-		if (!ctx->timing)
-			(void)scratch_alloc(&ctx->timing, (size_t)persistent_grid(ctx, 8) * 4 * 8 * sizeof(unsigned long long)); // (room for any NV_OPT_CULL_WORKGROUPS_PER_CU)
+		// room for the cull launch at any NV_OPT_CULL_WORKGROUPS_PER_CU (4 waves per workgroup) AND for the occlusion stage's grid (bit 28:
+		// listSharers x CC_LISTS blocks of 4 waves — more than the cull launch's on a small part or with NV_HIZ_SHARERS raised)
+		const size_t timingWaves = std::max((size_t)persistent_grid(ctx, 8) * 4, (size_t)ctx->listSharers * nv::CC_LISTS * 4);
+		if (ctx->timing && ctx->timingWaves < timingWaves)
+		{
+			scratch_free(ctx->timing);
+			ctx->timing = nullptr;
+		}
+		if (!ctx->timing && scratch_alloc(&ctx->timing, timingWaves * 8 * sizeof(unsigned long long)) == hipSuccess)
+			ctx->timingWaves = timingWaves;
 		a.probeOut = ctx->timing;
 	}
 #endif
@@ -1084,7 +1094,7 @@ int nv_debug_read_timing(nv_context* ctx, unsigned long long* out, uint32_t maxW
 {
 	if (!ctx || !ctx->timing || !out)
 		return NV_EINVAL;
-	uint32_t waves = persistent_grid(ctx, ctx->ccBlocksPerCU) * 4;
+	uint32_t waves = (uint32_t)ctx->timingWaves; // (the caller says how many it wants: the cull launch's, or the occlusion stage's)
 	if (waves > maxWaves)
 		waves = maxWaves;
 	return (int)hipMemcpy(out, ctx->timing, (size_t)waves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
