@@ -211,14 +211,17 @@ __global__ __launch_bounds__(256) void reduce_chain_kernel(ChainArgs a)
 // one 16-B load per lane and row (1 KiB contiguous per wave-instruction), and reduces 4 x 8 -> 2 x 4 -> 1 x 2 in
 // registers; level +2 pairs neighbouring lanes with a DPP shuffle, levels +3 and +4 pair the workgroup's four waves
 // (32 source rows) through 512 B of LDS.  Five levels per launch, every store a contiguous run.
-__global__ __launch_bounds__(256) void reduce_rows_kernel(ChainArgs a)
+// WAVES = 8 (round 5): 64 source rows per workgroup and a SIXTH level, so that the single-workgroup tail launch behind it starts
+// from a 64 x 64 level (16 KB) instead of 128 x 128 (64 KB) and has one LDS stage less.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void reduce_rows_kernel(ChainArgs a)
 {
-	__shared__ float s_l2[4][32];
+	__shared__ float s_l2[WAVES][32];
 
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint32_t L = a.firstLevel;
 	const uint32_t col0 = blockIdx.x * 256u + lane * 4u; // source column of this lane
-	const uint32_t row0 = blockIdx.y * 32u + wave * 8u;  // first source row of this wave
+	const uint32_t row0 = blockIdx.y * (WAVES * 8u) + wave * 8u;  // first source row of this wave
 
 	// the depth target is read once: non-temporal loads, which leave the caches to the pyramid the late passes probe (round 4: the two launches
 	// 29.7-29.8 -> 27.7-27.9 us by events, the frame 202.4-203.2 -> 198.0-200.2 us — the passes behind the pyramid find more of their data in the L2)
@@ -278,22 +281,32 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(ChainArgs a)
 		return;
 	__syncthreads();
 
-	// levels L+3 (2 x 16 per workgroup) and L+4 (1 x 8): lanes 0..31 of wave 0, lane = y * 16 + x
-	if (threadIdx.x < 32)
+	// levels L+3 (WAVES / 2 x 16 per workgroup), L+4 (WAVES / 4 x 8) and, with eight waves, L+5 (1 x 4): lanes 0 .. 8 WAVES - 1 of wave 0, lane = y * 16 + x.
+	// The four texels of a footprint always enter min4 in the sampler's order (x0,y0) (x1,y0) (x0,y1) (x1,y1).
+	if (threadIdx.x < 8u * WAVES)
 	{
 		const uint32_t x = threadIdx.x & 15u, y = threadIdx.x >> 4;
 		float m = min4(s_l2[2 * y][2 * x], s_l2[2 * y][2 * x + 1], s_l2[2 * y + 1][2 * x], s_l2[2 * y + 1][2 * x + 1]);
 		{
 			const uint32_t lw = a.sw / 16;
-			a.base[a.mipOffset[L + 3] + (size_t)(blockIdx.y * 2 + y) * lw + blockIdx.x * 16 + x] = m;
+			a.base[a.mipOffset[L + 3] + (size_t)(blockIdx.y * (WAVES / 2) + y) * lw + blockIdx.x * 16 + x] = m;
 		}
 		if (a.numLevels >= 5)
 		{
-			m = min4(m, __shfl_xor(m, 1, 64), __shfl_xor(m, 16, 64), __shfl_xor(m, 17, 64)); // meaningful on lanes y == 0, x even
-			if (y == 0 && (x & 1u) == 0)
+			m = min4(m, __shfl_xor(m, 1, 64), __shfl_xor(m, 16, 64), __shfl_xor(m, 17, 64)); // meaningful on lanes with y and x even
+			if ((y & 1u) == 0 && (x & 1u) == 0)
 			{
 				const uint32_t lw = a.sw / 32;
-				a.base[a.mipOffset[L + 4] + (size_t)blockIdx.y * lw + blockIdx.x * 8 + x / 2] = m;
+				a.base[a.mipOffset[L + 4] + (size_t)(blockIdx.y * (WAVES / 4) + y / 2) * lw + blockIdx.x * 8 + x / 2] = m;
+			}
+			if (WAVES == 8 && a.numLevels >= 6)
+			{
+				m = min4(m, __shfl_xor(m, 2, 64), __shfl_xor(m, 32, 64), __shfl_xor(m, 34, 64)); // meaningful on lanes with y == 0 and x a multiple of 4
+				if (y == 0 && (x & 3u) == 0)
+				{
+					const uint32_t lw = a.sw / 64;
+					a.base[a.mipOffset[L + 5] + (size_t)blockIdx.y * lw + blockIdx.x * 4 + x / 4] = m;
+				}
 			}
 		}
 	}
@@ -336,10 +349,16 @@ int launch_depthreduce(hipStream_t stream, const float* depth, uint32_t w, uint3
 		// big sources: row-coalesced five-level stage (needs whole 256 x 32 source tiles and exact halving down to its
 		// last level); everything else: the seven-level 128 x 128 tile chain
 		const bool rows = sw % 256 == 0 && sh % 32 == 0 && sw == 2 * lw && sh == 2 * lh && sw >= 512 && sh >= 64 && pyr.levels - L >= 5;
-		if (rows)
+		const bool rows6 = rows && sh % 64 == 0 && pyr.levels - L >= 6; // 256 x 64 source tiles, six levels
+		if (rows6)
+		{
+			a.numLevels = 6;
+			hipLaunchKernelGGL(reduce_rows_kernel<8>, dim3(sw / 256, sh / 64), dim3(512), 0, stream, a);
+		}
+		else if (rows)
 		{
 			a.numLevels = 5;
-			hipLaunchKernelGGL(reduce_rows_kernel, dim3(sw / 256, sh / 32), dim3(256), 0, stream, a);
+			hipLaunchKernelGGL(reduce_rows_kernel<4>, dim3(sw / 256, sh / 32), dim3(256), 0, stream, a);
 		}
 		else
 		{
