@@ -24,6 +24,17 @@ from niagara_amd import pipeline as P  # noqa: E402
 HBM = 8000.0
 
 
+def valu_roofline(kernel, measured_us):
+    """the vector-issue roofline of an issue-bound kernel next to its HBM figure (tools/valu_roofline.py; None while no
+    profiles/rNN_valu_counters.json is committed or hipcc is not at hand)"""
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import valu_roofline as V
+        return V.roofline_valu(kernel, measured_us)
+    except Exception as e:  # noqa: BLE001 — a reporting aid must not fail a measurement
+        return {"error": str(e)[:200]}
+
+
 def timed(ctx, fn, iters, slot):
     """(wall time per call in us with NO event brackets between the launches, average of the library's own event pair for
     `slot` in us, all slots); the wall time of the instrumented loop — every event record is a barrier packet and costs a few
@@ -112,7 +123,8 @@ def config2(ctx, iters, n_draws=1_000_000, copies=6, soa=True, fused_reset=False
             and (dvbs[(iters - 1) % copies].cpu().numpy().view(np.uint32) == dvo).all())
     algo = n_draws * 52 + v * 24 + 208 + 4
     return dict(config="2: 1M draws, drawcull<0,0>" + ("" if soa else " (AoS records in place)") + (" (count reset fused)" if fused_reset else ""), draws=n_draws, visible=v, kernel_us=k_us, step_us=wall, step_us_with_events=prof["wall_with_events_us"], draws_per_s=n_draws / (k_us * 1e-6),
-                algorithmic_bytes=algo, achieved_GBs=algo / k_us / 1e3, frac=algo / k_us / 1e3 / HBM, parity=verdict(same))
+                algorithmic_bytes=algo, achieved_GBs=algo / k_us / 1e3, frac=algo / k_us / 1e3 / HBM, parity=verdict(same),
+                **({"roofline_valu": {"draw_decide_kernel": valu_roofline("draw_decide_kernel", k_us)}} if soa and not fused_reset else {}))
 
 
 def config2_late(ctx, iters, n_draws=1_000_000, copies=6, size=2048):
@@ -489,6 +501,8 @@ def config_frame(ctx, iters, n_draws=1_000_000, lod0=2200, size=4096, copies=3, 
                algorithmic_bytes=algo, algorithmic_bytes_by_pass=bytes_, achieved_GBs=algo / frame_us / 1e3, frac=algo / frame_us / 1e3 / HBM,
                meshlets_tested_per_frame=tested, meshlets_per_s=tested / (frame_us * 1e-6), draws_per_s=2 * n_draws / (frame_us * 1e-6),
                frames_per_s=1e6 / frame_us, oracle_frames_simulated=simulated, frames_on_checked_copy=frames_of[c], parity=verdict(same))
+    out["roofline_valu"] = {"cluster_hiz_kernel": valu_roofline("cluster_hiz_kernel", breakdown["late_cluster_hiz_us"]),
+                            "late cull launch (direct form, frustum / cone ballots)": valu_roofline("cluster_mask_kernel<false, true, false, 8, true, true>", breakdown["late_cluster_cull_us"])}
     if cpp_driver:
         out["cpp_driver"] = frame_driver_timed(meshes, meshlets, draws, slots, depth_h, cd, size, fused, iters)
     ctx.set_option(P.NV_OPT_FUSED_COUNT_RESET, 0)
@@ -576,7 +590,8 @@ def config_n4(ctx, iters, n_draws=2048, cpd=1):
     oracle.trianglecull(g, commands, draws, meshlets, data, vertices, cib_h, ccb.cpu().numpy().view(np.uint32), mo, to)
     same = masks.cpu().numpy().tobytes() == mo.tobytes() and [int(x) for x in t] == [int(x) for x in to]
     return dict(config="N4: mesh-stage triangle cull, %d clusters" % m, clusters=int(t[0]), triangles=int(t[1]), kept=int(t[2]), call_us=us,
-                algorithmic_bytes=algo, achieved_GBs=algo / us / 1e3, frac=algo / us / 1e3 / HBM, triangles_per_s=int(t[1]) / (us * 1e-6), parity=verdict(same))
+                algorithmic_bytes=algo, achieved_GBs=algo / us / 1e3, frac=algo / us / 1e3 / HBM, triangles_per_s=int(t[1]) / (us * 1e-6), parity=verdict(same),
+                roofline_valu={"trianglecull_kernel": valu_roofline("trianglecull_kernel", us)})
 
 
 def cluster_config(ctx, iters, label, n_draws=156250, cpd=10, aos=False, scene_radius=300.0, backface=1, copies=1, cam_pos=(0, 0, 0)):
