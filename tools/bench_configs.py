@@ -124,7 +124,7 @@ def config2(ctx, iters, n_draws=1_000_000, copies=6, soa=True, fused_reset=False
     algo = n_draws * 52 + v * 24 + 208 + 4
     return dict(config="2: 1M draws, drawcull<0,0>" + ("" if soa else " (AoS records in place)") + (" (count reset fused)" if fused_reset else ""), draws=n_draws, visible=v, kernel_us=k_us, step_us=wall, step_us_with_events=prof["wall_with_events_us"], draws_per_s=n_draws / (k_us * 1e-6),
                 algorithmic_bytes=algo, achieved_GBs=algo / k_us / 1e3, frac=algo / k_us / 1e3 / HBM, parity=verdict(same),
-                **({"roofline_valu": {"draw_decide_kernel": valu_roofline("draw_decide_kernel", k_us)}} if soa and not fused_reset else {}))
+                **({"roofline_valu": {"draw_decide_kernel (measured_us = the decide AND the scatter launch)": valu_roofline("draw_decide_kernel", k_us)}} if soa and not fused_reset else {}))
 
 
 def config2_late(ctx, iters, n_draws=1_000_000, copies=6, size=2048):
