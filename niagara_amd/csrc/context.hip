@@ -773,7 +773,7 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 	// emitting draw, the per-draw form otherwise (and until a pass has been seen); NV_OPT_TASK_EMIT pins it
 	a.taskList = ctx->forceTaskList >= 0 ? (uint32_t)ctx->forceTaskList : (ctx->hintHost && ctx->hintHost[3] > 4u * ctx->hintHost[2] ? 1u : 0u);
 	// LDS-staged coarse pyramid levels for the late pass's HiZ probes: measured slower than reading them through L2 (a
-	// workgroup of 512 draws stages 22 KiB to serve the ~20 probes of its visible draws) — off unless asked for
+	// workgroup of 512 draws stages 22 KiB to serve the ~20 probes of its visible draws; EXPERIMENTS.md (B) §4.3) — off unless asked for
 	a.stagedBase = ~0u;
 #ifdef NV_EXPERIMENTS
 	if (late && ctx->hizLds && pyramid && pyramid->levels)

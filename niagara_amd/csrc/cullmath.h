@@ -252,7 +252,7 @@ NV_DEV float sample_min(const NvPyramidDesc& p, float u, float v, float level)
 // texel offsets relative to the pyramid base; hiz_finish: MIN over the texels that carry weight, in the oracle's order
 // (x0,y0) (x1,y0) (x0,y1) (x1,y1), and the comparison.  Offsets are always in range (clamped), also for an inactive probe.
 //
-// Round 4: the stage that runs these is bound by VALU issue (6.9 M probes x 348 instructions at frame scale, DESIGN.md §4.1b), and
+// Round 4: the stage that runs these is bound by VALU issue (6.9 M probes x 348 instructions at frame scale, DESIGN.md §4.2), and
 // 140 of the 348 were not the reference's arithmetic but the selection logic around it.  Three restatements of that logic, none of
 // which touches a floating-point operation of the reference:
 //   * a texel WITHOUT weight is not flagged and skipped in hiz_finish — its offset is replaced by the offset of the texel of the
