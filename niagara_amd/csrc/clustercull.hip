@@ -792,26 +792,18 @@ NV_DEV uint32_t segment_chunk(uint32_t chunkOf, uint32_t s)
 
 NV_DEV uint32_t deal_wave(const DealPlan& p, uint32_t w, uint32_t lane, uint32_t gen, uint32_t genWaves, uint32_t* chunkOf)
 {
-	const uint32_t W = p.waves;
 	if (!p.weighted)
 	{
-		*chunkOf = lane * W + w;
-		return p.perWaveChunks + (w < p.evenRem ? 1u : 0u);
+		*chunkOf = deal_wave_entry(p, w, 0u, genWaves, lane);
+		return deal_wave_chunks(p, w, gen);
 	}
-	const uint32_t g = gen < 6u ? gen : 5u;
-	const uint32_t rounds = p.rounds[0] * (g == 0) + p.rounds[1] * (g == 1) + p.rounds[2] * (g == 2) + p.rounds[3] * (g == 3) + p.rounds[4] * (g == 4) + p.rounds[5] * (g == 5);
-	// table entry j: round j of the weighted part (chunks of earlier rounds = genWaves * sum over generations of min(j, rounds)), then the even
-	// remainder.  Entry j lives in lane ((j & 15) << 2) | (j >> 4): the lanes of a segment's quad q all want entry 16 s + q (s = the segment's
+	// table entry j lives in lane ((j & 15) << 2) | (j >> 4): the lanes of a segment's quad q all want entry 16 s + q (s = the segment's
 	// number, four commands per chunk), which is lane s of their own quad — one DPP quad broadcast (segment_chunk) where a table in lane order
-	// needed a ds_bpermute_b32 round trip through LDS on every wave's start-up path.
+	// needed a ds_bpermute_b32 round trip through LDS on every wave's start-up path.  The arithmetic is dealing.h's (tests/test_dealing.py).
 	static_assert(CC_CHUNK == 4, "the chunk table's quad layout");
 	const uint32_t j = (lane >> 2) + 16u * (lane & 3u);
-	uint32_t before = 0;
-#pragma unroll
-	for (int k = 0; k < 6; ++k)
-		before += j < p.rounds[k] ? j : p.rounds[k];
-	*chunkOf = j < rounds ? before * genWaves + w : p.weightedTotal + w + (j - rounds) * W;
-	return rounds + p.restPerWave + (w < p.restRem ? 1u : 0u);
+	*chunkOf = deal_wave_entry(p, w, deal_wave_rounds(p, gen), genWaves, j);
+	return deal_wave_chunks(p, w, gen);
 }
 
 // DIRECT (SoA mirror only): no pass A — every valid command goes straight to pass B, bounds and cone read once.  The

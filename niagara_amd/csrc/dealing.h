@@ -125,4 +125,31 @@ NV_DP DealPlan deal_plan(uint32_t numCmds, uint32_t chunk, bool weightedWanted, 
 	return p;
 }
 
+// ---- the per-wave part (clustercull.hip deal_wave; host-compilable so that tests/test_dealing.py can hold the whole dealing — every chunk to
+// exactly one wave — on the CPU).  Wave w of generation gen (workgroup index / genBlocks; genWaves = genBlocks x 4):
+// its number of chunks, and the chunk its j-th table entry names (j < 64 when the plan is weighted; plain round-robin otherwise).
+NV_DP uint32_t deal_wave_rounds(const DealPlan& p, uint32_t gen)
+{
+	const uint32_t g = gen < 6u ? gen : 5u;
+	return p.rounds[0] * (g == 0) + p.rounds[1] * (g == 1) + p.rounds[2] * (g == 2) + p.rounds[3] * (g == 3) + p.rounds[4] * (g == 4) + p.rounds[5] * (g == 5);
+}
+
+NV_DP uint32_t deal_wave_chunks(const DealPlan& p, uint32_t w, uint32_t gen)
+{
+	return p.weighted ? deal_wave_rounds(p, gen) + p.restPerWave + (w < p.restRem ? 1u : 0u) : p.perWaveChunks + (w < p.evenRem ? 1u : 0u);
+}
+
+// entry j of wave w's chunk table: round j of the weighted part (chunks of earlier rounds = genWaves x the sum over generations of min(j, rounds)),
+// then the even remainder
+NV_DP uint32_t deal_wave_entry(const DealPlan& p, uint32_t w, uint32_t rounds, uint32_t genWaves, uint32_t j)
+{
+	if (!p.weighted)
+		return j * p.waves + w;
+	uint32_t before = 0;
+#pragma unroll
+	for (int k = 0; k < 6; ++k)
+		before += j < p.rounds[k] ? j : p.rounds[k];
+	return j < rounds ? before * genWaves + w : p.weightedTotal + w + (j - rounds) * p.waves;
+}
+
 } // namespace nv

@@ -205,3 +205,36 @@ def test_profile_variants_name_the_form_each_launch_took():
         assert ctx.profile_variants() == {"cull_aos": 1} and ctx.profile_variants() == {}
     finally:
         ctx.close()
+
+
+def test_a_fresh_contexts_first_frame_takes_the_direct_forms_for_its_own_drawculls_commands():
+    """No launch has left a filter statistic yet: a cluster pass over the command buffer THIS context's nv_drawcull(task) wrote runs on the commands of
+    draws the draw-level cull already found visible, and takes the direct / lane forms instead of the filter form (context.hip taskCommandsFrom; VERDICT r4
+    item 3c: a renderer's first frames hitched through the filter form).  A pre-built command list on a fresh context keeps the filter form.  Results
+    are the oracle's either way."""
+    import passes
+    from gpu_passes import run_frames
+    scene = make_scene(seed=31, n_draws=1200, meshlets_lod0=130)
+    flags = (1, 1, 1, 1, 1)
+    fo = passes.run_frames(oracle, scene, flags, frames=2)
+    ctx = P.Context()
+    try:
+        fg = run_frames(ctx, scene, flags, frames=1)
+        v = ctx.profile_variants()
+        # frame 0: the early cluster pass is the context's first cluster launch ever
+        assert v.get("cull_direct", 0) + v.get("cull_lanes_bits", 0) + v.get("cull_lanes", 0) >= 1, v
+        for phase in ("early", "late"):
+            for key in ("count4", "commands", "cc4", "cib", "dvb", "mvb"):
+                assert fo[0][phase][key].tobytes() == fg[0][phase][key].tobytes(), (phase, key)
+    finally:
+        ctx.close()
+    # a command list that did not come from this context's drawcull: no statistic, no provenance — the filter form
+    ctx = P.Context()
+    try:
+        draws, meshlets, commands, n = _instanced_scene(300, 5, 200)
+        cd = host.build_cull_data(cam_pos=(0, 0, 25), draw_count=len(draws), cullingEnabled=1, clusterBackfaceEnabled=1)
+        _Pass(ctx, draws, meshlets, commands, n).run(cd, 0, None)
+        v = ctx.profile_variants()
+        assert v.get("cull_filter_ring4", 0) + v.get("cull_filter_ring8", 0) == 1 and "cull_direct" not in v, v
+    finally:
+        ctx.close()
