@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--overlap-streams", type=int, default=3, help="streams of the `throughput_overlapped` side leg (N = 1 only; 0 = skip it)")
     ap.add_argument("--scatter-waves", type=int, default=0, help="NV_OPT_SCATTER_WAVES (4, 8 or 16) of the timed region; 0 = 16 with one stream, 8 with several")
     ap.add_argument("--no-contract-chain", action="store_true", help="skip the `contract_chain` side field (N = 1 with the CPU baseline only)")
+    ap.add_argument("--no-frame", action="store_true", help="skip the `frame` side field (N = 1 with the CPU baseline only)")
+    ap.add_argument("--frame-iters", type=int, default=30, help="frames timed for the `frame` side field")
     ap.add_argument("--dump-ids", default="", help="directory: every rank saves the visible-ID list of its last profiled pass, rebased to pool-wide command "
                                                    "indices (shard.to_global_ids), as ids_<rank>.npy — tests/test_distributed_gpu.py concatenates them")
     ap.add_argument("--explicit-reset", action="store_true",
@@ -104,8 +106,30 @@ def make_inputs(args, rank, world):
     return draws, meshlets, cd, (b, e), total_cmd
 
 
+def self_launch_command(gpus, argv, port=None):
+    """the command `python bench.py --gpus N ...` re-executes itself as when no launcher started it (WORLD_SIZE unset): the task contract's
+    own launcher line — one rank per GPU under torch.distributed.run on this node, rendezvous on 127.0.0.1 (the container's hostname may not
+    resolve) at a free port — with the caller's arguments unchanged."""
+    if port is None:
+        import socket
+        s0 = socket.socket()
+        s0.bind(("127.0.0.1", 0))
+        port = s0.getsockname()[1]
+        s0.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+            os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # VERDICT r5 item 1: the driver's command is `python3 bench.py --gpus N --steps S --warmup W` with no launcher in front.  Start the N
+        # ranks here; rank 0 of the child job prints the ONE JSON line on this process's stdout, and its exit status becomes this one's.
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))  # (the per-rank oracle checks share the host; torchrun would set 1)
+        raise SystemExit(subprocess.call(self_launch_command(args.gpus, sys.argv[1:]), env=env))
     import torch
     import torch.distributed as dist
 
@@ -231,6 +255,10 @@ def main():
     s_last = (args.steps - 1) % S
     last_counts = reds[s_last].last(passes_of(s_last, args.steps))
     visible_by_stream = [int(c[0].item()) for c in ccbs[:S]]
+    # the visible-ID list the TIMED loop's last pass left, copied out before the profiled loop below writes the same buffer:
+    # this is the list the oracle check further down holds
+    timed_visible = visible_by_stream[s_last]
+    timed_ids = cibs[s_last][:min(timed_visible, L.CLUSTER_LIMIT)].cpu().numpy().view(np.uint32).copy()
 
     # ---- roofline leg: the same passes again with the library's HIP events bracketing each kernel on the launch stream
     # (nv_profile_*), one pass after the other on ONE stream — the mode `value` is measured in when --streams is 1.  It is a
@@ -271,8 +299,13 @@ def main():
     ctx.profile(False)
     ctx.status()
 
-    visible = int(ccb[0].item())
-    visible_ids = cib[:min(visible, L.CLUSTER_LIMIT)].cpu().numpy().view(np.uint32)  # the list the profiled run's last pass left: checked against the oracle below
+    # the profiled loop's last pass ran the same code on the same pool (the rotated copies hold the same records): its list must be the timed loop's,
+    # which is the one checked against the oracle below
+    profiled_visible = int(ccb[0].item())
+    profiled_ids = cib[:min(profiled_visible, L.CLUSTER_LIMIT)].cpu().numpy().view(np.uint32)
+    if profiled_visible != timed_visible or profiled_ids.tobytes() != timed_ids.tobytes():
+        raise SystemExit("rank %d: the profiled loop's visible-ID list differs from the timed loop's (%d against %d IDs)" % (rank, profiled_visible, timed_visible))
+    visible, visible_ids = timed_visible, timed_ids
     if args.dump_ids:
         np.save(os.path.join(args.dump_ids, "ids_%d.npy" % rank), shard.to_global_ids(visible_ids, cmd_b))
 
@@ -386,7 +419,7 @@ def main():
         if rank == 0:
             out["cpu_baseline"] = cpu_baseline(args, cd, draws, meshlets, cmd_b, cmd_e, visible, visible_ids, world)
             out["parity"] = "bit-identical"
-            out["parity_checked"] = ("visible-ID list and count of the benchmarked pass against the CPU oracle: " +
+            out["parity_checked"] = ("visible-ID list and count of the TIMED loop's last pass (and, identical to it, the profiled loop's) against the CPU oracle: " +
                                      ("the whole batch" if not sharded else "every rank on its own shard, %d of %d ranks agree" % (world, world)))
     elif rank == 0:
         out["parity"] = "not checked (--no-cpu-baseline)"
@@ -395,6 +428,13 @@ def main():
     # process after everything above, with its own parity check of every buffer of the chain.  Never `value`.
     if rank == 0 and not sharded and not args.no_cpu_baseline and not args.no_contract_chain:
         out["contract_chain"] = contract_chain(local_rank)
+    # ---- side field (N = 1): niagara's dependent FRAME at BASELINE scale (src/niagara.cpp:1765-1788: early cull -> pyramid -> late cull, 1 M draws, ~10 M
+    # meshlets per cluster pass, 4096^2 depth), the production-shaped figure, timed by this process and held against the CPU oracle.  Never `value`.
+    if rank == 0 and not sharded and not args.no_cpu_baseline and not args.no_frame:
+        for c in ctxs:  # (the main leg's contexts and their scratch are done)
+            c.close()
+        ctxs = []
+        out["frame"] = frame_field(local_rank, args.frame_iters)
     if rank == 0:
         print(json.dumps(out), flush=True)
 
@@ -402,6 +442,29 @@ def main():
         c.close()
     if sharded:
         dist.destroy_process_group()
+
+
+def frame_field(device_index, iters):
+    """tools/bench_configs.py config_frame (fused: 11 launches per frame), three scene copies rotated so that no frame finds its draws, visibility words or
+    depth target in the Infinity Cache; every buffer of both phases and the pyramid of one more frame against the CPU oracle after the same history
+    (oracle/ only as the checker; a difference is a non-zero exit).  `frac` = SURVEY §8(d)'s algorithmic bytes of the five passes / frame time / 8 TB/s."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs
+    from niagara_amd import pipeline as P
+    ctx = P.Context(device_index)
+    try:
+        r = bench_configs.config_frame(ctx, iters)
+    finally:
+        ctx.close()
+    if r["parity"] != "bit-identical":
+        raise SystemExit("parity failure in the frame: " + str(r["parity"]))
+    keep = ("frame_us", "frac", "achieved_GBs", "algorithmic_bytes", "algorithmic_bytes_by_pass", "sum_of_kernels_us", "kernel_variants", "early", "late", "frames_timed",
+            "scene_copies_rotated", "meshlets_tested_per_frame", "meshlets_per_s", "draws_per_s", "oracle_frames_simulated", "parity", "roofline_valu")
+    f = {"what": r["config"], "regime": "one frame after the other on one stream; per-launch times = the library's HIP event pairs in separate frames"}
+    f.update({k: r[k] for k in keep if k in r})
+    f["launch_us"] = {k[:-3]: r[k] for k in r if k.endswith("_us") and k not in ("frame_us", "sum_of_kernels_us")}
+    f["parity_checked"] = "task commands, count words, visible-ID lists + submit padding, drawVisibility, meshletVisibility of both phases and the pyramid of one frame after the same history"
+    return f
 
 
 def contract_chain(device_index, n_draws=125000, iters=100):
@@ -417,7 +480,20 @@ def contract_chain(device_index, n_draws=125000, iters=100):
         r = bench_configs.config3b(ctx, iters, n_draws=n_draws, fused=True)
     finally:
         ctx.close()
-    return {"what": "BASELINE configs[2] with LOD select: " + r["config"], "draws": r["draws"], "task_commands": r["task_commands"],
+    # drawcull<0,1> reads 48 + 4 B per draw and writes 20 B per command; the cluster pass reads 12 B per meshlet tested + (20 + 48) B per
+    # command, writes 4 B per survivor + the count word
+    N, Cn, M, Vm = r["draws"], r["task_commands"], r["meshlets_tested"], r["visible"]
+    b_draw, b_cluster = 52 * N + 20 * Cn, 12 * M + 68 * Cn + 4 * Vm + 4
+    b_cull_launch = 12 * M + 68 * Cn + 8 * Cn  # (the cull launch alone: + its 8-byte ballot per command, the survivors' 4 B belong to the scatter launch)
+    roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes": b_draw + b_cluster,
+            "per_pass_bytes": {"drawcull": b_draw, "cluster": b_cluster}, "achieved": (b_draw + b_cluster) / r["step_us"] / 1e3,
+            "frac": (b_draw + b_cluster) / r["step_us"] / 1e3 / HBM_PEAK_GBS,
+            "cluster_launches_frac": b_cluster / max(r["cluster_cull_us"] + r["cluster_scatter_us"], 1e-9) / 1e3 / HBM_PEAK_GBS,
+            "cull_launch_frac": b_cull_launch / max(r["cluster_cull_us"], 1e-9) / 1e3 / HBM_PEAK_GBS,
+            "formulas": "drawcull<0,1>: 52 N + 20 C; cluster pass: 12 M + 68 C + 4 Vm + 4 (N draws, C commands, M meshlets tested, Vm visible)"}
+    if r["parity"] != "bit-identical":
+        raise SystemExit("parity failure in the contract chain: " + str(r["parity"]))
+    return {"what": "BASELINE configs[2] with LOD select: " + r["config"], "roofline": roof, "draws": r["draws"], "task_commands": r["task_commands"],
             "meshlets_tested": r["meshlets_tested"], "visible": r["visible"], "us_per_phase": r["step_us"], "meshlets_per_s": r["meshlets_per_s"],
             "drawcull_us": r["drawcull_us"], "cluster_cull_us": r["cluster_cull_us"], "cluster_scatter_us": r["cluster_scatter_us"],
             "options": "NV_OPT_FUSED_COUNT_RESET + NV_OPT_FUSED_SUBMIT (4 launches per phase)", "regime": "one phase after the other on one stream, %d phases" % iters,

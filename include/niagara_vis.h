@@ -272,7 +272,11 @@ int nv_share_scene(nv_context* dst, nv_context* src);
  * records directly otherwise.  The registration is by device pointer and the mirror is a
  * snapshot: call again after the buffer's contents change, and before the allocation is
  * freed or reused for something else — (NULL, 0) drops the registration (likewise for
- * nv_upload_meshes). */
+ * nv_upload_meshes).  A re-upload must be ORDERED against the passes in flight over the old
+ * contents (same stream, or the caller's event): next to the mirror it rewrites the pool's
+ * largest |centre component| / |radius|, which the cull launch's filter margins are derived
+ * from — a pass that pairs new records with the old bounds is no longer conservative (only
+ * the capacity-growth path synchronises the device by itself). */
 int nv_upload_meshlets(nv_context* ctx, void* stream, const NvMeshlet* d_meshlets, uint32_t meshletCount);
 
 /* Upload hook next to uploadBuffer(mb) (src/niagara.cpp:1049): registers the Mesh table's pointer and size.  nv_drawcull

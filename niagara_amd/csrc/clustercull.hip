@@ -411,6 +411,8 @@ NV_DEV float pin_vgpr(float x)
 // frustum[0], f.m[3..5], f.b1 carry frustum[2]), so a side plane's distance is one FMA instead of a multiply and an FMA — 17 instead of 19 instructions
 // per 64 meshlets in a loop that is bound by vector issue.  One more rounding per entry of two of the three chains (relative u each, against the > 2x the
 // margin's K = 48 leaves over the ~21 roundings it counts); tests/test_cert_margins.py holds this very form against the reference in its emulation.
+// The folded distance is the reference's only for NON-NEGATIVE side-plane coefficients (|f0 cx| = f0 |cx| needs f0 >= 0): the kernel switches the filter off
+// otherwise (foldSound, cluster_mask_kernel) — ADVICE r5; tests/test_cert_margins.py shows the folded form over-rejecting with a negated coefficient.
 template <bool FOLD>
 NV_DEV bool certainly_outside(const NvCullData& cd, const FilterUniform& f, uint32_t b0, uint32_t b1)
 {
@@ -961,7 +963,11 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 		// behind them (counted), so the dependent chain is commands -> {draws, first bounds} instead of
 		// commands -> draws -> filters -> first bounds.
 		constexpr bool FOLD_A = !LATE; // (the late variants have no eight VGPRs to spare under the six-workgroup bound)
-		const bool useFilter = a.filterK > 0.0f && !NV_DBG(a, 32u);   // filterK 0: coefficients outside the proven range (host); bit 5 (experiments): every valid command goes to the exact pass
+		// (the folded rows evaluate cz f1 - |f0 cx| = cz f1 - |f0| |cx|, the reference cz f1 - |cx| f0: the same number only for f0, f2 >= 0.  A mirrored
+		// or flipped projection — a negative side-plane coefficient — therefore takes no filter at all in the folded variants: every valid command goes to pass B, whose
+		// certified test and reference arithmetic keep the coefficient's sign.  Written so that a NaN coefficient also fails it.)
+		const bool foldSound = !FOLD_A || filter_fold_sound(a.cd.frustum);
+		const bool useFilter = a.filterK > 0.0f && foldSound && !NV_DBG(a, 32u);   // filterK 0: coefficients outside the proven range (host); bit 5 (experiments): every valid command goes to the exact pass
 		u32x4 g0 = {}, g1 = {};
 		auto gather_issue = [&]()
 		{

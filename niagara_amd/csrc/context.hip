@@ -653,7 +653,10 @@ int nv_upload_meshlets(nv_context* ctx, void* stream, const NvMeshlet* d_meshlet
 		ctx->scene->soaCapacity = padded;
 	}
 	if (!ctx->scene->poolWords && scratch_alloc(&ctx->scene->poolWords, 4 * sizeof(uint32_t)) != hipSuccess)
+	{
+		ctx->scene->mirroredFrom = nullptr; // (no pool bounds: no SoA pass may name the old mirror either)
 		return NV_ENOMEM;
+	}
 	int rc = nv::launch_soa_split((hipStream_t)stream, d_meshlets, meshletCount, padded, ctx->scene->soaBounds, ctx->scene->soaCones, ctx->scene->poolWords);
 	if (rc)
 		return rc;
@@ -828,7 +831,7 @@ static int fill_cluster_args(nv_context* ctx, nv::ClusterArgs& a, const NvCullDa
 	a.count4 = d_count4;
 	a.draws = d_draws;
 	a.meshlets = d_meshlets;
-	const bool soa = ctx->scene->mirroredFrom == d_meshlets && ctx->scene->soaBounds;
+	const bool soa = ctx->scene->mirroredFrom == d_meshlets && ctx->scene->soaBounds && ctx->scene->poolWords; // (poolWords: the SoA kernels read the pool's bounds unconditionally — ADVICE r5)
 	a.soaBounds = soa ? ctx->scene->soaBounds : nullptr;
 	a.soaCones = soa ? ctx->scene->soaCones : nullptr;
 	a.poolBounds = soa ? reinterpret_cast<const float*>(ctx->scene->poolWords + 2) : nullptr;
@@ -906,6 +909,9 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	bool direct = ctx->hintHost && nv::clustercull_prefers_direct(ctx->hintHost[0], ctx->hintHost[1], ctx->directPercent);
 	if (!(ctx->hintHost && ctx->hintHost[0] != 0) && d_commands == ctx->taskCommandsFrom) // no statistic yet: by where the commands come from
 		direct = true;
+	// (the provenance is good for ONE cluster launch: a later list at the same address — a freed and reused buffer, a caller-built list — is not this
+	// context's drawcull output unless another nv_drawcull(task) has written there since)
+	ctx->taskCommandsFrom = nullptr;
 	if (ctx->forceDirect >= 0)
 		direct = ctx->forceDirect != 0;
 	// Late pass with HiZ = three launches: the cull kernel in its early form (frustum + cone ballots), the occlusion probe
@@ -985,6 +991,7 @@ int nv_taskcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 		bool direct = ctx->hintHost && nv::clustercull_prefers_direct(ctx->hintHost[0], ctx->hintHost[1], ctx->directPercent);
 		if (!(ctx->hintHost && ctx->hintHost[0] != 0) && d_commands == ctx->taskCommandsFrom) // (as in nv_clustercull)
 			direct = true;
+		ctx->taskCommandsFrom = nullptr;
 		if (ctx->forceDirect >= 0)
 			direct = ctx->forceDirect != 0;
 		const bool poolInCache = a.soaBounds != nullptr && (uint64_t)ctx->scene->mirroredCount * 12u <= (48ull << 20);

@@ -97,7 +97,10 @@ NV_DP DealPlan deal_plan(uint32_t numCmds, uint32_t chunk, bool weightedWanted, 
 	const uint32_t genWaves = genBlocks * 4u;
 	// delays in 1/16 command: { 0, 0.5, 2.4, 4.2, 7.1, 13.1 }, mean 4.55
 	const int delay16[6] = { 0, 8, 38, 67, 114, 210 };
-	const int perWave16 = (int)deal_div(numChunks * (chunk * 16u), W, wavesMagic); // numChunks < 2^22 / chunk: no overflow, and < 2^39 / W
+	// The dividend through the magic must stay below 2^39 / W (deal_div).  HERE perWaveChunks < 60, so numChunks < 61 W and the dividend is below
+	// 61 W x 16 chunk = 3904 W for the chunk of 4 both passes use; 3904 W < 2^39 / W for W < 11 866 — and deal_magic offers a magic up to W = 8192 only
+	// (tests/test_dealing.py holds host plan == wave-derived plan at that largest grid, at the largest counts that reach this line).
+	const int perWave16 = (int)deal_div(numChunks * (chunk * 16u), W, wavesMagic);
 	uint32_t rounds[6], weightedTotal = 0;
 #pragma unroll
 	for (int k = 0; k < 6; ++k)

@@ -58,6 +58,12 @@ NV_FM float filter_k(const float frustum[4], float znear, float zfar)
 	return finite ? 4.0f * FILTER_K * FILTER_U * FILTER_SLACK * S : 0.0f;
 }
 
+// The early pass's filter loop evaluates a side plane's distance with the plane's coefficient folded into the row (clustercull.hip certainly_outside<FOLD>):
+// cz f1 - |f0 cx| = cz f1 - |f0| |cx|, where the reference (clustercull.comp.glsl:104-105) computes cz f1 - |cx| f0.  The two agree only for f0, f2 >= 0; for
+// a negative coefficient (a mirrored / flipped projection) the folded distance is too small by 2 |f0| |cx| and the filter would reject what the reference
+// keeps.  The folded variants therefore run without the filter unless this holds; false on NaN.
+NV_FM bool filter_fold_sound(const float frustum[4]) { return frustum[0] >= 0.0f && frustum[2] >= 0.0f; }
+
 // the view-only terms of filter_make: Vn = max over rows r of |V(r,0)| + |V(r,1)| + |V(r,2)|, V3n = max_r |V(r,3)|, sumV = the sum of the
 // twelve entries (0 x it is 0, or NaN for a non-finite view).  V column-major: V(r,k) = V[4k + r].
 NV_FM void filter_view_norms(const float* V, float* Vn_, float* V3n_, float* sumV_)

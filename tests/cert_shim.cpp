@@ -17,6 +17,8 @@ void shim_constants(float out[12])
 
 float shim_filter_k(const float frustum[4], float znear, float zfar) { return nv::filter_k(frustum, znear, zfar); }
 
+int shim_fold_sound(const float frustum[4]) { return nv::filter_fold_sound(frustum) ? 1 : 0; }
+
 void shim_view_norms(const float view[16], float out[3]) { nv::filter_view_norms(view, &out[0], &out[1], &out[2]); }
 
 // draws: n x {position.xyz, scale, orientation.xyzw} (the first 32 bytes of a MeshDraw, stride in floats); out: n x 19 floats

@@ -74,3 +74,18 @@ def test_scanner_flags_a_counted_wait_that_is_too_weak():
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
 def test_clustercull_asm_blocks_are_guarded():
     assert chk.main() == 0
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
+def test_dpp_scans_refuse_a_non_gfx9_target(tmp_path):
+    """VERDICT r5 item 8 / ADVICE r4: args.h's DPP scans (row_bcast:15 / 31, wave_shr:1) exist on GFX9-family wave64 parts only.  Compiled for
+    another target (gfx1100) the header must stop the build with its own #error text — not compile silently into something else; for gfx950 the same
+    translation unit compiles."""
+    import subprocess
+    src = tmp_path / "tu.hip"
+    src.write_text('#include "%s"\n#include "%s"\n' % (os.path.join(ROOT, "niagara_amd", "csrc", "cullmath.h"), os.path.join(ROOT, "niagara_amd", "csrc", "args.h")))
+    bad = subprocess.run(["hipcc", "--offload-arch=gfx1100", "-std=c++17", "-c", str(src), "-o", str(tmp_path / "bad.o")], capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0
+    assert "args.h: the DPP scans are written for GFX9-family wave64 targets (gfx950)" in bad.stderr
+    good = subprocess.run(["hipcc", "--offload-arch=gfx950", "-std=c++17", "-c", str(src), "-o", str(tmp_path / "good.o")], capture_output=True, text=True, timeout=300)
+    assert good.returncode == 0, good.stderr[-2000:]

@@ -35,6 +35,8 @@ def shim(tmp_path_factory):
     lib = C.CDLL(so)
     lib.shim_filter_k.restype = C.c_float
     lib.shim_filter_k.argtypes = [C.c_void_p, C.c_float, C.c_float]
+    lib.shim_fold_sound.restype = C.c_int
+    lib.shim_fold_sound.argtypes = [C.c_void_p]
     lib.shim_make_filters.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_float, C.c_float, C.c_float, C.c_void_p]
     return lib
 
@@ -215,6 +217,56 @@ def test_margins_cover_the_distance_to_the_reference(shim, case):
             assert cull_ref[ci, li]
         if De < -Tce:
             assert not cull_ref[ci, li]
+
+
+@pytest.mark.parametrize("signs", [(-1, 1), (1, -1), (-1, -1)], ids=["f0<0", "f2<0", "both<0"])
+def test_negative_side_plane_coefficients(shim, signs):
+    """CullData.frustum may hold anything (a mirrored / flipped projection negates a side plane's coefficient).  The reference
+    computes cz f1 - |cx| f0 with the coefficient's sign; pass B's forms (certified_visible, the unfolded filter) do the same and stay sound; the FOLDED
+    filter of the early pass's loop computes cz f1 - |f0 cx| and would reject clusters the reference keeps — which is why filtermath.h
+    filter_fold_sound switches the filter off for such input (cluster_mask_kernel: foldSound)."""
+    draws, meshlets, commands, cd = scene(300.0, 1.0, 1.0, (0, 0, 0), (0, 0, 0, 1), n_draws=400, cpd=2, seed=11)
+    fr = cd["frustum"][0].astype(f32).copy()
+    assert shim.shim_fold_sound(np.ascontiguousarray(fr).ctypes.data) == 1
+    fr[0] *= f32(signs[0])
+    fr[2] *= f32(signs[1])
+    cd = cd.copy()
+    cd["frustum"][0] = fr
+    assert shim.shim_fold_sound(np.ascontiguousarray(fr).ctypes.data) == 0
+    for special in (np.array([np.nan, 1, 1, 1], f32), np.array([1, 1, np.nan, 1], f32), np.array([-0.0, 0, 0.5, 0], f32)):
+        assert shim.shim_fold_sound(special.ctypes.data) == (0 if np.isnan(special).any() else 1)  # (-0.0 >= 0: the product is the reference's, a signed zero)
+    probe = oracle.probe_cluster_scalars(cd, commands, draws, meshlets)
+    filterK, F = filters_of(shim, cd, draws, *pool_bounds(meshlets))
+    assert filterK > 0  # (|f| is what filter_k looks at: the filter stays on as far as the host is concerned)
+    d = commands["drawId"]
+    ml = meshlets[commands["taskOffset"][:, None] + np.arange(64, dtype=np.uint32)[None, :]]
+    v = ml["center"].view(np.float16).astype(f32)
+    rad = ml["radius"].view(np.float16).astype(f32)
+    Fd = F[d][:, None, :] + 0 * rad[..., None]
+    m, b, aK, bK, aR, scale, tK = Fd[..., 0:9], Fd[..., 9:12], Fd[..., 12], Fd[..., 13], Fd[..., 14], Fd[..., 15], Fd[..., 18]
+    c = np.stack([fma64(m[..., 3 * r], v[..., 0], fma64(m[..., 3 * r + 1], v[..., 1], fma64(m[..., 3 * r + 2], v[..., 2], b[..., r]))) for r in range(3)], axis=-1)
+    T = fma64(aR, np.abs(rad), fma64(aK, np.abs(v[..., 2]), fma64(aK, np.abs(v[..., 1]), fma64(aK, np.abs(v[..., 0]), bK))))
+    ok = np.isfinite(probe[..., 0:3]).all(axis=-1) & np.isfinite(T)
+    znear, zfar = f32(cd["znear"][0]), f32(cd["zfar"][0])
+    g1 = fma64(c[..., 2], fr[1], -(np.abs(c[..., 0]) * fr[0]).astype(f32))
+    g2 = fma64(c[..., 2], fr[3], -(np.abs(c[..., 1]) * fr[2]).astype(f32))
+    g = np.minimum(np.minimum(g1, g2), np.minimum(c[..., 2] - znear, zfar - c[..., 2]))
+    vis_ref = probe[..., 14] != 0
+    assert vis_ref.sum() > 1000
+    # the forms that keep the sign: sound in both directions
+    out_m, in_m = g < -fma64(scale, rad, T), g > -fma64(scale, rad, -T)
+    assert not (ok & out_m & vis_ref).any() and not (ok & in_m & ~vis_ref).any()
+    assert not (ok & (g < -fma64(scale, rad, tK)) & vis_ref).any()
+    # the folded form: rejects what the reference keeps
+    ms, bs = m.copy(), b.copy()
+    ms[..., 0:3] = (fr[0] * m[..., 0:3]).astype(f32)
+    ms[..., 3:6] = (fr[2] * m[..., 3:6]).astype(f32)
+    bs[..., 0] = (fr[0] * b[..., 0]).astype(f32)
+    bs[..., 1] = (fr[2] * b[..., 1]).astype(f32)
+    cs = np.stack([fma64(ms[..., 3 * r], v[..., 0], fma64(ms[..., 3 * r + 1], v[..., 1], fma64(ms[..., 3 * r + 2], v[..., 2], bs[..., r]))) for r in range(3)], axis=-1)
+    gs = np.minimum(np.minimum(fma64(cs[..., 2], fr[1], -np.abs(cs[..., 0])), fma64(cs[..., 2], fr[3], -np.abs(cs[..., 1]))), np.minimum(cs[..., 2] - znear, zfar - cs[..., 2]))
+    wrong = ok & (gs < -fma64(scale, rad, tK)) & vis_ref
+    assert wrong.sum() > 100, "the folded form no longer over-rejects with a negated coefficient: is the guard still needed?"
 
 
 def test_unsound_inputs_make_nothing_certain(shim):

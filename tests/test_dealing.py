@@ -78,6 +78,29 @@ def test_the_hosts_plan_is_the_plan_a_wave_derives(shim):
             assert (a == b).all(), (n, scale, a, b)
 
 
+def test_the_largest_grid_the_magic_is_offered_for(shim):
+    """deal_magic is enabled up to a divisor of 8192 waves (a grid of 2048 workgroups), exact for dividends below 2^39 / 8192 = 67.1 M.  The
+    weighted branch divides numChunks x 64 — but only for passes of fewer than 60 chunks per wave (below 3904 W = 32 M at W = 8192), the plain branch
+    divides at most 2^22 chunks: host plan (magic) and wave-derived plan (plain division) agree over the whole range of counts at that grid, and every
+    chunk still goes to exactly one wave."""
+    grid = 2046  # (six generations of 341 workgroups: the largest weighted shape under the magic's limit of 8192 waves)
+    W = grid * 4
+    assert W <= 8192 < (grid + 6) * 4
+    rng = np.random.default_rng(7)
+    edge = [40 * W * 4, 59 * W * 4 - 1, 59 * W * 4, 60 * W * 4 - 4, 60 * W * 4 - 1, 60 * W * 4, 60 * W * 4 + 1, 61 * W * 4, 65535 * 64, 65535 * 64 - 1, 4 * W * 4, 4 * W * 4 - 1]
+    for n in edge + [int(x) for x in rng.integers(1, 65535 * 64, 300)]:
+        for scale in (100, 70, 130):
+            a, b = plan_of(shim, n, grid=grid, scale=scale, magic=1), plan_of(shim, n, grid=grid, scale=scale, magic=0)
+            assert (a == b).all(), (n, scale)
+    assert field(plan_of(shim, 40 * W * 4, grid=grid), "weighted") == 1  # (this shape does reach the weighted division)
+    for n in (40 * W * 4, 59 * W * 4, 60 * W * 4 - 1, 65535 * 64):
+        plan = plan_of(shim, n, grid=grid)
+        chunks = (n + 3) // 4
+        owner, per_wave = np.zeros(chunks, np.uint32), np.zeros(W, np.uint32)
+        assert shim.shim_deal_all(plan.ctypes.data_as(C.c_void_p), C.c_uint32(grid), C.c_uint32(chunks), owner.ctypes.data_as(C.c_void_p), per_wave.ctypes.data_as(C.c_void_p)) == 0
+        assert (owner != 0xFFFFFFFF).all()
+
+
 def test_a_commands_tile_by_one_mulhi(shim):
     rng = np.random.default_rng(2)
     for n in [1, 255, 256, 257, 65535, 65536, 65537, 156250, 250114, 1_562_500, 65535 * 64] + [int(x) for x in rng.integers(1, 65535 * 64, 30)]:

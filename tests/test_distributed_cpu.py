@@ -80,3 +80,32 @@ def test_padding_entries_are_not_rebased():
     out = shard.to_global_ids(ids, 1000)
     assert out.tolist() == [1003 | (5 << 24), 0xffffffff, 1070 | (63 << 24), 0xffffffff]
     assert shard.to_global_ids(np.zeros(0, np.uint32), 5).size == 0
+
+
+def test_bench_self_launch_command_is_the_contracts_launcher_line():
+    """`python3 bench.py --gpus N ...` with no launcher in front starts its own ranks — the task contract's launcher line
+    (torch.distributed.run, one node, N ranks, rendezvous on 127.0.0.1) with the caller's arguments unchanged"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    argv = ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+    cmd = bench.self_launch_command(4, argv, port=29517)
+    assert cmd == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", "29517",
+                   os.path.join(root, "bench.py")] + argv
+    assert bench.self_launch_command(2, [])[-2] != str(29517)  # (a free port when none is given)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the failure path: needs a host WITHOUT a GPU")
+def test_bench_self_launch_runs_ranks_and_propagates_their_exit_status():
+    """without a launcher and with --gpus 2 the process re-executes itself under torch.distributed.run; here (no GPU) both ranks fail at
+    cuda.set_device — the parent must report THEIR failure (non-zero exit, the ranks' traceback on stderr), not the old argument error"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--shared-device", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode != 0
+    assert "but WORLD_SIZE=1" not in out.stderr and "--gpus 2 but" not in out.stderr
+    assert "torch.distributed" in out.stderr or "ChildFailedError" in out.stderr or "local_rank" in out.stderr  # the launcher's report of its failed ranks

@@ -113,8 +113,8 @@ def test_bench_forced_sharded_over_rccl(batch, streams, launcher):
 
 
 def test_config5_eight_ranks_100m_meshlets(tmp_path):
-    """BASELINE config 5 end to end with the HIP kernels: `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 --total-meshlets
-    100000000` (gloo, the eight ranks sharing the box's one device — on an 8-GPU node the same command with the default backend is the
+    """BASELINE config 5 end to end with the HIP kernels: `python bench.py --gpus 8 --total-meshlets 100000000` — bench.py launching its own ranks
+    under torch.distributed.run (gloo, the eight ranks sharing the box's one device — on an 8-GPU node the same command with the default backend is the
     RCCL run).  The line must carry `parity` (every rank against the oracle on its shard, inside bench.py) and `cpu_baseline`; and the
     eight ranks' rebased ID lists, concatenated in rank order, must be the oracle's list over the UNSHARDED 100 M-meshlet pool."""
     import argparse
@@ -124,9 +124,10 @@ def test_config5_eight_ranks_100m_meshlets(tmp_path):
     from niagara_amd import host, synth
     world, total, cpd = 8, 100_000_000, 10
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
-           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--shared-device", "--steps", "3", "--warmup", "2",
+    # (no launcher in front — bench.py starts its own eight ranks, as the driver's `python3 bench.py --gpus N ...` needs)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--shared-device", "--steps", "3", "--warmup", "2",
            "--total-meshlets", str(total), "--copies", "2", "--cpu-seconds", "0.5", "--dump-ids", str(tmp_path)]
+    env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
@@ -151,11 +152,47 @@ def test_config5_eight_ranks_100m_meshlets(tmp_path):
     assert (ids == cib[:len(ids)]).all()
 
 
+def test_bench_launches_its_own_ranks():
+    """VERDICT r5 item 1, the exact command of its `Done`: `python3 bench.py --gpus 2 --backend gloo --shared-device --steps 5 --warmup 2` with NO launcher
+    and no rendezvous variables in the environment: rc 0, one JSON line for two ranks, parity on both shards"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--shared-device", "--steps", "5", "--warmup", "2"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 5 and rec["warmup"] == 2 and rec["scaling"] == "weak"
+    assert rec["config"]["meshlets_total"] == 2 * 10_000_000 and rec["value"] > 0
+    assert rec["parity"] == "bit-identical" and "2 of 2 ranks" in rec["parity_checked"] and rec["cpu_baseline"]["value"] > 0
+
+
+def test_bench_driver_command_carries_frame_and_contract_rooflines():
+    """the driver's N = 1 command as it is run at round end: the line carries the headline's roofline + cpu_baseline, `contract_chain` with its own roofline
+     and the dependent `frame` at BASELINE scale with its HBM fraction, per-launch times and parity (item 6a)"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["parity"] == "bit-identical" and "TIMED loop" in rec["parity_checked"]
+    assert 0 < rec["roofline"]["frac"] < 1 and rec["cpu_baseline"]["value"] > 0
+    cc = rec["contract_chain"]
+    assert cc["parity"] == "bit-identical" and 0 < cc["roofline"]["frac"] < 1
+    assert cc["roofline"]["algorithmic_bytes"] == sum(cc["roofline"]["per_pass_bytes"].values())
+    assert cc["roofline"]["per_pass_bytes"]["drawcull"] == 52 * cc["draws"] + 20 * cc["task_commands"]
+    assert cc["roofline"]["per_pass_bytes"]["cluster"] == 12 * cc["meshlets_tested"] + 68 * cc["task_commands"] + 4 * cc["visible"] + 4
+    fr = rec["frame"]
+    assert fr["parity"] == "bit-identical" and 0 < fr["frac"] < 1 and fr["frame_us"] > 0
+    assert set(fr["launch_us"]) >= {"early_drawcull", "early_cluster_cull", "early_cluster_scatter", "pyramid", "late_drawcull", "late_cluster_cull", "late_cluster_hiz", "late_cluster_scatter"}
+    assert sum(fr["launch_us"].values()) < fr["frame_us"] * 1.5 and fr["early"]["meshlets_tested"] > 5_000_000 and fr["late"]["meshlets_tested"] > 5_000_000
+
+
 def test_bench_single_gpu_line_is_one_regime():
     """the default line's value / ms_per_step are one pass after the other on one stream, the dominant kernel's
     event time fits inside a step, and the several-passes-in-flight figure is a side field"""
     sys.path.insert(0, ROOT)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--draws", "6000", "--cpu-seconds", "0.2"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--draws", "6000", "--cpu-seconds", "0.2", "--no-frame"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
