@@ -195,12 +195,13 @@ int nv_profile_read(nv_context* ctx, float out_ms[NV_PROF_SLOTS], uint32_t out_c
 #define NV_VARIANT_CULL_FILTER_RING8 1 /* the same with the 8-deep ring */
 #define NV_VARIANT_CULL_DIRECT 2       /* no filter pass, one command per wave */
 #define NV_VARIANT_CULL_LANES_BITS 3   /* early pass, one lane per set visibility bit */
-#define NV_VARIANT_CULL_LANES 4        /* early pass over a cache-resident pool, one lane per valid cluster */
+#define NV_VARIANT_CULL_LANES 4        /* (0.3: early pass over a cache-resident pool, one lane per valid cluster; never chosen since 0.4) */
 #define NV_VARIANT_CULL_AOS 5          /* no SoA mirror registered for the meshlet buffer: records read in place */
 #define NV_VARIANT_HIZ_STAGE 6         /* late pass with HiZ: occlusion-stage launches */
 #define NV_VARIANT_TASK_LIST 7         /* drawcull TASK scatter: one lane per output command */
 #define NV_VARIANT_TASK_PER_DRAW 8     /* drawcull TASK scatter: per-draw form */
-#define NV_VARIANT_SLOTS 9
+#define NV_VARIANT_CULL_DIRECT_PACKED 9 /* no filter pass, windows of 64 valid meshlets per wave iteration (early form without visibility bits) */
+#define NV_VARIANT_SLOTS 10
 int nv_profile_variants(nv_context* ctx, uint32_t out_count[NV_VARIANT_SLOTS]);
 
 /* ---- options ----
@@ -236,6 +237,9 @@ int nv_profile_variants(nv_context* ctx, uint32_t out_count[NV_VARIANT_SLOTS]);
  *                         pass with visibility bits then tests one lane per SET BIT (last frame's visible clusters) instead of
  *                         one wave per command,
  *                     3 = as 2, but one wave per command also in the early pass with visibility bits;
+ *                     4 = as 3, and one command per wave iteration also where the direct form would walk packed windows of 64 valid
+ *                         meshlets (early form without visibility bits: the cluster pass behind drawcull's LOD select, the late pass's
+ *                         first stage);
  *   NV_OPT_CULL_RING  0 = by the last launch's command count, 4 = the 4-deep load ring (passes of a few hundred thousand commands),
  *                     8 = the 8-deep ring (long streams, late passes). */
 #define NV_OPT_CULL_FORM 5

@@ -56,7 +56,7 @@ _SIGS = {
     "nv_share_scene": (_i, [_vp, _vp]),
     "nv_profile_enable": (_i, [_vp, _i]),
     "nv_profile_read": (_i, [_vp, C.POINTER(C.c_float * 5), C.POINTER(C.c_uint32 * 5)]),
-    "nv_profile_variants": (_i, [_vp, C.POINTER(C.c_uint32 * 9)]),
+    "nv_profile_variants": (_i, [_vp, C.POINTER(C.c_uint32 * 10)]),  # NV_VARIANT_SLOTS
     "nv_upload_meshlets": (_i, [_vp, _vp, _vp, _u32]),
     "nv_upload_meshes": (_i, [_vp, _vp, _vp, _u32]),
     "nv_upload_draws": (_i, [_vp, _vp, _vp, _u32, _vp]),

@@ -351,6 +351,19 @@ constexpr uint32_t CC_SHALLOW_COMMANDS = 500000;
 #ifndef NV_CC_DB
 #define NV_CC_DB 3
 #endif
+// the DIRECT form's pass B walks EVERY command of the segment through the ring: it is the launch's whole stream (12 bytes per meshlet), not the
+// short tail it is behind the filter — its depth is a constant of its own (round 6 sweep: DESIGN.md §4.1)
+#ifndef NV_CC_DB_DIRECT
+#define NV_CC_DB_DIRECT 3
+#endif
+constexpr int CC_DB_DIRECT = NV_CC_DB_DIRECT;
+// the packed direct form (round 6): windows of 64 ENTRIES in flight, and the room of the per-wave window words (64 windows of a full segment + the ring's run-out)
+#ifndef NV_CP_DB
+#define NV_CP_DB 3
+#endif
+constexpr int CP_DB = NV_CP_DB;
+constexpr int CP_WINDOWS = 80;
+static_assert(64 + 2 * CP_DB + 1 <= CP_WINDOWS, "the ring issues up to 2 CP_DB - 2 windows past a full segment's last, the map runs one window ahead of it");
 constexpr int CC_DB = NV_CC_DB;         // ring slots of the exact pass (r2 sweep on 3A: 6 slots 30.2 us / step, 3 slots 29.3; pass B is
                                  // short in the sparse case and a deep ring is mostly redundant loads at its end)
 
@@ -721,6 +734,23 @@ NV_DEV void ringB_issue(SlotB& s, const ClusterArgs& a, uint32_t taskOffset, uin
 #endif
 }
 
+// the packed direct form: the lane's meshlet index comes from the wave's entry -> command map (one lane = one ENTRY of the segment's flattened meshlet list)
+NV_DEV void ringP_issue(SlotB& s, const ClusterArgs& a, uint32_t mi, uint64_t order)
+{
+	const uint32_t off8 = mi * 8u, off4 = mi * 4u;
+#ifdef NV_PLAIN_LOADS
+	(void)order;
+	s.bounds = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(a.soaBounds) + off8);
+	s.cone = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.soaCones) + off4);
+#else
+	asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %2, %3" NV_POLICY_B "\n\tglobal_load_dword %1, %4, %5" NV_POLICY_CONE
+	             : "=&v"(s.bounds), "=&v"(s.cone)
+	             : "v"(off8), "s"(a.soaBounds), "v"(off4), "s"(a.soaCones), "s"(order)
+	             : "memory");
+#endif
+	s.mvbWord = 0;
+}
+
 template <bool BITS, int YOUNGER>
 NV_DEV void ringB_wait(SlotB& s)
 {
@@ -816,12 +846,20 @@ NV_DEV uint32_t deal_wave(const DealPlan& p, uint32_t w, uint32_t lane, uint32_t
 // DEFER (late pass with HiZ: the early form, LATE = BITS = false): frustum / cone ballots only, no tile counts — the occlusion
 // stage (cluster_hiz_kernel) finishes the commands that have survivors; the visibility bits of the commands without any are
 // cleared here (clustercull.comp.glsl:125-131 with visible == false), so that the stage touches 3 % of the commands, not all.
-template <bool LATE, bool SOA, bool BITS, int CC_DA, bool DIRECT = false, bool DEFER = false>
+template <bool LATE, bool SOA, bool BITS, int CC_DA, bool DIRECT = false, bool DEFER = false, bool PACK = false>
 __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs a)
 {
+	static_assert(!PACK || (DIRECT && SOA && !LATE && !BITS), "the packed walk is a form of the direct early pass without visibility bits");
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t w = blockIdx.x * CC_WAVES + wave;
+
+	// PACK: per wave, the table of its segment's non-empty commands (the certified test's coefficients of the command's draw, the command's first meshlet
+	// minus its first entry, its drawId: 80 B), the heads of the entry -> command map (bit p: a command starts at entry p + 1) which the windows' `visible`
+	// ballots overwrite as the walk passes, and the windows' `not certainly outside` ballots (the launch's statistic).  6.4 KB per wave, 25.6 KB per workgroup.
+	__shared__ float4 s_tab[PACK ? CC_WAVES : 1][PACK ? 64 : 1][5];
+	__shared__ uint64_t s_heads[PACK ? CC_WAVES : 1][PACK ? CP_WINDOWS : 1];
+	__shared__ uint64_t s_nout[PACK ? CC_WAVES : 1][PACK ? CP_WINDOWS : 1];
 
 	// late pass: the pyramid's level offsets in LDS, one copy per wave (written and read by the same wave: no barrier).
 	// Built from the scalar kernel arguments with constant indices — a per-lane index into the argument array would be
@@ -984,7 +1022,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 			r.d0 = make_float4(__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w));
 			r.d1 = make_float4(__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z), __uint_as_float(g1.w));
 			r.f = make_filter<false>(a.cd, lane_draw(r), a.filterK, a.viewRowNorm, a.viewTransNorm, a.viewSum, poolVmax3, poolRmax); // (is127: in front of pass B)
-			if (FOLD_A)
+			if (FOLD_A && !DIRECT) // (the direct forms have no filter loop)
 			{
 #pragma unroll
 				for (int i = 0; i < 3; ++i)
@@ -1010,6 +1048,11 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 		{
 			// hipcc must have waited for its own segment loads before the first uncounted load is issued
 			asm volatile("" : "+v"(r.drawId), "+v"(r.taskOffset), "+v"(r.meshletVisibilityOffset), "+v"(r.taskCount), "+v"(r.lateDrawVisibility));
+			// (PACK: the scan over the commands' sizes in front of the first uncounted load — in the experiments build it carries an exec-mask assertion, i.e. a
+			// path out of the kernel, which must not start with loads in flight)
+			uint32_t packIncl = 0;
+			if constexpr (PACK)
+				packIncl = wave_scan_inclusive_u32(r.taskCount < 64u ? r.taskCount : 64u);
 			gather_issue();
 
 			// ---- pass A: stream the 8 bounds bytes of every command through the conservative frustum filter.
@@ -1062,7 +1105,203 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				ringA_issue<BITS_A>(slot, a, off8, offw, order);
 			};
 
-			if (DIRECT)
+			if constexpr (PACK)
+			{
+				// ---- the packed walk (round 6).  One command per wave iteration runs the certified test on the command's LIVE lanes only — 40 of
+				// 64 on average behind drawcull's LOD select (a draw's meshlets end in a partial command), and the launch is bound by vector issue.  Here the
+				// segment's valid meshlets are ONE list of E entries (command-major: the order of the commands, the lanes of a command in order) and a wave
+				// iteration takes a WINDOW of 64 consecutive entries, whatever commands they belong to: every lane of every window but the segment's last is
+				// live.  What was wave-uniform per command becomes per-lane: the coefficients come from the wave's table in LDS (five 16-byte reads per lane,
+				// mostly broadcasts: a window spans one to three commands), the entry -> command map is a bit mask of the commands' first entries and one
+				// v_mbcnt pair per window, and a window's ballot is cut back into the commands' ballots lane-parallel at the segment's end.  Decisions are
+				// certified_visible's, per lane; a lane it leaves undecided runs the reference arithmetic (bits_round's form).
+				// The map needs the commands only, so the ring's first windows are requested BEHIND the MeshDraw gather and in front of the wait for it: the
+				// dependent chain of a wave's start is commands -> {draws, first windows} -> coefficients, as in the filter form.
+				// (Unconditional, also for a segment of empty commands only — E = 0, no window, the ring's requests re-read meshlet 0: a branch around the walk
+				// would give the gather a second wait site, and hipcc joins the two with copies of registers whose loads are still in flight.)
+				candMask = __ballot(r.taskCount != 0); // every valid command (lanes without a command hold 0)
+				{
+					const uint32_t tcc = r.taskCount < 64u ? r.taskCount : 64u;
+					const uint32_t incl = packIncl;
+					const uint32_t excl = incl - tcc; // the command's first entry
+					const uint32_t E = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+					const uint32_t rankC = __builtin_amdgcn_mbcnt_hi((uint32_t)(candMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)candMask, 0u)); // among the non-empty commands
+					float4(*tab)[5] = s_tab[wave];
+					const char* tabBytes = reinterpret_cast<const char*>(tab);
+					uint64_t* heads = s_heads[wave];
+					uint64_t* nout = s_nout[wave];
+					if (tcc || (candMask == 0 && lane == 0)) // (no command at all: entry 0 = meshlet 0 of draw 0)
+						*reinterpret_cast<uint2*>(reinterpret_cast<char*>(tab[rankC]) + 72) = make_uint2(tcc ? r.taskOffset - excl : 0u, tcc ? r.drawId : 0u);
+					heads[lane] = 0ull;
+					if (lane < (uint32_t)CP_WINDOWS - 64u)
+						heads[64u + lane] = 0ull;
+					// (LDS serves a wave's operations in order; the statements only keep hipcc from reordering what it sees as accesses of different lanes)
+					asm volatile("" ::: "memory");
+					if (tcc && excl) // rank(e) = the commands, other than the segment's first non-empty one, whose first entry is <= e = the set bits at positions < e
+						atomicOr(reinterpret_cast<uint32_t*>(heads) + ((excl - 1u) >> 5), 1u << ((excl - 1u) & 31u));
+					asm volatile("" ::: "memory");
+
+					const uint32_t nW = (E + 63u) >> 6, eLast = E ? E - 1u : 0u;
+					const NvCullData& cd = a.cd;
+					// the map runs one window AHEAD of the ring's issue: window j's {table entry, first-meshlet base} are in registers when its loads are issued,
+					// and the heads word of the window after it is already requested — no LDS round trip sits between a landed window and the next request
+					uint32_t startsBefore = 0; // (the same in every lane) commands that start in front of the mapped window, the first one not counted
+					uint32_t ePos = lane;      // the lane's entry in the window being issued
+					uint32_t jMap = 0;         // the window being mapped
+					uint64_t H = heads[0];
+					uint32_t rkNext = 0, miBaseNext = 0;
+					auto map_next = [&]()
+					{
+						const uint32_t hlo = (uint32_t)H, hhi = (uint32_t)(H >> 32);
+						rkNext = __umul24(__builtin_amdgcn_mbcnt_hi(hhi, __builtin_amdgcn_mbcnt_lo(hlo, startsBefore)), 80u);
+						startsBefore += (uint32_t)__builtin_popcount(hlo) + (uint32_t)__builtin_popcount(hhi);
+						miBaseNext = *reinterpret_cast<const uint32_t*>(tabBytes + rkNext + 72u);
+						++jMap;
+						H = heads[jMap]; // (jMap <= 64 + 2 CP_DB: zero past the segment's last window — the lanes stay on the last command)
+					};
+					map_next();
+					SlotB ring[CP_DB];
+					uint32_t rankOf[CP_DB]; // the lane's command in the slot's window: the byte offset of its table entry
+					auto issueP = [&](SlotB& slot, uint32_t& rk, uint64_t order)
+					{
+						rk = rkNext;
+						const uint32_t e = ePos < eLast ? ePos : eLast; // the lanes past the list's end (and the ring's windows past its last) re-read the last entry: in range, unconditional
+						ringP_issue(slot, a, miBaseNext + e, order);
+						ePos += 64u;
+						map_next();
+					};
+#pragma unroll
+					for (int k = 0; k < CP_DB; ++k)
+						issueP(ring[k], rankOf[k], 0);
+					NV_COUNTED_WAIT("s_waitcnt vmcnt(%2) ; nv_ready %0 %1" : "+v"(g0), "+v"(g1) : "i"(CP_DB * 2) : "memory"); // the gather
+					gather_finish();
+					r.f.is127 = filter_is127(r.f.scale);
+					if (tcc)
+					{
+						tab[rankC][0] = make_float4(r.f.m[0], r.f.m[1], r.f.m[2], r.f.b[0]);
+						tab[rankC][1] = make_float4(r.f.m[3], r.f.m[4], r.f.m[5], r.f.b[1]);
+						tab[rankC][2] = make_float4(r.f.m[6], r.f.m[7], r.f.m[8], r.f.b[2]);
+						tab[rankC][3] = make_float4(r.f.aK, r.f.bK, r.f.aR, r.f.scale);
+						*reinterpret_cast<float2*>(&tab[rankC][4]) = make_float2(r.f.coneK, r.f.is127);
+					}
+					asm volatile("" ::: "memory");
+					const bool useCertP = a.filterK > 0.0f && !NV_DBG(a, 1048576u); // bit 20 (experiments): the reference arithmetic only
+					const uint64_t certM = useCertP ? ~0ull : 0ull; // (no certified test: every valid lane takes the reference arithmetic)
+					for (uint32_t j0 = 0; j0 < nW; j0 += CP_DB)
+					{
+#pragma unroll
+						for (int k = 0; k < CP_DB; ++k)
+						{
+							const uint32_t j = j0 + k;
+							// the coefficients, requested in front of the wait for the window's meshlets
+							const char* te = tabBytes + rankOf[k];
+							const float4 r0 = reinterpret_cast<const float4*>(te)[0], r1 = reinterpret_cast<const float4*>(te)[1], r2 = reinterpret_cast<const float4*>(te)[2],
+							             r3 = reinterpret_cast<const float4*>(te)[3];
+							const float2 r4 = reinterpret_cast<const float2*>(te)[8];
+							ringB_wait<false, CP_DB - 1>(ring[k]);
+							uint64_t visM = 0;
+							if (j < nW)
+							{
+								const uint32_t b0 = (uint32_t)ring[k].bounds, b1 = (uint32_t)(ring[k].bounds >> 32), cone = ring[k].cone;
+								const uint32_t left = E - j * 64u;
+								const uint64_t validM = left >= 64u ? ~0ull : (1ull << left) - 1ull;
+								// certified_visible, one lane = one cluster
+								const float vx = half_bits_to_float(b0 & 0xffffu), vy = half_bits_to_float(b0 >> 16), vz = half_bits_to_float(b1 & 0xffffu);
+								const float rad = half_bits_to_float(b1 >> 16);
+								const float cx = __builtin_fmaf(r0.x, vx, __builtin_fmaf(r0.y, vy, __builtin_fmaf(r0.z, vz, r0.w)));
+								const float cy = __builtin_fmaf(r1.x, vx, __builtin_fmaf(r1.y, vy, __builtin_fmaf(r1.z, vz, r1.w)));
+								const float cz = __builtin_fmaf(r2.x, vx, __builtin_fmaf(r2.y, vy, __builtin_fmaf(r2.z, vz, r2.w)));
+								const float aK = r3.x, bK = r3.y, aR = r3.z, scale = r3.w, coneK = r4.x, is127 = r4.y;
+								float T = __builtin_fmaf(aK, __builtin_fabsf(vx), bK);
+								T = __builtin_fmaf(aK, __builtin_fabsf(vy), T);
+								T = __builtin_fmaf(aK, __builtin_fabsf(vz), T);
+								T = __builtin_fmaf(aR, __builtin_fabsf(rad), T);
+								const float thrHi = __builtin_fmaf(scale, rad, T), thrLo = __builtin_fmaf(scale, rad, -T);
+								const float g1 = __builtin_fmaf(cz, cd.frustum[1], -(__builtin_fabsf(cx) * cd.frustum[0]));
+								const float g2 = __builtin_fmaf(cz, cd.frustum[3], -(__builtin_fabsf(cy) * cd.frustum[2]));
+								const float gn = cz - cd.znear;
+								const float gf = cd.zfar - cz;
+								const float g = __builtin_fminf(__builtin_fminf(g1, g2), __builtin_fminf(gn, gf));
+								const uint64_t outM = __ballot(g < -thrHi) & certM, inM = __ballot(g > -thrLo) & certM;
+								uint64_t decidedM = outM | inM;
+								visM = inM;
+								if (cd.clusterBackfaceEnabled != 0 && (inM & validM))
+								{
+									const float kx = s8_to_float(cone, 0), ky = s8_to_float(cone, 1), kz = s8_to_float(cone, 2), kc = s8_to_float(cone, 3);
+									const float wx = __builtin_fmaf(r0.x, kx, __builtin_fmaf(r0.y, ky, r0.z * kz));
+									const float wy = __builtin_fmaf(r1.x, kx, __builtin_fmaf(r1.y, ky, r1.z * kz));
+									const float wz = __builtin_fmaf(r2.x, kx, __builtin_fmaf(r2.y, ky, r2.z * kz));
+									const float lhs = __builtin_fmaf(cx, wx, __builtin_fmaf(cy, wy, cz * wz)) * is127;
+									const float len = __builtin_amdgcn_sqrtf(__builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, cz * cz)));
+									const float rhs = __builtin_fmaf(kc * INV_127, len, scale * rad);
+									const float D = lhs - rhs;
+									const float Tc = T * coneK;
+									const uint64_t cullM = __ballot(D > Tc), keepM = __ballot(D < -Tc);
+									decidedM = outM | (inM & (cullM | keepM)); // (a cluster outside the frustum is decided whatever its cone says)
+									visM = inM & keepM;
+								}
+								visM &= validM;
+								const uint64_t undecidedM = validM & ~decidedM;
+								if (undecidedM) // the reference's arithmetic (clustercull.comp.glsl:72-80,102-108) for the lanes inside a margin, as cull_command evaluates it
+								{
+									bool visible = false;
+									if (undecidedM >> lane & 1ull)
+									{
+										const float4* dp = reinterpret_cast<const float4*>(a.draws + *reinterpret_cast<const uint32_t*>(te + 76));
+										const float4 q0 = dp[0], q1 = dp[1];
+										DrawUniform u;
+										u.pos = { q0.x, q0.y, q0.z };
+										u.scale = q0.w;
+										u.q = { q1.x, q1.y, q1.z };
+										u.qw = q1.w;
+										LaneData l;
+										l.b0 = b0;
+										l.b1 = b1;
+										l.cone = cone;
+										l.mvbWord = 0;
+										f3 c;
+										float rr;
+										lane_sphere(cd, u, l, c, rr);
+										visible = frustum_test(cd, c, rr);
+										if (cd.clusterBackfaceEnabled != 0 && visible)
+										{
+											f3 axis;
+											float cutoff;
+											lane_cone(cd, u, l, axis, cutoff);
+											visible = !cone_cull(c, rr, axis, cutoff);
+										}
+									}
+									visM = (visM & ~undecidedM) | (__ballot(visible) & undecidedM);
+								}
+								if (lane == 0)
+								{
+									heads[j] = visM; // (window j's heads were consumed CP_DB + 1 windows ago)
+									nout[j] = validM & ~outM;
+								}
+							}
+							issueP(ring[k], rankOf[k], visM);
+						}
+					}
+					ring_drain();
+#pragma unroll
+					for (int k = 0; k < CP_DB; ++k)
+						ring_release(ring[k]);
+					// ---- the commands' ballots, cut out of the windows' (lane c = the segment's c-th command)
+					asm volatile("" ::: "memory");
+					{
+						const uint32_t jc = excl >> 6, sh = excl & 63u;
+						const uint64_t need = tcc >= 64u ? ~0ull : (1ull << tcc) - 1ull;
+						const uint64_t vlo = heads[jc], vhi = heads[jc + 1u], nlo = nout[jc], nhi = nout[jc + 1u];
+						const uint64_t m = (sh ? (vlo >> sh) | (vhi << (64u - sh)) : vlo) & need;
+						const uint64_t nm = (sh ? (nlo >> sh) | (nhi << (64u - sh)) : nlo) & need;
+						maskLo = (uint32_t)m;
+						maskHi = (uint32_t)(m >> 32);
+						passedFilter += (uint32_t)__builtin_popcountll(__ballot(nm != 0)); // what pass A's filter would not have finished
+					}
+					asm volatile("" ::: "memory");
+				}
+			}
+			else if (DIRECT)
 			{
 				NV_COUNTED_WAIT("s_waitcnt vmcnt(%2) ; nv_ready %0 %1" : "+v"(g0), "+v"(g1) : "i"(0) : "memory"); // the gather
 				gather_finish();
@@ -1138,7 +1377,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 			// top priority for pass B, because it is on the launch's critical path — late pass 44.8 -> 48.8 us, early pass
 			// unchanged: the boosted wave takes issue slots from the streaming waves that keep HBM busy; likewise
 			// keeping level 3 out of the streaming waves' rotation: early pass +1.5 us.)
-			if (candMask && !NV_DBG(a, 1024u)) // bit 10 (experiments): no exact pass
+			if (!PACK && candMask && !NV_DBG(a, 1024u)) // bit 10 (experiments): no exact pass.  (PACK: the walk above was the exact pass)
 			{
 				uint32_t curDraw = ~0u, certDraw = ~0u;
 				DrawUniform du = {};
@@ -1197,7 +1436,9 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 					}
 					return m;
 				};
-				SlotB ring[CC_DB];
+				{
+				constexpr int DB = DIRECT ? CC_DB_DIRECT : CC_DB;
+				SlotB ring[DB];
 				if (DIRECT)
 				{
 					// Every command of the segment is a candidate: the walk is c = 0, 1, 2, ... — no pending mask, no find-first-bit, no per-slot
@@ -1205,15 +1446,15 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 					// form).  Dummy commands and the lanes past the wave's last command hold taskCount 0: nothing to test, their loads
 					// re-read meshlet 0; a slot index past the segment wraps to its first commands (redundant, in range, like the filter ring's).
 #pragma unroll
-					for (int k = 0; k < CC_DB; ++k)
+					for (int k = 0; k < DB; ++k)
 						ringB_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, k), __builtin_amdgcn_readlane(r.taskCount, k),
 						                  __builtin_amdgcn_readlane(r.meshletVisibilityOffset, k), lane, 0);
-					for (uint32_t c0 = 0; c0 < cnt; c0 += CC_DB)
+					for (uint32_t c0 = 0; c0 < cnt; c0 += DB)
 					{
 #pragma unroll
-						for (int k = 0; k < CC_DB; ++k)
+						for (int k = 0; k < DB; ++k)
 						{
-							ringB_wait<BITS, CC_DB - 1>(ring[k]);
+							ringB_wait<BITS, DB - 1>(ring[k]);
 							const uint32_t c = c0 + k;
 							uint64_t m = 0;
 							// (an empty command is skipped as a whole, not tested with need == 0: its lane holds the filter of draw 0 — what its gather
@@ -1227,7 +1468,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 								cur.mvbWord = ring[k].mvbWord;
 								m = exact_command(c, cur);
 							}
-							const uint32_t nx = (c + CC_DB) & 63u;
+							const uint32_t nx = (c + DB) & 63u;
 							ringB_issue<BITS>(ring[k], a, __builtin_amdgcn_readlane(r.taskOffset, nx), __builtin_amdgcn_readlane(r.taskCount, nx),
 							                  __builtin_amdgcn_readlane(r.meshletVisibilityOffset, nx), lane, m);
 						}
@@ -1291,8 +1532,9 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				}
 				ring_drain();
 #pragma unroll
-				for (int k = 0; k < CC_DB; ++k)
+				for (int k = 0; k < DB; ++k)
 					ring_release(ring[k]);
+				}
 			}
 		}
 		else
@@ -2602,12 +2844,28 @@ template <bool LATE, bool SOA, int DEPTH, bool DIRECT = false>
 static void launch_cc(hipStream_t stream, const ClusterArgs& a, uint32_t gridBlocks)
 {
 	dim3 grid(gridBlocks), block(CC_THREADS);
+	// the direct form's packed walk (windows of 64 valid meshlets instead of one command per iteration): early form without visibility bits, over the mirror
+	constexpr bool CAN_PACK = DIRECT && SOA && !LATE;
+	const bool pack = CAN_PACK && a.packDirect != 0;
 	if (!LATE && a.deferHiz)
-		hipLaunchKernelGGL((cluster_mask_kernel<false, SOA, false, DEPTH, DIRECT, true>), grid, block, 0, stream, a);
+	{
+		if (pack)
+			hipLaunchKernelGGL((cluster_mask_kernel<false, SOA, false, DEPTH, DIRECT, true, CAN_PACK>), grid, block, 0, stream, a);
+		else
+			hipLaunchKernelGGL((cluster_mask_kernel<false, SOA, false, DEPTH, DIRECT, true>), grid, block, 0, stream, a);
+	}
 	else if (a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0)
 		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, true, DEPTH, DIRECT>), grid, block, 0, stream, a);
+	else if (pack)
+		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, false, DEPTH, DIRECT, false, CAN_PACK>), grid, block, 0, stream, a);
 	else
 		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, false, DEPTH, DIRECT>), grid, block, 0, stream, a);
+}
+
+// what launch_cluster_mask resolves (late, soa, direct) and the arguments to: the packed walk? (context.hip count_cull_variant)
+bool clustercull_takes_packed(const ClusterArgs& a, int late, bool soa, bool direct)
+{
+	return soa && direct && a.filterK > 0.0f && !late && a.packDirect != 0 && (a.deferHiz || !(a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0));
 }
 
 // any grid size (pure map); shallow = use the 4-deep filter ring (early pass over the SoA mirror only); direct = no filter
@@ -2660,11 +2918,10 @@ bool clustercull_prefers_direct(uint32_t previousCommandCount, uint32_t previous
 template <bool SOA>
 static void launch_cb(hipStream_t stream, const ClusterArgs& a, uint32_t gridBlocks)
 {
+	// (the form without visibility bits — every valid cluster an entry, cluster_bits_kernel<SOA, false> — was the host's choice for a cache-resident pool in
+	// rounds 4-5; the direct form's packed walk took its place in round 6 and it is no longer instantiated)
 	dim3 grid(gridBlocks), block(CB_THREADS);
-	if (a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0)
-		hipLaunchKernelGGL((cluster_bits_kernel<SOA, true>), grid, block, 0, stream, a);
-	else
-		hipLaunchKernelGGL((cluster_bits_kernel<SOA, false>), grid, block, 0, stream, a);
+	hipLaunchKernelGGL((cluster_bits_kernel<SOA, true>), grid, block, 0, stream, a);
 }
 
 int launch_cluster_bits(hipStream_t stream, const ClusterArgs& a, bool soa, uint32_t gridBlocks)

@@ -23,6 +23,7 @@ namespace nv
 int launch_cluster_mask(hipStream_t, const ClusterArgs&, int late, bool soa, uint32_t maskBlocks, bool shallow, bool direct, uint32_t expectedCmds);
 bool clustercull_prefers_shallow(uint32_t previousCommandCount);
 bool clustercull_prefers_direct(uint32_t previousCommandCount, uint32_t previousPassedFilter, uint32_t percent);
+bool clustercull_takes_packed(const ClusterArgs&, int late, bool soa, bool direct);
 int launch_cluster_scatter(hipStream_t, const ClusterArgs&, uint32_t scatterBlocks, uint32_t waves);
 int launch_cluster_hiz(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
 int launch_cluster_bits(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
@@ -333,7 +334,7 @@ void count_cull_variant(nv_context* ctx, const nv::ClusterArgs& a, bool lanes, b
 	else if (!a.soaBounds)
 		v = NV_VARIANT_CULL_AOS;
 	else if (direct && a.filterK > 0.0f)
-		v = NV_VARIANT_CULL_DIRECT;
+		v = nv::clustercull_takes_packed(a, late, true, true) ? NV_VARIANT_CULL_DIRECT_PACKED : NV_VARIANT_CULL_DIRECT;
 	else
 		v = !late && shallow ? NV_VARIANT_CULL_FILTER_RING4 : NV_VARIANT_CULL_FILTER_RING8;
 	ctx->variants[v] += 1u;
@@ -343,7 +344,7 @@ void count_cull_variant(nv_context* ctx, const nv::ClusterArgs& a, bool lanes, b
 
 extern "C" {
 
-const char* nv_version(void) { return "niagara_vis 0.3 (gfx950)"; } // 0.2: NV_PROF_SLOTS 4 -> 5; 0.3: nv_reserve, nv_share_scene
+const char* nv_version(void) { return "niagara_vis 0.4 (gfx950)"; } // 0.2: NV_PROF_SLOTS 4 -> 5; 0.3: nv_reserve, nv_share_scene; 0.4: NV_VARIANT_SLOTS 9 -> 10
 
 int nv_create(nv_context** out_ctx, int device)
 {
@@ -507,9 +508,9 @@ int nv_set_option(nv_context* ctx, int option, int value)
 		ctx->scatterWaves = (uint32_t)value;
 		return NV_OK;
 	case NV_OPT_CULL_FORM:
-		if (value < 0 || value > 3)
+		if (value < 0 || value > 4)
 			return NV_EINVAL;
-		ctx->forceDirect = value - 1; // 0 -> -1 (by statistic), 1 -> 0 (filter form), 2 -> 1 (direct form), 3 -> 2 (direct, one command per wave also with visibility bits)
+		ctx->forceDirect = value - 1; // 0 -> -1 (by statistic), 1 -> 0 (filter form), 2 -> 1 (direct form), 3 -> 2 (direct, one command per wave also with visibility bits), 4 -> 3 (as 3, and no packed walk)
 		return NV_OK;
 	case NV_OPT_TASK_EMIT:
 		if (value < 0 || value > 2)
@@ -880,6 +881,7 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	a.clusterCount4 = d_clusterCount4;
 	a.fusedReset = ctx->fusedReset;
 	a.fusedSubmit = ctx->fusedSubmit;
+	a.packDirect = ctx->forceDirect != 3 ? 1u : 0u; // NV_OPT_CULL_FORM 4: one command per wave iteration also where the packed walk applies
 	a.countsSink = reinterpret_cast<unsigned long long*>(ctx->countsSink);
 #ifdef NV_EXPERIMENTS
 	a.debugMode = ctx->debugMode;
@@ -918,14 +920,13 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	// with one lane per survivor (clustercull.hip cluster_hiz_kernel: visibility bits, skip, tile counts), the scatter.
 	const bool twoStage = late && cull->clusterOcclusionEnabled == 1;
 	a.deferHiz = twoStage ? 1u : 0u;
-	// Where the filter would not pay (direct), EARLY passes test one LANE per cluster that can be visible at all instead of one wave per
-	// command (clustercull.hip cluster_bits_kernel): with visibility bits (candidates = set bits: 26 against 38-40 us at frame scale), and,
-	// while the registered meshlet pool is small enough to stay in the caches (an instanced scene; a pool streamed from HBM loses: 52-62
-	// against 40 us for 10 M meshlets), also without (every valid cluster a candidate).  The late pass keeps one command per wave: both
-	// lane forms of it measured slower (clustercull.hip, above cluster_bits_kernel).  NV_OPT_CULL_FORM 3 keeps one command per wave throughout.
-	const bool poolInCache = a.soaBounds != nullptr && (uint64_t)ctx->scene->mirroredCount * 12u <= (48ull << 20);
+	// Where the filter would not pay (direct), an EARLY pass with visibility bits tests one LANE per cluster that can be visible at all — per set bit —
+	// instead of one wave per command (clustercull.hip cluster_bits_kernel: 26 against 38-40 us at frame scale).  Without bits the direct form walks
+	// packed windows of 64 valid meshlets (cluster_mask_kernel PACK, round 6: the cluster pass behind drawcull's LOD select 24 us against 34 for the
+	// lane-per-valid-cluster form rounds 4-5 chose for a cache-resident pool, and 44 for one command per wave iteration); so does the late pass's first
+	// stage.  NV_OPT_CULL_FORM 3 keeps one wave per command with visibility bits, 4 one command per wave iteration throughout.
 	const bool bits = cull->clusterOcclusionEnabled == 1 && cull->postPass == 0;
-	const bool laneForm = !late && direct && ctx->forceDirect != 2 && (bits || poolInCache);
+	const bool laneForm = !late && direct && ctx->forceDirect < 2 && bits;
 	if (laneForm)
 		rc = nv::launch_cluster_bits(s, a, a.soaBounds != nullptr, persistent_grid(ctx, ctx->bitsBlocksPerCU));
 	else
@@ -994,8 +995,7 @@ int nv_taskcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 		ctx->taskCommandsFrom = nullptr;
 		if (ctx->forceDirect >= 0)
 			direct = ctx->forceDirect != 0;
-		const bool poolInCache = a.soaBounds != nullptr && (uint64_t)ctx->scene->mirroredCount * 12u <= (48ull << 20);
-		const bool bitsForm = direct && ctx->forceDirect != 2 && ((cull->clusterOcclusionEnabled == 1 && cull->postPass == 0) || poolInCache);
+		const bool bitsForm = direct && ctx->forceDirect < 2 && cull->clusterOcclusionEnabled == 1 && cull->postPass == 0;
 		if (bitsForm)
 			rc = nv::launch_cluster_bits(s, a, a.soaBounds != nullptr, persistent_grid(ctx, ctx->bitsBlocksPerCU));
 		else

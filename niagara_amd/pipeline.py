@@ -90,11 +90,11 @@ class Context:
         names = ("cluster_cull", "cluster_scatter", "drawcull", "depthreduce", "cluster_hiz")
         return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(names)}
 
-    VARIANTS = ("cull_filter_ring4", "cull_filter_ring8", "cull_direct", "cull_lanes_bits", "cull_lanes", "cull_aos", "hiz_stage", "task_list", "task_per_draw")
+    VARIANTS = ("cull_filter_ring4", "cull_filter_ring8", "cull_direct", "cull_lanes_bits", "cull_lanes", "cull_aos", "hiz_stage", "task_list", "task_per_draw", "cull_direct_packed")
 
     def profile_variants(self):
         """{variant: launches since the last call}: which kernel form the host's per-launch choices resolved to (non-zero entries only)"""
-        cnt = (C.c_uint32 * 9)()
+        cnt = (C.c_uint32 * len(self.VARIANTS))()
         check(lib.nv_profile_variants(self.h, C.byref(cnt)), "nv_profile_variants")
         return {n: int(cnt[i]) for i, n in enumerate(self.VARIANTS) if cnt[i]}
 

@@ -193,13 +193,17 @@ def test_profile_variants_name_the_form_each_launch_took():
         p.run(cd, 0, None)
         assert ctx.profile_variants() == {"cull_filter_ring4": 1, "cull_filter_ring8": 1}
         ctx.set_option(P.NV_OPT_CULL_FORM, 2)
-        p.run(cd, 0, None)       # cache-resident pool, no visibility bits: one lane per valid cluster
+        p.run(cd, 0, None)       # no visibility bits: the direct form's packed walk (windows of 64 valid meshlets)
         p.run(bits, 0, mvb0)     # with bits: one lane per set bit
-        p.run(bits, 1, mvb0)     # late with HiZ: one command per wave (direct) + the occlusion stage
-        assert ctx.profile_variants() == {"cull_lanes": 1, "cull_lanes_bits": 1, "cull_direct": 1, "hiz_stage": 1}
+        p.run(bits, 1, mvb0)     # late with HiZ: the packed walk as the first stage + the occlusion stage
+        assert ctx.profile_variants() == {"cull_direct_packed": 2, "cull_lanes_bits": 1, "hiz_stage": 1}
         ctx.set_option(P.NV_OPT_CULL_FORM, 3)
-        p.run(bits, 0, mvb0)
+        p.run(bits, 0, mvb0)     # one wave per command also with visibility bits
         assert ctx.profile_variants() == {"cull_direct": 1}
+        ctx.set_option(P.NV_OPT_CULL_FORM, 4)
+        p.run(cd, 0, None)       # one command per wave iteration also where the packed walk applies
+        p.run(bits, 1, mvb0)
+        assert ctx.profile_variants() == {"cull_direct": 2, "hiz_stage": 1}
         ctx.upload_meshlets(None, 0)  # no mirror: the records are read in place
         p.run(cd, 0, None)
         assert ctx.profile_variants() == {"cull_aos": 1} and ctx.profile_variants() == {}
@@ -222,7 +226,7 @@ def test_a_fresh_contexts_first_frame_takes_the_direct_forms_for_its_own_drawcul
         fg = run_frames(ctx, scene, flags, frames=1)
         v = ctx.profile_variants()
         # frame 0: the early cluster pass is the context's first cluster launch ever
-        assert v.get("cull_direct", 0) + v.get("cull_lanes_bits", 0) + v.get("cull_lanes", 0) >= 1, v
+        assert v.get("cull_direct", 0) + v.get("cull_lanes_bits", 0) + v.get("cull_direct_packed", 0) >= 1, v
         for phase in ("early", "late"):
             for key in ("count4", "commands", "cc4", "cib", "dvb", "mvb"):
                 assert fo[0][phase][key].tobytes() == fg[0][phase][key].tobytes(), (phase, key)
@@ -235,6 +239,6 @@ def test_a_fresh_contexts_first_frame_takes_the_direct_forms_for_its_own_drawcul
         cd = host.build_cull_data(cam_pos=(0, 0, 25), draw_count=len(draws), cullingEnabled=1, clusterBackfaceEnabled=1)
         _Pass(ctx, draws, meshlets, commands, n).run(cd, 0, None)
         v = ctx.profile_variants()
-        assert v.get("cull_filter_ring4", 0) + v.get("cull_filter_ring8", 0) == 1 and "cull_direct" not in v, v
+        assert v.get("cull_filter_ring4", 0) + v.get("cull_filter_ring8", 0) == 1 and "cull_direct" not in v and "cull_direct_packed" not in v, v
     finally:
         ctx.close()

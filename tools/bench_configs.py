@@ -683,6 +683,15 @@ def verdict(same):
     return "bit-identical"
 
 
+# NV_BENCH_CULL_FORM=n (A/B runs only): every context this module — or bench.contract_chain through it — creates pins NV_OPT_CULL_FORM to n
+if os.environ.get("NV_BENCH_CULL_FORM"):
+    class _PinnedContext(P.Context):
+        def __init__(self, *args, **kw):
+            super().__init__(*args, **kw)
+            self.set_option(P.NV_OPT_CULL_FORM, int(os.environ["NV_BENCH_CULL_FORM"]))
+    P.Context = _PinnedContext
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
