@@ -956,6 +956,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 		stamps[6] = wall_clock64(); // 100 MHz, chip-wide: comparable across CUs (the cycle counter is not)
 
 	uint32_t passedFilter = 0; // commands of this wave the conservative filter does not finish (DIRECT: would not have finished)
+	uint32_t meshletsSeen = 0; // valid meshlets of this wave's commands, per lane (summed once, at the wave's end): with the command count the pass's FILL (meshlets per command slot), the second statistic of the host's choice
 	// (the same per WAVE, in front of its first segment: NV_FILLER_PS / NV_FILLER_PV)
 #if defined(NV_FILLER_PS)
 #pragma unroll
@@ -1053,6 +1054,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 			uint32_t packIncl = 0;
 			if constexpr (PACK)
 				packIncl = wave_scan_inclusive_u32(r.taskCount < 64u ? r.taskCount : 64u);
+			meshletsSeen += r.taskCount < 64u ? r.taskCount : 64u; // (the fill statistic: word 2 of a tile counter's line, summed by the scatter launch)
 			gather_issue();
 
 			// ---- pass A: stream the 8 bounds bytes of every command through the conservative frustum filter.
@@ -1664,6 +1666,13 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 		const uint32_t spread = numTiles ? (1u << (31 - __builtin_clz(numTiles))) - 1u : 0u;
 		atomicAdd(&a.tileCounts->counts[bank][(w & spread) * CC_COUNT_STRIDE + 1], passedFilter);
 	}
+	if (SOA && !(!LATE && !DEFER && a.payloadCounts != nullptr))
+	{
+		const uint32_t sum = wave_sum_u32(meshletsSeen);
+		const uint32_t spread = numTiles ? (1u << (31 - __builtin_clz(numTiles))) - 1u : 0u;
+		if (lane == 0 && sum)
+			atomicAdd(&a.tileCounts->counts[bank][(w & spread) * CC_COUNT_STRIDE + 2], sum);
+	}
 	NV_STAMP(5);
 	if (dbgTime && lane == 0)
 		stamps[7] = wall_clock64();
@@ -1700,6 +1709,7 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 	const uint32_t base0 = load_uniform_u32(&a.tileCounts->base);
 	uint32_t cnt0[TILE_LOADS] = {}, cnt1[TILE_LOADS] = {}; // this thread's tiles tid, tid + SC_THREADS, ..., per bank
 	uint32_t pf0[TILE_LOADS] = {}, pf1[TILE_LOADS] = {};   // likewise the cull kernel's filter statistic (word 1 of the line)
+	uint32_t mf0[TILE_LOADS] = {}, mf1[TILE_LOADS] = {};   // and its fill statistic (word 2: valid meshlets of the pass's commands)
 #pragma unroll
 	for (int j = 0; j < TILE_LOADS; ++j)
 	{
@@ -1708,8 +1718,13 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 		{
 			cnt0[j] = a.tileCounts->counts[0][i * CC_COUNT_STRIDE];
 			cnt1[j] = a.tileCounts->counts[1][i * CC_COUNT_STRIDE];
-			pf0[j] = a.tileCounts->counts[0][i * CC_COUNT_STRIDE + 1];
-			pf1[j] = a.tileCounts->counts[1][i * CC_COUNT_STRIDE + 1];
+			if (tile == numTiles - 1) // (uniform: only the last tile sums the statistics — the same lines as its tile counts, requested in the same clause)
+			{
+				pf0[j] = a.tileCounts->counts[0][i * CC_COUNT_STRIDE + 1];
+				pf1[j] = a.tileCounts->counts[1][i * CC_COUNT_STRIDE + 1];
+				mf0[j] = a.tileCounts->counts[0][i * CC_COUNT_STRIDE + 2];
+				mf1[j] = a.tileCounts->counts[1][i * CC_COUNT_STRIDE + 2];
+			}
 		}
 	}
 	const uint32_t first = tile * T;
@@ -1746,6 +1761,7 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 	{
 		a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE] = 0;
 		a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE + 1] = 0;
+		a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE + 2] = 0;
 		if (i < CC_LISTS)
 			a.tileCounts->listCount[bank ^ 1u][i * CC_COUNT_STRIDE] = 0;
 	}
@@ -1754,7 +1770,10 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 		a.tileCounts->parity = bank ^ 1u;
 		a.tileCounts->listOverflow[bank ^ 1u] = 0;
 		if (numTiles == 0 && a.hostHint)
+		{
 			__hip_atomic_store(a.hostHint + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(a.hostHint + 5, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
 		if (numTiles == 0) // no commands at all: the count word keeps its base, the submit words describe an empty grid
 		{
 			if (a.fusedReset)
@@ -1781,7 +1800,7 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 	if (tile >= numTiles)
 		return;
 
-	uint32_t before = 0, all = 0, passed = 0;
+	uint32_t before = 0, all = 0, passed = 0, filled = 0;
 #pragma unroll
 	for (int j = 0; j < TILE_LOADS; ++j)
 	{
@@ -1790,19 +1809,28 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 		all += v;
 		before += i < tile ? v : 0u;
 		passed += bank ? pf1[j] : pf0[j];
+		filled += bank ? mf1[j] : mf0[j];
 	}
 	if (tile == numTiles - 1 && a.hostHint) // (one workgroup: the statistic is a tuning hint, its sum need not be fast; its mapped-host store at the launch's end costs nothing measurable: round 4, NV_DEBUG_MODE A/B)
 	{
-		__shared__ uint32_t s_passed;
+		__shared__ uint32_t s_passed, s_filled;
 		if (tid == 0)
+		{
 			s_passed = 0;
+			s_filled = 0;
+		}
 		__syncthreads();
-		const uint32_t wp = wave_sum_u32(passed);
+		const uint32_t wp = wave_sum_u32(passed), wf = wave_sum_u32(filled);
 		if (lane == 0 && wp)
 			atomicAdd(&s_passed, wp);
+		if (lane == 0 && wf)
+			atomicAdd(&s_filled, wf);
 		__syncthreads();
 		if (tid == 0)
+		{
 			__hip_atomic_store(a.hostHint + 1, s_passed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(a.hostHint + 5, s_filled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
 	}
 	const uint32_t wBefore = wave_sum_u32(before), wAll = wave_sum_u32(all);
 	if (lane == 0)
@@ -2517,7 +2545,7 @@ __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs
 	const uint32_t iters = (numCmds + G * (uint32_t)CB_CMDS - 1u) / (G * (uint32_t)CB_CMDS);
 	uint32_t per = iters ? (numCmds + G * iters - 1u) / (G * iters) : 0u;
 	per = per < 16u ? 16u : per; // (<= CB_CMDS by construction)
-	uint32_t passedAcc = 0;
+	uint32_t passedAcc = 0, meshletsAcc = 0;
 
 	// pipeline prologue: commands of iterations 0 and 1, MeshDraw and words of iteration 0
 	uint32_t chunk = blockIdx.x;
@@ -2635,6 +2663,7 @@ __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs
 			// does not finish): a command with a set bit was visible a frame ago, and nearly always still has a cluster the
 			// filter cannot finish — counting those per entry cost 8 instructions per cluster for a tuning hint.
 			passedAcc += BITS ? (cand ? 1u : 0u) : (cand ? s_passed[tid] : 0u);
+			meshletsAcc += taskCount < 64u ? taskCount : 64u; // the fill statistic (cluster_mask_kernel: meshletsSeen)
 		}
 		if (a.payloadCounts) // (uniform) nv_taskcull's early pass: the payloads straight from here (see cluster_mask_kernel), no tile counts
 		{
@@ -2678,6 +2707,12 @@ __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs
 		{
 			const uint32_t numTiles = (numCmds + T2 - 1) / T2;
 			atomicAdd(&a.tileCounts->counts[bank][((blockIdx.x * (CB_THREADS / 64) + wave) % (numTiles ? numTiles : 1u)) * CC_COUNT_STRIDE + 1], sum);
+		}
+		const uint32_t msum = wave_sum_u32(meshletsAcc);
+		if (lane == 0 && msum && !a.payloadCounts)
+		{
+			const uint32_t numTiles = (numCmds + T2 - 1) / T2;
+			atomicAdd(&a.tileCounts->counts[bank][((blockIdx.x * (CB_THREADS / 64) + wave) % (numTiles ? numTiles : 1u)) * CC_COUNT_STRIDE + 2], msum);
 		}
 	}
 }
@@ -2912,6 +2947,16 @@ bool clustercull_prefers_shallow(uint32_t previousCommandCount) { return previou
 bool clustercull_prefers_direct(uint32_t previousCommandCount, uint32_t previousPassedFilter, uint32_t percent)
 {
 	return previousCommandCount != 0 && (uint64_t)previousPassedFilter * 100u > (uint64_t)previousCommandCount * percent;
+}
+
+// The filter form's time goes with the number of COMMANDS (its stream is bound by instruction issue: ~60 instructions per command whatever the command's
+// size), the packed direct walk's with the number of valid MESHLETS / 64.  Behind drawcull's LOD select a draw's meshlets end in a partial command — config
+// 3B at BASELINE scale: 250 k commands, 40 valid lanes on average — and the packed walk then wins even where the filter rejects nearly everything (24 against
+// 34 us there, a cache-resident pool; 3A's full commands streamed from HBM: filter 21 us, packed walk 32).  fillPercent = the pass's valid meshlets per
+// command slot below which the packed walk is taken whatever the filter statistic says (context.hip: 85 for a cache-resident pool, 60 otherwise).
+bool clustercull_prefers_packed(uint32_t previousCommandCount, uint32_t previousMeshlets, uint32_t fillPercent)
+{
+	return previousCommandCount != 0 && previousMeshlets != 0 && (uint64_t)previousMeshlets * 100u < (uint64_t)previousCommandCount * 64u * fillPercent;
 }
 
 // early pass with visibility bits, dense form (one lane per set bit): any grid size (equal contiguous shares per block, grid-stride beyond CB_CMDS commands per block)

@@ -24,6 +24,7 @@ int launch_cluster_mask(hipStream_t, const ClusterArgs&, int late, bool soa, uin
 bool clustercull_prefers_shallow(uint32_t previousCommandCount);
 bool clustercull_prefers_direct(uint32_t previousCommandCount, uint32_t previousPassedFilter, uint32_t percent);
 bool clustercull_takes_packed(const ClusterArgs&, int late, bool soa, bool direct);
+bool clustercull_prefers_packed(uint32_t previousCommandCount, uint32_t previousMeshlets, uint32_t fillPercent);
 int launch_cluster_scatter(hipStream_t, const ClusterArgs&, uint32_t scatterBlocks, uint32_t waves);
 int launch_cluster_hiz(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
 int launch_cluster_bits(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
@@ -914,18 +915,25 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	// (the provenance is good for ONE cluster launch: a later list at the same address — a freed and reused buffer, a caller-built list — is not this
 	// context's drawcull output unless another nv_drawcull(task) has written there since)
 	ctx->taskCommandsFrom = nullptr;
+	// [5] = the valid meshlets of the previous launch's commands: a pass of partial commands (drawcull's LOD select) takes the direct form's packed walk whatever
+	// the filter statistic says, where that form exists (early form without visibility bits, over the mirror) — clustercull.hip clustercull_prefers_packed
+	const bool bits = cull->clusterOcclusionEnabled == 1 && cull->postPass == 0;
+	const bool twoStage = late && cull->clusterOcclusionEnabled == 1;
+	if (!direct && ctx->hintHost && a.soaBounds && a.filterK > 0.0f && (twoStage || (!late && !bits)))
+	{
+		const bool poolInCache = (uint64_t)ctx->scene->mirroredCount * 12u <= (48ull << 20);
+		direct = nv::clustercull_prefers_packed(ctx->hintHost[0], ctx->hintHost[5], poolInCache ? 85u : 60u);
+	}
 	if (ctx->forceDirect >= 0)
 		direct = ctx->forceDirect != 0;
 	// Late pass with HiZ = three launches: the cull kernel in its early form (frustum + cone ballots), the occlusion probe
 	// with one lane per survivor (clustercull.hip cluster_hiz_kernel: visibility bits, skip, tile counts), the scatter.
-	const bool twoStage = late && cull->clusterOcclusionEnabled == 1;
 	a.deferHiz = twoStage ? 1u : 0u;
 	// Where the filter would not pay (direct), an EARLY pass with visibility bits tests one LANE per cluster that can be visible at all — per set bit —
 	// instead of one wave per command (clustercull.hip cluster_bits_kernel: 26 against 38-40 us at frame scale).  Without bits the direct form walks
 	// packed windows of 64 valid meshlets (cluster_mask_kernel PACK, round 6: the cluster pass behind drawcull's LOD select 24 us against 34 for the
 	// lane-per-valid-cluster form rounds 4-5 chose for a cache-resident pool, and 44 for one command per wave iteration); so does the late pass's first
 	// stage.  NV_OPT_CULL_FORM 3 keeps one wave per command with visibility bits, 4 one command per wave iteration throughout.
-	const bool bits = cull->clusterOcclusionEnabled == 1 && cull->postPass == 0;
 	const bool laneForm = !late && direct && ctx->forceDirect < 2 && bits;
 	if (laneForm)
 		rc = nv::launch_cluster_bits(s, a, a.soaBounds != nullptr, persistent_grid(ctx, ctx->bitsBlocksPerCU));
