@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 								}
 								visM &= validM;
 								const uint64_t undecidedM = validM & ~decidedM;
-								if (undecidedM) // the reference's arithmetic (clustercull.comp.glsl:72-80,102-108) for the lanes inside a margin, as cull_command evaluates it
+								if (undecidedM && !NV_DBG(a, 536870912u)) // the reference's arithmetic (clustercull.comp.glsl:72-80,102-108) for the lanes inside a margin, as cull_command evaluates it.  (bit 29, experiments: skipped — what the undecided lanes cost)
 								{
 									bool visible = false;
 									if (undecidedM >> lane & 1ull)
@@ -2442,7 +2442,7 @@ NV_DEV void bits_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint
 			decided = decided && (out || cull || keep); // (a cluster outside the frustum is decided whatever its cone says)
 			visible = visible && keep;
 		}
-		if (!decided) // the reference's arithmetic (clustercull.comp.glsl:72-80,102-108), as cull_command evaluates it
+		if (!decided && !NV_DBG(a, 536870912u)) // the reference's arithmetic (clustercull.comp.glsl:72-80,102-108), as cull_command evaluates it.  (bit 29, experiments: skipped)
 		{
 			const float4 q0 = s_draw[owner][0], q1 = s_draw[owner][1];
 			DrawUniform u;
