@@ -783,10 +783,14 @@ NV_DEV void ring_release(SlotB& s) { asm volatile("; released %0 %1 %2" : "+v"(s
 // the n-th set bit of its command's mask — was built and measured in round 6 and is not here: tools/experiments/sparse_exact_pass_r6.diff.  The walk's
 // fixed price, ~500 instructions and half a dozen LDS round trips per segment, is more than the one or two candidates of a usual segment cost one at a
 // time: headline pass 26.0 -> 27.9 us; as a hybrid — the walk for segments with four or more candidates — both rings in one kernel spill: 31-32 us.)
+// The margin is the draw's tK >= T of every meshlet of the pool (filtermath.h filter_make: what the filter pass uses) instead of the meshlet's own T: four
+// multiply-adds and a 16-byte LDS read less per window, a margin wider by a few per cent (tests/test_cert_margins.py holds both two-sided tests, with T and
+// with tK, against the reference's decisions); a pool with a non-finite record has tK = inf and every lane takes the reference arithmetic.
 // Table entry (CP_ENTRY bytes per non-empty command, in the order of the commands; LDS is what bounds the six workgroups per CU):
-//   +0 the coefficients: m[0..2], b0 | m[3..5], b1 | m[6..8], b2 | aK, bK, aR, scale | coneK, is127  (72 bytes)
-//   +72 taskOffset - the command's first entry   +76 first entry | the command's lane in the segment << 16
-constexpr uint32_t CP_ENTRY = 80, CP_ENTRY_HEAD = 72;
+//   +0 the coefficients: m[0..2], b0 | m[3..5], b1 | m[6..8], b2 | tK, scale, tK coneK, is127  (64 bytes)
+//   +64 taskOffset - the command's first entry   +68 first entry | the command's lane in the segment << 16   (+72: padding — 16-byte reads)
+constexpr uint32_t CP_ENTRY = 80, CP_ENTRY_HEAD = 64;
+static_assert(CP_ENTRY % 16 == 0, "the coefficients are read with ds_read_b128");
 
 NV_DEV void walk_coefficients(char* at, const FilterDraw& f)
 {
@@ -794,8 +798,7 @@ NV_DEV void walk_coefficients(char* at, const FilterDraw& f)
 	t4[0] = make_float4(f.m[0], f.m[1], f.m[2], f.b[0]);
 	t4[1] = make_float4(f.m[3], f.m[4], f.m[5], f.b[1]);
 	t4[2] = make_float4(f.m[6], f.m[7], f.m[8], f.b[2]);
-	t4[3] = make_float4(f.aK, f.bK, f.aR, f.scale);
-	reinterpret_cast<float2*>(at)[8] = make_float2(f.coneK, f.is127);
+	t4[3] = make_float4(f.tK, f.scale, f.tK * f.coneK, f.is127);
 }
 
 // heads: bit p set = a command other than the first starts at entry p + 1 (so the commands in front of entry e, the first not counted, are the set
@@ -810,14 +813,21 @@ NV_DEV void packed_walk(const ClusterArgs& a, char* tabBytes, uint64_t* heads, u
 	const uint32_t nW = (E + 63u) >> 6, eLast = E ? E - 1u : 0u;
 	// the map runs one window AHEAD of the ring's issue: window j's {table entry, meshlet} are in registers when its loads are issued, and the heads
 	// word of the window after it is already requested — no LDS round trip sits between a landed window and the next request
-	uint32_t startsBefore = 0; // (the same in every lane) commands that start in front of the mapped window, the first one not counted
+	uint32_t startsBefore = 0; // commands that start in front of the mapped window, the first one not counted (scalar)
 	uint32_t ePos = lane;      // the lane's entry in the window being mapped
 	uint32_t jMap = 0;         // the window being mapped
 	uint64_t H = heads[0];
-	uint32_t rkNext = 0, miNext = 0;
+	uint32_t rkNext = 0; // the lane's table entry in the mapped window (byte offset: an LDS POINTER kept across the ring decays to a generic one — flat
+	                     // loads, which count on vmcnt too, and hipcc then waits for the whole ring in front of every window: 3A dense 33 -> 50 us)
+	uint32_t miNext = 0;
 	auto map_next = [&]()
 	{
+		// (the heads word is the same in every lane: through the scalar unit, so that the running count of commands costs no vector instruction)
+#ifdef NV_WALK_VMAP
 		const uint32_t hlo = (uint32_t)H, hhi = (uint32_t)(H >> 32);
+#else
+		const uint32_t hlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)H), hhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(H >> 32));
+#endif
 		rkNext = __umul24(__builtin_amdgcn_mbcnt_hi(hhi, __builtin_amdgcn_mbcnt_lo(hlo, startsBefore)), CP_ENTRY);
 		startsBefore += (uint32_t)__builtin_popcount(hlo) + (uint32_t)__builtin_popcount(hhi);
 		const uint32_t e = ePos < eLast ? ePos : eLast; // the lanes past the list's end (and the ring's windows past its last) re-read the last entry: in range, unconditional
@@ -828,18 +838,22 @@ NV_DEV void packed_walk(const ClusterArgs& a, char* tabBytes, uint64_t* heads, u
 	};
 	map_next();
 	SlotB ring[CP_DB];
-	uint32_t rankOf[CP_DB]; // the lane's command in the slot's window: the byte offset of its table entry
-	auto issueP = [&](SlotB& slot, uint32_t& rk, uint64_t order)
+	uint32_t entryOf[CP_DB]; // the lane's command in the slot's window: the byte offset of its table entry
+	auto issueP = [&](SlotB& slot, uint32_t& te, uint64_t order)
 	{
-		rk = rkNext;
+		te = rkNext;
 		ringP_issue(slot, a, miNext, order);
 		map_next();
 	};
 #pragma unroll
 	for (int k = 0; k < CP_DB; ++k)
-		issueP(ring[k], rankOf[k], 0);
+		issueP(ring[k], entryOf[k], 0);
 	between();
-	const uint64_t certM = useCertP ? ~0ull : 0ull; // (no certified test: every valid lane takes the reference arithmetic)
+#ifdef NV_EXPERIMENTS
+	const uint64_t certM = useCertP ? ~0ull : 0ull; // (bit 20: no certified test — every valid lane takes the reference arithmetic)
+#else
+	(void)useCertP; // (the host takes the direct form only with filterK > 0: launch_cluster_mask)
+#endif
 	for (uint32_t j0 = 0; j0 < nW; j0 += CP_DB)
 	{
 #pragma unroll
@@ -847,10 +861,9 @@ NV_DEV void packed_walk(const ClusterArgs& a, char* tabBytes, uint64_t* heads, u
 		{
 			const uint32_t j = j0 + k;
 			// the coefficients, requested in front of the wait for the window's meshlets
-			const char* te = tabBytes + rankOf[k];
+			const char* te = tabBytes + entryOf[k];
 			const float4* tc = reinterpret_cast<const float4*>(te);
 			const float4 r0 = tc[0], r1 = tc[1], r2 = tc[2], r3 = tc[3];
-			const float2 r4 = reinterpret_cast<const float2*>(tc)[8];
 			ringB_wait<false, CP_DB - 1>(ring[k]);
 			uint64_t visM = 0;
 			if (j < nW)
@@ -864,18 +877,18 @@ NV_DEV void packed_walk(const ClusterArgs& a, char* tabBytes, uint64_t* heads, u
 				const float cx = __builtin_fmaf(r0.x, vx, __builtin_fmaf(r0.y, vy, __builtin_fmaf(r0.z, vz, r0.w)));
 				const float cy = __builtin_fmaf(r1.x, vx, __builtin_fmaf(r1.y, vy, __builtin_fmaf(r1.z, vz, r1.w)));
 				const float cz = __builtin_fmaf(r2.x, vx, __builtin_fmaf(r2.y, vy, __builtin_fmaf(r2.z, vz, r2.w)));
-				const float aK = r3.x, bK = r3.y, aR = r3.z, scale = r3.w, coneK = r4.x, is127 = r4.y;
-				float T = __builtin_fmaf(aK, __builtin_fabsf(vx), bK);
-				T = __builtin_fmaf(aK, __builtin_fabsf(vy), T);
-				T = __builtin_fmaf(aK, __builtin_fabsf(vz), T);
-				T = __builtin_fmaf(aR, __builtin_fabsf(rad), T);
+				const float T = r3.x, scale = r3.y, Tc = r3.z, is127 = r3.w; // (the draw's tK and tK coneK)
 				const float thrHi = __builtin_fmaf(scale, rad, T), thrLo = __builtin_fmaf(scale, rad, -T);
 				const float g1 = __builtin_fmaf(cz, cd.frustum[1], -(__builtin_fabsf(cx) * cd.frustum[0]));
 				const float g2 = __builtin_fmaf(cz, cd.frustum[3], -(__builtin_fabsf(cy) * cd.frustum[2]));
 				const float gn = cz - cd.znear;
 				const float gf = cd.zfar - cz;
 				const float g = __builtin_fminf(__builtin_fminf(g1, g2), __builtin_fminf(gn, gf));
+#ifdef NV_EXPERIMENTS
 				const uint64_t outM = __ballot(g < -thrHi) & certM, inM = __ballot(g > -thrLo) & certM;
+#else
+				const uint64_t outM = __ballot(g < -thrHi), inM = __ballot(g > -thrLo);
+#endif
 				uint64_t decidedM = outM | inM;
 				visM = inM;
 				if (cd.clusterBackfaceEnabled != 0 && (inM & validM))
@@ -888,7 +901,6 @@ NV_DEV void packed_walk(const ClusterArgs& a, char* tabBytes, uint64_t* heads, u
 					const float len = __builtin_amdgcn_sqrtf(__builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, cz * cz)));
 					const float rhs = __builtin_fmaf(kc * INV_127, len, scale * rad);
 					const float D = lhs - rhs;
-					const float Tc = T * coneK;
 					const uint64_t cullM = __ballot(D > Tc), keepM = __ballot(D < -Tc);
 					decidedM = outM | (inM & (cullM | keepM)); // (a cluster outside the frustum is decided whatever its cone says)
 					visM = inM & keepM;
@@ -935,7 +947,7 @@ NV_DEV void packed_walk(const ClusterArgs& a, char* tabBytes, uint64_t* heads, u
 					nout[j] = validM & ~outM;
 				}
 			}
-			issueP(ring[k], rankOf[k], visM);
+			issueP(ring[k], entryOf[k], visM);
 		}
 	}
 	ring_drain();
@@ -1209,8 +1221,8 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				r.fold[3] = a.cd.frustum[0] * r.f.b[0];
 				r.fold[7] = a.cd.frustum[2] * r.f.b[1];
 			}
-			if (!useFilter) // an infinite margin: nothing is certainly outside.  (Here, lane-parallel once per segment: as a test where the filter loop
-				r.f.tK = __builtin_inff(); // broadcasts a draw's filter, hipcc materialised the uniform flag with two vector instructions per COMMAND)
+			if (!useFilter && !DIRECT) // an infinite margin: nothing is certainly outside.  (Here, lane-parallel once per segment: as a test where the filter loop
+				r.f.tK = __builtin_inff(); // broadcasts a draw's filter, hipcc materialised the uniform flag with two vector instructions per COMMAND.  The direct forms have no filter loop; the packed walk's certified test reads tK.)
 		};
 
 		const bool useCert = a.filterK > 0.0f && !NV_DBG(a, 1048576u); // bit 20 (experiments): pass B with the reference arithmetic only

@@ -175,6 +175,11 @@ def test_margins_cover_the_distance_to_the_reference(shim, case):
     assert drift.max() < 0.05, "%s: folding the plane coefficients moves a distance by %.3f of T" % (name, drift.max())
     assert (ok & out_f).sum() >= 0.97 * (ok & out_m).sum(), "%s: the pool-wide margin gives up %d of %d certain rejections" % (name, (ok & out_m & ~out_f).sum(), (ok & out_m).sum())
     assert (ok & (out_m | in_m)).mean() > 0.9  # the margins must not be so wide that nothing is decided
+    # the direct form's packed walk (clustercull.hip packed_walk, round 6) runs the TWO-SIDED test with the per-draw margin tK as well: both of its certain
+    # frustum decisions against the reference's predicate (its cone decisions with tK coneK: below)
+    in_t = g > -fma64(scale, rad, -tK)
+    assert not (ok & in_t & ~vis_ref).any(), name
+    assert (ok & (out_f | in_t)).sum() >= 0.97 * (ok & (out_m | in_m)).sum(), name
     # cone
     k, kc = ml["cone_axis"].astype(f32), ml["cone_cutoff"].astype(f32)
     w = np.stack([fma64(m[..., 3 * r], k[..., 0], fma64(m[..., 3 * r + 1], k[..., 1], (m[..., 3 * r + 2] * k[..., 2]).astype(f32))) for r in range(3)], axis=-1)
@@ -191,6 +196,8 @@ def test_margins_cover_the_distance_to_the_reference(shim, case):
         ratio_d = np.where(okc, np.abs(D.astype(np.float64) - D_ref) / Tc.astype(np.float64), 0.0)
         assert ratio_d.max() < 0.5, "%s: |D~ - D_ref| reaches %.3f of the cone margin" % (name, ratio_d.max())
         assert not (okc & (((D > Tc) & ~cull_ref) | ((D < -Tc) & cull_ref))).any(), name
+        Tct = (tK * coneK).astype(f32)  # the packed walk's cone margin
+        assert not (okc & np.isfinite(Tct) & (((D > Tct) & ~cull_ref) | ((D < -Tct) & cull_ref))).any(), name
 
     # ---- the same for a sample of lanes in exact rational arithmetic: every FMA = the exact a b + c rounded once to fp32
     rng = np.random.default_rng(3)
