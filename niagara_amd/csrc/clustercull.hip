@@ -2938,9 +2938,16 @@ bool clustercull_takes_packed(const ClusterArgs& a, int late, bool soa, bool dir
 // pass (SoA mirror only; the host's guess from the previous launch's statistic — a wrong guess only costs speed)
 // expectedCmds: the host's guess of the indirect command count (the previous launch's, or the explicit override): the dealing plan travels
 // with the arguments for it (dealing.h); 0 = no guess
+bool clustercull_takes_packed(const ClusterArgs& a, int late, bool soa, bool direct);
+
 int launch_cluster_mask(hipStream_t stream, const ClusterArgs& args, int late, bool soa, uint32_t maskBlocks, bool shallow, bool direct, uint32_t expectedCmds)
 {
 	ClusterArgs a = args;
+	// The dealing's delay compensation was calibrated on the filter form (a wave of config 3A lives ~11 us).  A wave of the packed walk lives 18-23 us and
+	// is bound by vector issue, so a later generation — the younger waves of every SIMD — falls behind by more than its start delay: 2.5 x the compensation
+	// (round 6 sweep 0 / 100 / 200 / 300 / 400 %: contract chain's cull launch 26.8 / 25.9 / 24.8 / 24.7 / 25.3 us, 3A dense 35.0 / 33.0 / 33.0 / 32.1 / 32.7)
+	if (clustercull_takes_packed(a, late, soa, direct))
+		a.dealScale = a.dealScale * 5u / 2u;
 	a.plan = deal_plan(expectedCmds, late ? CC_CHUNK_LATE : CC_CHUNK, !late, maskBlocks * CC_WAVES, a.cullWavesMagic, a.generations, a.genBlocks, maskBlocks, a.dealScale,
 	                   a.scatterTiles, a.tilesMagic);
 	if (expectedCmds == 0)
