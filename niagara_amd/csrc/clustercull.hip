@@ -79,7 +79,7 @@ NV_DEV DrawUniform load_draw(const NvMeshDraw* draws, uint32_t drawId)
 NV_DEV NvMeshTaskCommand load_command(const NvMeshTaskCommand* commands, uint32_t ci)
 {
 	k_u32p c = (k_u32p)(uintptr_t)(commands + ci);
-	return NvMeshTaskCommand{ c[0], c[1], c[2], c[3], c[4] };
+	return NvMeshTaskCommand{ c[0], c[1], c[2] < 64u ? c[2] : 64u, c[3], c[4] }; // (taskCount above TASK_WGSIZE: the reference's invocations are lanes 0 .. 63, clustercull.comp.glsl:66-70)
 }
 
 // The reference reads meshlets[mi] for all 64 lanes and masks the result with `valid` afterwards
@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 			const uint32_t* p = reinterpret_cast<const uint32_t*>(a.commands + myIdx);
 			r.drawId = p[0];
 			r.taskOffset = p[1];
-			r.taskCount = p[2];
+			r.taskCount = p[2] < 64u ? p[2] : 64u; // (a taskCount above TASK_WGSIZE means 64: the reference's invocations are lanes 0 .. 63, clustercull.comp.glsl:66-70 — drawcull never writes one, a caller's list may)
 			r.lateDrawVisibility = p[3];
 			r.meshletVisibilityOffset = p[4];
 		}
@@ -2189,7 +2189,7 @@ __global__ __launch_bounds__(CH_THREADS) void cluster_hiz_kernel(ClusterArgs a)
 				const uint32_t* p = reinterpret_cast<const uint32_t*>(a.commands + idx);
 				drawId = p[0];
 				taskOffset = p[1];
-				taskCount = p[2];
+				taskCount = p[2] < 64u ? p[2] : 64u;
 				lateDrawVisibility = p[3];
 				mvo = p[4];
 			}
@@ -2538,7 +2538,7 @@ NV_DEV BitsCommand bits_load_command(const ClusterArgs& a, uint32_t idx, bool li
 	BitsCommand c;
 	c.drawId = p[0];
 	c.taskOffset = p[1];
-	c.taskCount = p[2];
+	c.taskCount = p[2] < 64u ? p[2] : 64u;
 	c.mvo = p[4];
 	return c;
 }

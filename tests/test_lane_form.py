@@ -242,3 +242,55 @@ def test_a_fresh_contexts_first_frame_takes_the_direct_forms_for_its_own_drawcul
         assert v.get("cull_filter_ring4", 0) + v.get("cull_filter_ring8", 0) == 1 and "cull_direct" not in v and "cull_direct_packed" not in v, v
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("shape", ["ragged", "sixteens", "ones", "empties", "full", "over64", "single"])
+def test_packed_walk_command_shapes(shape):
+    """The direct form's packed walk (cluster_mask_kernel PACK, round 6) lays the VALID meshlets of a wave's 64 commands end to end and tests them in windows
+    of 64: command sizes decide where the windows' borders fall.  Shapes that put them everywhere: any taskCount in 0 .. 64 (empty commands inside a segment,
+    in front of it, behind it), sizes that divide 64 (a border on every fourth command), one meshlet per command (64 commands = one window), nothing but empty
+    commands, full commands only (every window = one command), taskCount above 64 (the reference tests lanes 0 .. 63: clustercull.comp.glsl:66-70) and a pass
+    of ONE command.  Early pass without visibility bits (the walk's ballots and statistic) and the late pass with HiZ (the walk as the first stage: DEFER),
+    each against the oracle, pinned direct (NV_OPT_CULL_FORM 2) and — the same lists — one command per wave iteration (4)."""
+    rng = np.random.default_rng(11)
+    ctx = P.Context()
+    try:
+        draws, meshlets, commands, n = _instanced_scene(700, 9, 300)
+        draws["position"] *= np.float32(0.05)
+        tc = commands["taskCount"][:n]
+        if shape == "ragged":
+            tc[:] = rng.integers(0, 65, n)
+        elif shape == "sixteens":
+            tc[:] = rng.choice([16, 32, 48, 64], n)
+        elif shape == "ones":
+            tc[:] = 1
+        elif shape == "empties":
+            tc[:] = 0
+            tc[rng.integers(0, n, 5)] = rng.integers(1, 65, 5)
+        elif shape == "over64":
+            tc[::3] = rng.integers(65, 1000, len(tc[::3]))
+        elif shape == "single":
+            n = 1
+        t64 = np.minimum(commands["taskCount"][:len(commands)].astype(np.int64), 64)
+        commands["meshletVisibilityOffset"][:] = (np.concatenate([[0], np.cumsum(t64)[:-1]]) + 3).astype(np.uint32)  # words shared by neighbours
+        pyr, gp = _pyramid(ctx)
+        cd = host.build_cull_data(cam_pos=(0, 0, 25), draw_count=len(draws), cullingEnabled=1, clusterBackfaceEnabled=1)
+        cd["pyramidWidth"], cd["pyramidHeight"] = pyr.width, pyr.height
+        late_cd = cd.copy()
+        late_cd["clusterOcclusionEnabled"] = 1
+        mvb0 = rng.integers(0, 2 ** 32, int(t64.sum()) // 32 + 8, dtype=np.uint64).astype(np.uint32)
+        p = _Pass(ctx, draws, meshlets, commands, n, pyr, gp)
+        for form, variant in ((2, "cull_direct_packed"), (4, "cull_direct")):
+            ctx.set_option(P.NV_OPT_CULL_FORM, form)
+            ctx.profile_variants()
+            for rep in range(2):  # (both banks of the tile counters)
+                p.run(cd, 0, None)
+                p.run(late_cd, 1, mvb0)
+            v = ctx.profile_variants()
+            assert v.get(variant, 0) == 4 and v.get("hiz_stage", 0) == 2, (form, v)
+        nocone = cd.copy()
+        nocone["clusterBackfaceEnabled"] = 0
+        ctx.set_option(P.NV_OPT_CULL_FORM, 2)
+        p.run(nocone, 0, None)
+    finally:
+        ctx.close()

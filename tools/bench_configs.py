@@ -207,7 +207,9 @@ def config3b(ctx, iters, n_draws=15625 * 4, fused=False):
             and bool((pipe.dvb == 1).all().item()))
     return dict(config="3B: drawcull<0,1> -> tasksubmit -> clustercull<0> -> clustersubmit" + (" (NV_OPT_FUSED_SUBMIT + FUSED_COUNT_RESET: 4 launches)" if fused else " (8 launches)"), draws=n_draws, task_commands=cmds, meshlets_tested=tested,
                 visible=int(pipe.ccb[0].item()), step_us=wall_plain, step_us_with_events=wall, step_us_graph_replay=wall_graph, cluster_cull_us=k_us, cluster_scatter_us=prof["cluster_scatter"][0] / max(1, prof["cluster_scatter"][1]) * 1e3,
-                drawcull_us=prof["drawcull"][0] / max(1, prof["drawcull"][1]) * 1e3, meshlets_per_s=tested / (wall_plain * 1e-6), parity=verdict(same))
+                drawcull_us=prof["drawcull"][0] / max(1, prof["drawcull"][1]) * 1e3, meshlets_per_s=tested / (wall_plain * 1e-6), parity=verdict(same),
+                kernel_variants=ctx.profile_variants(),
+                **({"roofline_valu": {"cull launch (direct form's packed walk)": valu_roofline("cluster_mask_kernel<false, true, false, 8, true, false, true>", k_us)}} if n_draws >= 100000 else {}))
 
 
 def config4(ctx, iters, size=4096, n_draws=15625, cpd=10, copies=4):
@@ -502,7 +504,7 @@ def config_frame(ctx, iters, n_draws=1_000_000, lod0=2200, size=4096, copies=3, 
                meshlets_tested_per_frame=tested, meshlets_per_s=tested / (frame_us * 1e-6), draws_per_s=2 * n_draws / (frame_us * 1e-6),
                frames_per_s=1e6 / frame_us, oracle_frames_simulated=simulated, frames_on_checked_copy=frames_of[c], parity=verdict(same))
     out["roofline_valu"] = {"cluster_hiz_kernel": valu_roofline("cluster_hiz_kernel", breakdown["late_cluster_hiz_us"]),
-                            "late cull launch (direct form, frustum / cone ballots)": valu_roofline("cluster_mask_kernel<false, true, false, 8, true, true>", breakdown["late_cluster_cull_us"])}
+                            "late cull launch (direct form's packed walk, frustum / cone ballots)": valu_roofline("cluster_mask_kernel<false, true, false, 8, true, true, true>", breakdown["late_cluster_cull_us"])}
     if cpp_driver:
         out["cpp_driver"] = frame_driver_timed(meshes, meshlets, draws, slots, depth_h, cd, size, fused, iters)
     ctx.set_option(P.NV_OPT_FUSED_COUNT_RESET, 0)
@@ -631,7 +633,8 @@ def cluster_config(ctx, iters, label, n_draws=156250, cpd=10, aos=False, scene_r
     scat = prof["cluster_scatter"][0] / max(1, prof["cluster_scatter"][1]) * 1e3
     return dict(config=label, meshlets=m, visible=total, commands_with_survivors=round(with_survivor, 4), cull_us=k_us, scatter_us=scat, step_us=wall, step_us_with_events=prof["wall_with_events_us"],
                 algorithmic_bytes=algo, achieved_GBs=algo / k_us / 1e3, frac=algo / k_us / 1e3 / HBM, pass_frac=(algo - n * 8 + total * 4) / (k_us + scat) / 1e3 / HBM,
-                meshlets_per_s=m / (wall * 1e-6), parity=verdict(same))
+                meshlets_per_s=m / (wall * 1e-6), parity=verdict(same),
+                **({"roofline_valu": {"cull launch (direct form's packed walk)": valu_roofline("cluster_mask_kernel<false, true, false, 8, true, false, true>", k_us)}} if with_survivor > 0.5 and not aos else {}))
 
 
 def config_task(ctx, iters, n_draws=15625, cpd=10, late=0, copies=4):

@@ -36,8 +36,12 @@ HALF = re.compile(r"^v_(cmp|cndmask|min|max|med3|floor|ceil|trunc|rndne|fract|cv
 # kernel (substring of the demangled name) -> (source file, substring of the MANGLED name of the instance the frame / config runs, what the reference's own arithmetic is)
 KERNELS = {
     "cluster_hiz_kernel": ("clustercull.hip", "cluster_hiz_kernelILb1ELb1E", "207 per probe (reference sphere + projectSphere + the four texel tests)"),
-    "cluster_mask_kernel<false, true, false, 8, true, true>": ("clustercull.hip", "cluster_mask_kernelILb0ELb1ELb0ELi8ELb1ELb1E", "~60 per command (certified frustum + cone test)"),
-    "cluster_mask_kernel<false, true, false, 8, true, false>": ("clustercull.hip", "cluster_mask_kernelILb0ELb1ELb0ELi8ELb1ELb0E", "~60 per command (certified frustum + cone test)"),
+    # (round 6: the direct form's packed walk — windows of 64 valid meshlets; the last template argument)
+    "cluster_mask_kernel<false, true, false, 8, true, true, true>": ("clustercull.hip", "cluster_mask_kernelILb0ELb1ELb0ELi8ELb1ELb1ELb1E", "~50 per window of 64 meshlets (certified frustum + cone test)"),
+    "cluster_mask_kernel<false, true, false, 8, true, false, true>": ("clustercull.hip", "cluster_mask_kernelILb0ELb1ELb0ELi8ELb1ELb0ELb1E", "~50 per window of 64 meshlets (certified frustum + cone test)"),
+    "cluster_mask_kernel<false, true, false, 8, true, true, false>": ("clustercull.hip", "cluster_mask_kernelILb0ELb1ELb0ELi8ELb1ELb1ELb0E", "~60 per command (certified frustum + cone test)"),
+    "cluster_mask_kernel<false, true, false, 8, true, false, false>": ("clustercull.hip", "cluster_mask_kernelILb0ELb1ELb0ELi8ELb1ELb0ELb0E", "~60 per command (certified frustum + cone test)"),
+    "cluster_bits_kernel": ("clustercull.hip", "cluster_bits_kernelILb1ELb1E", "~60 per set bit (certified frustum + cone test)"),
     "trianglecull_kernel": ("trianglecull.hip", "trianglecull_kernel", "122 per vertex + 45 per triangle: 13.5 M per 131 072-cluster pass"),
     "draw_decide_kernel": ("drawcull.hip", "draw_decide_kernel", "~95 per draw (sphere, frustum, LOD select; + projectSphere and the probe in the late pass)"),
 }
@@ -97,6 +101,16 @@ def roofline_valu(kernel, measured_us, units=None):
            "note": "class mix from the kernel's compiled text (static), instruction count from the counters (dynamic)"}
     if "SQ_INSTS_SALU" in entry:
         out["salu_insts"] = entry["SQ_INSTS_SALU"]
+    # (round 6) the EXECUTED class counts, where the counters pass collected them: fp32 multiply-adds / multiplies / adds at the full-rate
+    # cost, transcendentals at the quarter-rate cost, conversions at the half-rate cost — and everything the counters do not classify (compares, selects,
+    # min / max, v_fma_mix, moves, lane operations: SQ_INSTS_VALU minus the classified ones) at the CHEAPEST cost, so that this floor can only be too low
+    cls = {c: entry.get("SQ_INSTS_VALU_" + c) for c in ("FMA_F32", "MUL_F32", "ADD_F32", "TRANS_F32", "CVT", "INT32")}
+    if all(v is not None for v in cls.values()):
+        rest = max(0.0, insts - sum(cls.values()))
+        cyc = COST["full"] * (cls["FMA_F32"] + cls["MUL_F32"] + cls["ADD_F32"] + cls["INT32"] + rest) + COST["quarter"] * cls["TRANS_F32"] + COST["half"] * cls["CVT"]
+        fl = cyc / SIMDS / (CLOCK_GHZ * 1e3)
+        out["executed"] = {"class_counts": dict(cls, unclassified=rest), "floor_us_lower_bound": fl, "frac_lower_bound": fl / measured_us if measured_us else None,
+                           "note": "class counts from the SQ_INSTS_VALU_* counters (executed); unclassified instructions priced at the cheapest class"}
     if units:
         out["insts_per_" + units[0]] = insts * 64.0 / units[1] if units[0] in ("probe", "lane") else insts / units[1]
     return out
