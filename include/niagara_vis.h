@@ -240,6 +240,8 @@ int nv_profile_variants(nv_context* ctx, uint32_t out_count[NV_VARIANT_SLOTS]);
  *                     4 = as 3, and one command per wave iteration also where the direct form would walk packed windows of 64 valid
  *                         meshlets (early form without visibility bits: the cluster pass behind drawcull's LOD select, the late pass's
  *                         first stage);
+ *                     5 = as 2, but the early pass with visibility bits walks packed windows too (the valid meshlets of the commands that have a
+ *                         set bit) instead of testing one lane per set bit;
  *   NV_OPT_CULL_RING  0 = by the last launch's command count, 4 = the 4-deep load ring (passes of a few hundred thousand commands),
  *                     8 = the 8-deep ring (long streams, late passes). */
 #define NV_OPT_CULL_FORM 5

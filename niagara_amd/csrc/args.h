@@ -170,6 +170,7 @@ struct ClusterArgs
 	uint32_t fusedReset; // NV_OPT_FUSED_COUNT_RESET
 	uint32_t fusedSubmit; // NV_OPT_FUSED_SUBMIT
 	uint32_t deferHiz;   // late pass with HiZ: the cull kernel leaves frustum / cone ballots and no tile counts, cluster_hiz_kernel finishes
+	uint32_t packBits;   // the early pass WITH visibility bits as a packed walk too (entries = the valid meshlets of the commands that have a set bit) instead of one lane per set bit / one wave per command
 	uint32_t packDirect; // the direct form walks windows of 64 valid meshlets (clustercull.hip PACK) where it applies; 0: one command per wave iteration (NV_OPT_CULL_FORM 4)
 	unsigned long long* countsSink; // nv_set_counts_sink (nullptr: off)
 };

@@ -735,20 +735,32 @@ NV_DEV void ringB_issue(SlotB& s, const ClusterArgs& a, uint32_t taskOffset, uin
 }
 
 // the packed direct form: the lane's meshlet index comes from the wave's entry -> command map (one lane = one ENTRY of the segment's flattened meshlet list)
-NV_DEV void ringP_issue(SlotB& s, const ClusterArgs& a, uint32_t mi, uint64_t order)
+template <bool BITS>
+NV_DEV void ringP_issue(SlotB& s, const ClusterArgs& a, uint32_t mi, uint32_t offw, uint64_t order)
 {
 	const uint32_t off8 = mi * 8u, off4 = mi * 4u;
 #ifdef NV_PLAIN_LOADS
 	(void)order;
 	s.bounds = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(a.soaBounds) + off8);
 	s.cone = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.soaCones) + off4);
+	s.mvbWord = BITS ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.mvb) + offw) : 0u;
 #else
-	asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %2, %3" NV_POLICY_B "\n\tglobal_load_dword %1, %4, %5" NV_POLICY_CONE
-	             : "=&v"(s.bounds), "=&v"(s.cone)
-	             : "v"(off8), "s"(a.soaBounds), "v"(off4), "s"(a.soaCones), "s"(order)
-	             : "memory");
+	if (BITS)
+	{
+		asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %3, %4" NV_POLICY_B "\n\tglobal_load_dword %1, %5, %6" NV_POLICY_CONE "\n\tglobal_load_dword %2, %7, %8"
+		             : "=&v"(s.bounds), "=&v"(s.cone), "=&v"(s.mvbWord)
+		             : "v"(off8), "s"(a.soaBounds), "v"(off4), "s"(a.soaCones), "v"(offw), "s"(a.mvb), "s"(order)
+		             : "memory");
+	}
+	else
+	{
+		asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %2, %3" NV_POLICY_B "\n\tglobal_load_dword %1, %4, %5" NV_POLICY_CONE
+		             : "=&v"(s.bounds), "=&v"(s.cone)
+		             : "v"(off8), "s"(a.soaBounds), "v"(off4), "s"(a.soaCones), "s"(order)
+		             : "memory");
+		s.mvbWord = 0;
+	}
 #endif
-	s.mvbWord = 0;
 }
 
 template <bool BITS, int YOUNGER>
@@ -788,7 +800,7 @@ NV_DEV void ring_release(SlotB& s) { asm volatile("; released %0 %1 %2" : "+v"(s
 // with tK, against the reference's decisions); a pool with a non-finite record has tK = inf and every lane takes the reference arithmetic.
 // Table entry (CP_ENTRY bytes per non-empty command, in the order of the commands; LDS is what bounds the six workgroups per CU):
 //   +0 the coefficients: m[0..2], b0 | m[3..5], b1 | m[6..8], b2 | tK, scale, tK coneK, is127  (64 bytes)
-//   +64 taskOffset - the command's first entry   +68 first entry | the command's lane in the segment << 16   (+72: padding — 16-byte reads)
+//   +64 taskOffset - the command's first entry   +68 BITS: meshletVisibilityOffset - the command's first entry   +72 first entry | the command's lane in the segment << 16
 constexpr uint32_t CP_ENTRY = 80, CP_ENTRY_HEAD = 64;
 static_assert(CP_ENTRY % 16 == 0, "the coefficients are read with ds_read_b128");
 
@@ -806,7 +818,7 @@ NV_DEV void walk_coefficients(char* at, const FilterDraw& f)
 // segDrawId: lane c = the drawId of the segment's c-th command (the reference arithmetic's draw comes through a lane permutation: rare).
 // between(): what the caller does between the ring's first requests and the first window's test (PACK: the MeshDraw gather's wait and the
 // coefficients — the map needs the commands only, so the dependent chain of a wave's start is commands -> {draws, first windows} -> coefficients).
-template <class Between>
+template <bool BITS, class Between>
 NV_DEV void packed_walk(const ClusterArgs& a, char* tabBytes, uint64_t* heads, uint64_t* nout, uint32_t lane, uint32_t E, uint32_t segDrawId, bool useCertP, Between&& between)
 {
 	const NvCullData& cd = a.cd;
@@ -819,7 +831,7 @@ NV_DEV void packed_walk(const ClusterArgs& a, char* tabBytes, uint64_t* heads, u
 	uint64_t H = heads[0];
 	uint32_t rkNext = 0; // the lane's table entry in the mapped window (byte offset: an LDS POINTER kept across the ring decays to a generic one — flat
 	                     // loads, which count on vmcnt too, and hipcc then waits for the whole ring in front of every window: 3A dense 33 -> 50 us)
-	uint32_t miNext = 0;
+	uint32_t miNext = 0, wNext = 0; // the lane's meshlet (and, BITS, the byte offset of its visibility word) in the mapped window
 	auto map_next = [&]()
 	{
 		// (the heads word is the same in every lane: through the scalar unit, so that the running count of commands costs no vector instruction)
@@ -831,7 +843,14 @@ NV_DEV void packed_walk(const ClusterArgs& a, char* tabBytes, uint64_t* heads, u
 		rkNext = __umul24(__builtin_amdgcn_mbcnt_hi(hhi, __builtin_amdgcn_mbcnt_lo(hlo, startsBefore)), CP_ENTRY);
 		startsBefore += (uint32_t)__builtin_popcount(hlo) + (uint32_t)__builtin_popcount(hhi);
 		const uint32_t e = ePos < eLast ? ePos : eLast; // the lanes past the list's end (and the ring's windows past its last) re-read the last entry: in range, unconditional
-		miNext = *reinterpret_cast<const uint32_t*>(tabBytes + rkNext + CP_ENTRY_HEAD) + e;
+		if (BITS)
+		{
+			const uint2 h = *reinterpret_cast<const uint2*>(tabBytes + rkNext + CP_ENTRY_HEAD); // {taskOffset - first entry, meshletVisibilityOffset - first entry}
+			miNext = h.x + e;
+			wNext = ((h.y + e) >> 5) * 4u;
+		}
+		else
+			miNext = *reinterpret_cast<const uint32_t*>(tabBytes + rkNext + CP_ENTRY_HEAD) + e;
 		ePos += 64u;
 		++jMap;
 		H = heads[jMap]; // (jMap <= 64 + 2 CP_DB: zero past the segment's last window — the lanes stay on the last command)
@@ -842,7 +861,7 @@ NV_DEV void packed_walk(const ClusterArgs& a, char* tabBytes, uint64_t* heads, u
 	auto issueP = [&](SlotB& slot, uint32_t& te, uint64_t order)
 	{
 		te = rkNext;
-		ringP_issue(slot, a, miNext, order);
+		ringP_issue<BITS>(slot, a, miNext, wNext, order);
 		map_next();
 	};
 #pragma unroll
@@ -864,13 +883,22 @@ NV_DEV void packed_walk(const ClusterArgs& a, char* tabBytes, uint64_t* heads, u
 			const char* te = tabBytes + entryOf[k];
 			const float4* tc = reinterpret_cast<const float4*>(te);
 			const float4 r0 = tc[0], r1 = tc[1], r2 = tc[2], r3 = tc[3];
-			ringB_wait<false, CP_DB - 1>(ring[k]);
+			// (BITS: the lane's bit within its visibility word — the entry's bit base again, and the lane's entry: cheaper than a register per ring slot)
+			uint32_t bitShift = 0;
+			if (BITS)
+			{
+				const uint32_t e = j * 64u + lane;
+				bitShift = (*reinterpret_cast<const uint32_t*>(te + CP_ENTRY_HEAD + 4) + (e < eLast ? e : eLast)) & 31u;
+			}
+			ringB_wait<BITS, CP_DB - 1>(ring[k]);
 			uint64_t visM = 0;
 			if (j < nW)
 			{
 				const uint32_t b0 = (uint32_t)ring[k].bounds, b1 = (uint32_t)(ring[k].bounds >> 32), cone = ring[k].cone;
 				const uint32_t left = E - j * 64u;
-				const uint64_t validM = left >= 64u ? ~0ull : (1ull << left) - 1ull;
+				uint64_t validM = left >= 64u ? ~0ull : (1ull << left) - 1ull;
+				if (BITS) // the early pass with visibility bits: only last frame's visible clusters can be visible (clustercull.comp.glsl:91-92) — the others decide nothing
+					validM &= __ballot((ring[k].mvbWord >> bitShift & 1u) != 0);
 				// certified_visible, one lane = one cluster
 				const float vx = half_bits_to_float(b0 & 0xffffu), vy = half_bits_to_float(b0 >> 16), vz = half_bits_to_float(b1 & 0xffffu);
 				const float rad = half_bits_to_float(b1 >> 16);
@@ -910,7 +938,7 @@ NV_DEV void packed_walk(const ClusterArgs& a, char* tabBytes, uint64_t* heads, u
 				if (undecidedM && !NV_DBG(a, 536870912u)) // the reference's arithmetic (clustercull.comp.glsl:72-80,102-108) for the lanes inside a margin, as cull_command evaluates it.  (bit 29, experiments: skipped — what the undecided lanes cost)
 				{
 					// the lane's draw: the drawId of its command, from the lane of the segment that holds the command (all lanes take part in the permutation)
-					const uint32_t cmdLane = *reinterpret_cast<const uint32_t*>(te + CP_ENTRY_HEAD + 4) >> 16;
+					const uint32_t cmdLane = *reinterpret_cast<const uint32_t*>(te + CP_ENTRY_HEAD + 8) >> 16;
 					const uint32_t drawId = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(cmdLane << 2), (int)segDrawId);
 					bool visible = false;
 					if (undecidedM >> lane & 1ull)
@@ -944,7 +972,8 @@ NV_DEV void packed_walk(const ClusterArgs& a, char* tabBytes, uint64_t* heads, u
 				if (lane == 0)
 				{
 					heads[j] = visM; // (window j's heads were consumed CP_DB + 1 windows ago)
-					nout[j] = validM & ~outM;
+					if (!BITS)
+						nout[j] = validM & ~outM;
 				}
 			}
 			issueP(ring[k], entryOf[k], visM);
@@ -1036,7 +1065,7 @@ NV_DEV uint32_t deal_wave(const DealPlan& p, uint32_t w, uint32_t lane, uint32_t
 template <bool LATE, bool SOA, bool BITS, int CC_DA, bool DIRECT = false, bool DEFER = false, bool PACK = false>
 __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs a)
 {
-	static_assert(!PACK || (DIRECT && SOA && !LATE && !BITS), "the packed walk is a form of the direct early pass without visibility bits");
+	static_assert(!PACK || (DIRECT && SOA && !LATE), "the packed walk is a form of the direct early pass");
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t w = blockIdx.x * CC_WAVES + wave;
@@ -1046,7 +1075,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 	// statistic): 6.3 KB per wave, 25.1 KB per workgroup.
 	__shared__ float4 s_tab[PACK ? CC_WAVES : 1][PACK ? 64 : 1][CP_ENTRY / 16];
 	__shared__ uint64_t s_heads[PACK ? CC_WAVES : 1][PACK ? CP_WINDOWS : 1];
-	__shared__ uint64_t s_nout[PACK ? CC_WAVES : 1][PACK ? CP_WINDOWS : 1];
+	__shared__ uint64_t s_nout[PACK && !BITS ? CC_WAVES : 1][PACK && !BITS ? CP_WINDOWS : 1];
 
 	// late pass: the pyramid's level offsets in LDS, one copy per wave (written and read by the same wave: no barrier).
 	// Built from the scalar kernel arguments with constant indices — a per-lane index into the argument array would be
@@ -1239,7 +1268,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 			// (PACK: the scan over the commands' sizes in front of the first uncounted load — in the experiments build it carries an exec-mask assertion, i.e. a
 			// path out of the kernel, which must not start with loads in flight)
 			uint32_t packIncl = 0;
-			if constexpr (PACK)
+			if constexpr (PACK && !BITS)
 				packIncl = wave_scan_inclusive_u32(r.taskCount < 64u ? r.taskCount : 64u);
 			meshletsSeen += r.taskCount < 64u ? r.taskCount : 64u; // (the fill statistic: word 2 of a tile counter's line, summed by the scatter launch)
 			gather_issue();
@@ -1299,17 +1328,49 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				// ---- the direct form as a packed walk (packed_walk above): the segment's valid meshlets in windows of 64.
 				// (Unconditional, also for a segment of empty commands only — E = 0, no window, the ring's requests re-read meshlet 0: a branch around the walk
 				// would give the gather a second wait site, and hipcc joins the two with copies of registers whose loads are still in flight.)
-				candMask = __ballot(r.taskCount != 0); // every valid command (lanes without a command hold 0)
-				const uint32_t tcc = r.taskCount < 64u ? r.taskCount : 64u;
+				uint32_t tcc = r.taskCount; // (<= 64; lanes without a command hold 0)
+				if constexpr (BITS)
+				{
+					// The early pass with visibility bits (clustercull.comp.glsl:86-95): a command none of whose clusters was visible last frame has no entry at
+					// all, and a window's lanes whose bit is clear decide nothing.  The commands' visibility words — three per command at most — are requested
+					// behind the MeshDraw gather and waited for together with it: the map needs them (chain: commands -> {draws, words} -> windows).
+					const uint32_t mvo = r.meshletVisibilityOffset;
+					const uint32_t wFirst = tcc ? mvo >> 5 : 0u, wLast = tcc ? (mvo + tcc - 1u) >> 5 : 0u;
+					uint32_t w0, w1, w2;
+					{
+						const uint32_t o0 = wFirst * 4u, o1 = (wFirst + 1u < wLast ? wFirst + 1u : wLast) * 4u, o2 = (wFirst + 2u < wLast ? wFirst + 2u : wLast) * 4u;
+#ifdef NV_PLAIN_LOADS
+						w0 = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.mvb) + o0);
+						w1 = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.mvb) + o1);
+						w2 = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.mvb) + o2);
+#else
+						asm volatile("s_nop 4\n\tglobal_load_dword %0, %3, %6\n\tglobal_load_dword %1, %4, %6\n\tglobal_load_dword %2, %5, %6"
+						             : "=&v"(w0), "=&v"(w1), "=&v"(w2)
+						             : "v"(o0), "v"(o1), "v"(o2), "s"(a.mvb)
+						             : "memory");
+#endif
+					}
+					NV_COUNTED_WAIT("s_waitcnt vmcnt(%5) ; nv_ready %0 %1 %2 %3 %4" : "+v"(g0), "+v"(g1), "+v"(w0), "+v"(w1), "+v"(w2) : "i"(0) : "memory"); // the gather and the words
+					const uint32_t sh = mvo & 31u;
+					const uint32_t lo = sh ? (w0 >> sh) | (w1 << (32u - sh)) : w0, hi = sh ? (w1 >> sh) | (w2 << (32u - sh)) : w1;
+					const uint64_t valid = tcc >= 64u ? ~0ull : (1ull << tcc) - 1ull;
+					if (((((uint64_t)hi << 32) | lo) & valid) == 0)
+						tcc = 0; // nothing of this command can be visible
+					packIncl = wave_scan_inclusive_u32(tcc); // (every uncounted load has landed: the experiments build's exec-mask assertion may leave here)
+				}
+				candMask = __ballot(tcc != 0); // every command that has an entry
 				const uint32_t excl = packIncl - tcc; // the command's first entry
 				const uint32_t E = (uint32_t)__builtin_amdgcn_readlane((int)packIncl, 63);
-				const uint32_t rankC = __builtin_amdgcn_mbcnt_hi((uint32_t)(candMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)candMask, 0u)); // among the non-empty commands
+				const uint32_t rankC = __builtin_amdgcn_mbcnt_hi((uint32_t)(candMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)candMask, 0u)); // among the commands with entries
 				char* tabBytes = reinterpret_cast<char*>(s_tab[wave]);
 				char* myEntry = tabBytes + rankC * CP_ENTRY;
 				uint64_t* heads = s_heads[wave];
-				uint64_t* nout = s_nout[wave];
-				if (tcc || (candMask == 0 && lane == 0)) // (no command at all: entry 0 = meshlet 0)
-					*reinterpret_cast<uint2*>(myEntry + CP_ENTRY_HEAD) = make_uint2(tcc ? r.taskOffset - excl : 0u, excl | lane << 16);
+				uint64_t* nout = BITS ? nullptr : s_nout[wave];
+				if (tcc || (candMask == 0 && lane == 0)) // (no command at all: entry 0 = meshlet 0, visibility word 0)
+				{
+					*reinterpret_cast<uint2*>(myEntry + CP_ENTRY_HEAD) = make_uint2(tcc ? r.taskOffset - excl : 0u, tcc ? r.meshletVisibilityOffset - excl : 0u);
+					*reinterpret_cast<uint32_t*>(myEntry + CP_ENTRY_HEAD + 8) = excl | lane << 16;
+				}
 				heads[lane] = 0ull;
 				if (lane < (uint32_t)CP_WINDOWS - 64u)
 					heads[64u + lane] = 0ull;
@@ -1318,15 +1379,14 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				if (tcc && excl)
 					atomicOr(reinterpret_cast<uint32_t*>(heads) + ((excl - 1u) >> 5), 1u << ((excl - 1u) & 31u));
 				asm volatile("" ::: "memory");
-				packed_walk(a, tabBytes, heads, nout, lane, E, r.drawId, a.filterK > 0.0f && !NV_DBG(a, 1048576u), [&]() // bit 20 (experiments): the reference arithmetic only
+				packed_walk<BITS>(a, tabBytes, heads, nout, lane, E, r.drawId, a.filterK > 0.0f && !NV_DBG(a, 1048576u), [&]() // bit 20 (experiments): the reference arithmetic only
 				{
-					NV_COUNTED_WAIT("s_waitcnt vmcnt(%2) ; nv_ready %0 %1" : "+v"(g0), "+v"(g1) : "i"(CP_DB * 2) : "memory"); // the gather
+					if constexpr (!BITS)
+						NV_COUNTED_WAIT("s_waitcnt vmcnt(%2) ; nv_ready %0 %1" : "+v"(g0), "+v"(g1) : "i"(CP_DB * 2) : "memory"); // the gather
 					gather_finish();
 					r.f.is127 = filter_is127(r.f.scale);
 					if (tcc)
-					{
 						walk_coefficients(myEntry, r.f);
-					}
 					asm volatile("" ::: "memory");
 				});
 				// ---- the commands' ballots, cut out of the windows' (lane c = the segment's c-th command)
@@ -1334,12 +1394,18 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				{
 					const uint32_t jc = excl >> 6, sh = excl & 63u;
 					const uint64_t need = tcc >= 64u ? ~0ull : (1ull << tcc) - 1ull;
-					const uint64_t vlo = heads[jc], vhi = heads[jc + 1u], nlo = nout[jc], nhi = nout[jc + 1u];
+					const uint64_t vlo = heads[jc], vhi = heads[jc + 1u];
 					const uint64_t m = (sh ? (vlo >> sh) | (vhi << (64u - sh)) : vlo) & need;
-					const uint64_t nm = (sh ? (nlo >> sh) | (nhi << (64u - sh)) : nlo) & need;
 					maskLo = (uint32_t)m;
 					maskHi = (uint32_t)(m >> 32);
-					passedFilter += (uint32_t)__builtin_popcountll(__ballot(nm != 0)); // what pass A's filter would not have finished
+					if constexpr (BITS)
+						passedFilter += (uint32_t)__builtin_popcountll(candMask); // (cluster_bits_kernel's statistic: a command with a set bit nearly always still has a cluster the filter cannot finish)
+					else
+					{
+						const uint64_t nlo = nout[jc], nhi = nout[jc + 1u];
+						const uint64_t nm = (sh ? (nlo >> sh) | (nhi << (64u - sh)) : nlo) & need;
+						passedFilter += (uint32_t)__builtin_popcountll(__ballot(nm != 0)); // what pass A's filter would not have finished
+					}
 				}
 				asm volatile("" ::: "memory");
 			}
@@ -2921,7 +2987,12 @@ static void launch_cc(hipStream_t stream, const ClusterArgs& a, uint32_t gridBlo
 			hipLaunchKernelGGL((cluster_mask_kernel<false, SOA, false, DEPTH, DIRECT, true>), grid, block, 0, stream, a);
 	}
 	else if (a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0)
-		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, true, DEPTH, DIRECT>), grid, block, 0, stream, a);
+	{
+		if (pack && a.packBits != 0)
+			hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, true, DEPTH, DIRECT, false, CAN_PACK>), grid, block, 0, stream, a);
+		else
+			hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, true, DEPTH, DIRECT>), grid, block, 0, stream, a);
+	}
 	else if (pack)
 		hipLaunchKernelGGL((cluster_mask_kernel<LATE, SOA, false, DEPTH, DIRECT, false, CAN_PACK>), grid, block, 0, stream, a);
 	else
@@ -2931,7 +3002,7 @@ static void launch_cc(hipStream_t stream, const ClusterArgs& a, uint32_t gridBlo
 // what launch_cluster_mask resolves (late, soa, direct) and the arguments to: the packed walk? (context.hip count_cull_variant)
 bool clustercull_takes_packed(const ClusterArgs& a, int late, bool soa, bool direct)
 {
-	return soa && direct && a.filterK > 0.0f && !late && a.packDirect != 0 && (a.deferHiz || !(a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0));
+	return soa && direct && a.filterK > 0.0f && !late && a.packDirect != 0 && (a.deferHiz || a.packBits != 0 || !(a.cd.clusterOcclusionEnabled == 1 && a.cd.postPass == 0));
 }
 
 // any grid size (pure map); shallow = use the 4-deep filter ring (early pass over the SoA mirror only); direct = no filter

@@ -509,9 +509,9 @@ int nv_set_option(nv_context* ctx, int option, int value)
 		ctx->scatterWaves = (uint32_t)value;
 		return NV_OK;
 	case NV_OPT_CULL_FORM:
-		if (value < 0 || value > 4)
+		if (value < 0 || value > 5)
 			return NV_EINVAL;
-		ctx->forceDirect = value - 1; // 0 -> -1 (by statistic), 1 -> 0 (filter form), 2 -> 1 (direct form), 3 -> 2 (direct, one command per wave also with visibility bits), 4 -> 3 (as 3, and no packed walk)
+		ctx->forceDirect = value - 1; // 0 -> -1 (by statistic), 1 -> 0 (filter form), 2 -> 1 (direct form), 3 -> 2 (direct, one command per wave also with visibility bits), 4 -> 3 (as 3, and no packed walk), 5 -> 4 (direct, the packed walk also in the early pass with visibility bits)
 		return NV_OK;
 	case NV_OPT_TASK_EMIT:
 		if (value < 0 || value > 2)
@@ -883,6 +883,7 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	a.fusedReset = ctx->fusedReset;
 	a.fusedSubmit = ctx->fusedSubmit;
 	a.packDirect = ctx->forceDirect != 3 ? 1u : 0u; // NV_OPT_CULL_FORM 4: one command per wave iteration also where the packed walk applies
+	a.packBits = ctx->forceDirect == 4 ? 1u : 0u;   // NV_OPT_CULL_FORM 5: the early pass with visibility bits as a packed walk too
 	a.countsSink = reinterpret_cast<unsigned long long*>(ctx->countsSink);
 #ifdef NV_EXPERIMENTS
 	a.debugMode = ctx->debugMode;

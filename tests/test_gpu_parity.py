@@ -524,7 +524,7 @@ def test_pinned_kernel_variants_equal_the_oracle(ctx):
             cib_o, cc4_o = np.zeros(n * 64, np.uint32), np.zeros(4, np.uint32)
             oracle.clustercull(cd, 0, commands, c4, draws, meshlets, None, None, cib_o, cc4_o, threads=oracle.max_threads())
             total = int(cc4_o[0])
-            for form in (0, 1, 2, 3, 4):
+            for form in (0, 1, 2, 3, 4, 5):
                 for ring in (0, 4, 8):
                     ctx.set_option(P.NV_OPT_CULL_FORM, form)
                     ctx.set_option(P.NV_OPT_CULL_RING, ring)
@@ -532,7 +532,7 @@ def test_pinned_kernel_variants_equal_the_oracle(ctx):
                     ctx.clustercull(cd, 0, dcb, dccb, db, mlb, None, None, cib, ccb)
                     assert int(ccb[0].item()) == total, (radius_note, form, ring)
                     assert (G.host_u32(cib)[:total] == cib_o[:total]).all(), (radius_note, form, ring)
-        for opt, bad in ((P.NV_OPT_CULL_FORM, 5), (P.NV_OPT_CULL_RING, 5)):
+        for opt, bad in ((P.NV_OPT_CULL_FORM, 6), (P.NV_OPT_CULL_RING, 5)):
             with pytest.raises(P.NvError):
                 ctx.set_option(opt, bad)
     finally:
@@ -907,7 +907,7 @@ def test_cone_test_is_exact_on_the_threshold(ctx):
     # ... and the early pass in its pinned dense forms with every bit set: one lane per set bit (2), one wave per command (3)
     ones = np.full(n * 2 + 3, 0xffffffff, np.uint32)
     try:
-        for form in (2, 3, 4):
+        for form in (2, 3, 4, 5):
             ctx.set_option(P.NV_OPT_CULL_FORM, form)
             t = _compare_cluster_pass(ctx, draws, meshlets, commands, n, c2, 0, ones, pyr, gp)
             assert t == total
@@ -1150,7 +1150,7 @@ def test_early_pass_bit_expanding_form(ctx, soa):
     words = int(packed[-1] + 64) // 32 + 4
     totals = []
     try:
-        for form in (2, 3, 4, 1, 0):
+        for form in (2, 3, 4, 5, 1, 0):
             ctx.set_option(P.NV_OPT_CULL_FORM, form)
             for density in (0.0, 0.03, 0.3, 1.0):
                 bits = rng.random(words * 32) < density
