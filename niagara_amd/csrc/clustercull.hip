@@ -1913,7 +1913,9 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 		passed += bank ? pf1[j] : pf0[j];
 		filled += bank ? mf1[j] : mf0[j];
 	}
-	if (tile == numTiles - 1 && a.hostHint) // (one workgroup: the statistic is a tuning hint, its sum need not be fast; its mapped-host store at the launch's end costs nothing measurable: round 4, NV_DEBUG_MODE A/B)
+	// (one workgroup: the statistics are tuning hints, their sum need not be fast — but it is two barriers and a store to host memory, so it is a MIDDLE tile's:
+	// the last tile already writes the count word, the submit words and their padding, and the launch ends with its slowest workgroup)
+	if (tile == numTiles >> 1 && a.hostHint)
 	{
 		__shared__ uint32_t s_passed, s_filled;
 		if (tid == 0)

@@ -564,6 +564,30 @@ def test_task_emission_forms_equal_the_oracle(ctx, lod0):
     ctx.status()
 
 
+def test_draws_of_thousands_of_task_groups(ctx):
+    """Draws of thousands of task groups each (meshes whose LOD 0 has 2046, 2047, 2048 and 5000 groups: the borders of the 11-bit count a
+    16-bit result record would carry — tools/experiments/result_records16_r6.diff, measured and not adopted) next to an ordinary one, both
+    emission forms of nv_drawcull(task = 1): the oracle's commands."""
+    scene = make_scene(seed=43, n_draws=120, n_meshes=5, lods=2, meshlets_lod0=100, scene_radius=20.0)
+    for mi, groups in enumerate((2046, 2047, 2048, 5000)):
+        scene["meshes"][mi]["lods"][0]["meshletCount"] = groups * 64 - 3
+    cd = passes.set_flags(scene["cull"], (0, 0, 0, 0, 1))  # no culling, LOD 0: every draw emits its mesh's full range
+    dvb = np.ones(len(scene["draws"]), np.uint32)
+    want, c4 = passes.run_drawcull(oracle, scene, cd, 0, 1, dvb.copy(), None)
+    n = int(c4[0])
+    assert n > 120 * 1000
+    g = G.GpuScene(ctx, scene)
+    try:
+        for emit in (1, 2, 0):
+            ctx.set_option(P.NV_OPT_TASK_EMIT, emit)
+            dcb, dccb, _ = g.drawcull(cd, 0, 1, dvb, with_pyramid=False)
+            assert (G.host_u32(dccb)[:1] == c4[:1]).all(), emit
+            assert P.from_device(dcb, L.TASKCMD)[:n].tobytes() == want[:n].tobytes(), emit
+    finally:
+        ctx.set_option(P.NV_OPT_TASK_EMIT, 0)
+    ctx.status()
+
+
 def test_three_contexts_share_one_scene_mirror():
     """contexts on three streams (three views in flight) use ONE set of SoA mirrors after nv_share_scene —
     device memory grows by one mirror, not three — and each produces the oracle's list for its own view."""

@@ -704,7 +704,9 @@ if __name__ == "__main__":
     ALLOW_MISMATCH = a.allow_mismatch
     ctx = P.Context(0)
     runs = {"2": lambda: config2(ctx, a.iters), "2_fused": lambda: config2(P.Context(0), a.iters, fused_reset=True), "2_aos": lambda: config2(P.Context(0), a.iters, soa=False), "2l": lambda: config2_late(ctx, a.iters), "3b": lambda: config3b(ctx, a.iters), "3b_fused": lambda: config3b(P.Context(0), a.iters, fused=True),
-            "3b_chain": lambda: config3b(P.Context(0), a.iters, n_draws=125000, fused=True),  # bench.py's `contract_chain`: BASELINE configs[2] with LOD select at 10 M meshlets "4": lambda: config4(ctx, a.iters),
+            # (3b_chain = bench.py's `contract_chain`: BASELINE configs[2] with LOD select at 10 M meshlets)
+            "3b_chain": lambda: config3b(P.Context(0), a.iters, n_draws=125000, fused=True),
+            "4": lambda: config4(ctx, a.iters),
             "4b": lambda: config4(ctx, a.iters, size=1024), "n4": lambda: config_n4(ctx, a.iters),
             "frame": lambda: config_frame(P.Context(0), a.iters, cpp_driver=True), "frame_py": lambda: config_frame(P.Context(0), a.iters), "frame_contract": lambda: config_frame(P.Context(0), a.iters, fused=False),
             "task": lambda: config_task(ctx, a.iters),
