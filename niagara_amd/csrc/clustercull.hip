@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 	// vkCmdDispatchIndirect(dccb, 4): see indirect_command_count
 	const uint32_t numCmds = a.commandCountOverride ? a.commandCountOverride : (rawGroups < 65535u ? rawGroups : 65535u) * 64u;
 	const uint32_t bank = bankWord & 1u;
-	// (nv_taskcull's payload form has its own word: no scatter launch follows it that would refresh the filter statistic in word 2, so
+	// (nv_taskcull's payload form has its own word: no scatter launch follows it that would refresh the filter statistic in word 1, so
 	// its count must not become the denominator of nv_clustercull's next filter / direct choice — ADVICE r3)
 	if (a.hostHint && blockIdx.x == 0 && threadIdx.x == 0)
 		__hip_atomic_store(a.hostHint + (a.payloadCounts ? 4 : 0), numCmds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1172,7 +1172,6 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 		stamps[6] = wall_clock64(); // 100 MHz, chip-wide: comparable across CUs (the cycle counter is not)
 
 	uint32_t passedFilter = 0; // commands of this wave the conservative filter does not finish (DIRECT: would not have finished)
-	uint32_t meshletsSeen = 0; // valid meshlets of this wave's commands, per lane (summed once, at the wave's end): with the command count the pass's FILL (meshlets per command slot), the second statistic of the host's choice
 	// (the same per WAVE, in front of its first segment: NV_FILLER_PS / NV_FILLER_PV)
 #if defined(NV_FILLER_PS)
 #pragma unroll
@@ -1270,7 +1269,6 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 			uint32_t packIncl = 0;
 			if constexpr (PACK && !BITS)
 				packIncl = wave_scan_inclusive_u32(r.taskCount < 64u ? r.taskCount : 64u);
-			meshletsSeen += r.taskCount < 64u ? r.taskCount : 64u; // (the fill statistic: word 2 of a tile counter's line, summed by the scatter launch)
 			gather_issue();
 
 			// ---- pass A: stream the 8 bounds bytes of every command through the conservative frustum filter.
@@ -1764,16 +1762,13 @@ __global__ __launch_bounds__(CC_THREADS, 6) void cluster_mask_kernel(ClusterArgs
 				atomicAdd(&a.tileCounts->counts[bank][tileOf * CC_COUNT_STRIDE], pc);
 		}
 	}
-	// the launch's statistics for the host's choice of the next launch's form — the commands the filter did not (or would not have) finished, and the valid
-	// meshlets of the wave's commands (the pass's fill) — as ONE 64-bit add per wave, spread over the tile counters' lines (words 2 and 3 of a line; the
-	// scatter kernel sums them.  As two adds, the second on every wave, the headline pass took 26.5 instead of 26.1 us)
-	if (!(!LATE && !DEFER && a.payloadCounts != nullptr)) // (payloads: no scatter launch follows that would sum and clear them)
+	// the launch's filter statistic for the host's choice of the next launch's form: one add per wave, spread over the tile
+	// counters' lines (word 1 of a line; the scatter kernel sums them)
+	if (lane == 0 && passedFilter && !(!LATE && !DEFER && a.payloadCounts != nullptr)) // (payloads: no scatter launch follows that would sum and clear them)
 	{
-		const uint32_t filled = SOA ? wave_sum_u32(meshletsSeen) : 0u;
 		// (any of the lines of the tiles that hold commands — the scatter launch sums them all: the largest power of two of them, a mask instead of a remainder)
 		const uint32_t spread = numTiles ? (1u << (31 - __builtin_clz(numTiles))) - 1u : 0u;
-		if (lane == 0 && (passedFilter | filled))
-			atomicAdd(reinterpret_cast<unsigned long long*>(&a.tileCounts->counts[bank][(w & spread) * CC_COUNT_STRIDE + 2]), (unsigned long long)passedFilter | (unsigned long long)filled << 32);
+		atomicAdd(&a.tileCounts->counts[bank][(w & spread) * CC_COUNT_STRIDE + 1], passedFilter);
 	}
 	NV_STAMP(5);
 	if (dbgTime && lane == 0)
@@ -1810,8 +1805,7 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 	const uint32_t k2parity = load_uniform_u32(&a.tileCounts->k2parity);
 	const uint32_t base0 = load_uniform_u32(&a.tileCounts->base);
 	uint32_t cnt0[TILE_LOADS] = {}, cnt1[TILE_LOADS] = {}; // this thread's tiles tid, tid + SC_THREADS, ..., per bank
-	uint32_t pf0[TILE_LOADS] = {}, pf1[TILE_LOADS] = {};   // likewise the cull kernel's filter statistic (word 2 of the line)
-	uint32_t mf0[TILE_LOADS] = {}, mf1[TILE_LOADS] = {};   // and its fill statistic (word 3: valid meshlets of the pass's commands)
+	uint32_t pf0[TILE_LOADS] = {}, pf1[TILE_LOADS] = {};   // likewise the cull kernel's filter statistic (word 1 of the line)
 #pragma unroll
 	for (int j = 0; j < TILE_LOADS; ++j)
 	{
@@ -1820,15 +1814,8 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 		{
 			cnt0[j] = a.tileCounts->counts[0][i * CC_COUNT_STRIDE];
 			cnt1[j] = a.tileCounts->counts[1][i * CC_COUNT_STRIDE];
-			// (the statistics, words 2 and 3 of the line, one 8-byte load per bank.  Every tile loads them although only the last sums them: under
-			// `tile == numTiles - 1` the loads leave the clause of the tile counts and the last tile — the one that writes the count word — waits for two
-			// round trips instead of one: scatter launch 7.35 -> 7.75 us)
-			const uint2 st0 = *reinterpret_cast<const uint2*>(&a.tileCounts->counts[0][i * CC_COUNT_STRIDE + 2]);
-			const uint2 st1 = *reinterpret_cast<const uint2*>(&a.tileCounts->counts[1][i * CC_COUNT_STRIDE + 2]);
-			pf0[j] = st0.x;
-			mf0[j] = st0.y;
-			pf1[j] = st1.x;
-			mf1[j] = st1.y;
+			pf0[j] = a.tileCounts->counts[0][i * CC_COUNT_STRIDE + 1];
+			pf1[j] = a.tileCounts->counts[1][i * CC_COUNT_STRIDE + 1];
 		}
 	}
 	const uint32_t first = tile * T;
@@ -1864,7 +1851,7 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 	for (uint32_t i = tile * SC_THREADS + tid; i < CC_MAX_SCATTER_TILES; i += gridDim.x * SC_THREADS)
 	{
 		a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE] = 0;
-		*reinterpret_cast<uint2*>(&a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE + 2]) = make_uint2(0u, 0u);
+		a.tileCounts->counts[bank ^ 1u][i * CC_COUNT_STRIDE + 1] = 0;
 		if (i < CC_LISTS)
 			a.tileCounts->listCount[bank ^ 1u][i * CC_COUNT_STRIDE] = 0;
 	}
@@ -1873,9 +1860,7 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 		a.tileCounts->parity = bank ^ 1u;
 		a.tileCounts->listOverflow[bank ^ 1u] = 0;
 		if (numTiles == 0 && a.hostHint)
-		{
-			__hip_atomic_store(reinterpret_cast<unsigned long long*>(a.hostHint + 6), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-		}
+			__hip_atomic_store(a.hostHint + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		if (numTiles == 0) // no commands at all: the count word keeps its base, the submit words describe an empty grid
 		{
 			if (a.fusedReset)
@@ -1902,7 +1887,7 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 	if (tile >= numTiles)
 		return;
 
-	uint32_t before = 0, all = 0, passed = 0, filled = 0;
+	uint32_t before = 0, all = 0, passed = 0;
 #pragma unroll
 	for (int j = 0; j < TILE_LOADS; ++j)
 	{
@@ -1911,30 +1896,19 @@ __global__ __launch_bounds__(SC_WAVES * 64) void cluster_scatter_kernel(ClusterA
 		all += v;
 		before += i < tile ? v : 0u;
 		passed += bank ? pf1[j] : pf0[j];
-		filled += bank ? mf1[j] : mf0[j];
 	}
-	// (one workgroup: the statistics are tuning hints, their sum need not be fast — but it is two barriers and a store to host memory, so it is a MIDDLE tile's:
-	// the last tile already writes the count word, the submit words and their padding, and the launch ends with its slowest workgroup)
-	if (tile == numTiles >> 1 && a.hostHint)
+	if (tile == numTiles - 1 && a.hostHint) // (one workgroup: the statistic is a tuning hint, its sum need not be fast; its mapped-host store at the launch's end costs nothing measurable: round 4, NV_DEBUG_MODE A/B)
 	{
-		__shared__ uint32_t s_passed, s_filled;
+		__shared__ uint32_t s_passed;
 		if (tid == 0)
-		{
 			s_passed = 0;
-			s_filled = 0;
-		}
 		__syncthreads();
-		const uint32_t wp = wave_sum_u32(passed), wf = wave_sum_u32(filled);
+		const uint32_t wp = wave_sum_u32(passed);
 		if (lane == 0 && wp)
 			atomicAdd(&s_passed, wp);
-		if (lane == 0 && wf)
-			atomicAdd(&s_filled, wf);
 		__syncthreads();
 		if (tid == 0)
-		{
-			// (words 6 and 7 of the mapped hints, ONE store: a second store to host memory behind the first is a second trip over the bus at the launch's end)
-			__hip_atomic_store(reinterpret_cast<unsigned long long*>(a.hostHint + 6), (unsigned long long)s_passed | (unsigned long long)s_filled << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-		}
+			__hip_atomic_store(a.hostHint + 1, s_passed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 	const uint32_t wBefore = wave_sum_u32(before), wAll = wave_sum_u32(all);
 	if (lane == 0)
@@ -2649,7 +2623,7 @@ __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs
 	const uint32_t iters = (numCmds + G * (uint32_t)CB_CMDS - 1u) / (G * (uint32_t)CB_CMDS);
 	uint32_t per = iters ? (numCmds + G * iters - 1u) / (G * iters) : 0u;
 	per = per < 16u ? 16u : per; // (<= CB_CMDS by construction)
-	uint32_t passedAcc = 0, meshletsAcc = 0;
+	uint32_t passedAcc = 0;
 
 	// pipeline prologue: commands of iterations 0 and 1, MeshDraw and words of iteration 0
 	uint32_t chunk = blockIdx.x;
@@ -2767,7 +2741,6 @@ __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs
 			// does not finish): a command with a set bit was visible a frame ago, and nearly always still has a cluster the
 			// filter cannot finish — counting those per entry cost 8 instructions per cluster for a tuning hint.
 			passedAcc += BITS ? (cand ? 1u : 0u) : (cand ? s_passed[tid] : 0u);
-			meshletsAcc += taskCount < 64u ? taskCount : 64u; // the fill statistic (cluster_mask_kernel: meshletsSeen)
 		}
 		if (a.payloadCounts) // (uniform) nv_taskcull's early pass: the payloads straight from here (see cluster_mask_kernel), no tile counts
 		{
@@ -2804,14 +2777,13 @@ __global__ __launch_bounds__(CB_THREADS, 4) void cluster_bits_kernel(ClusterArgs
 		oldw[1] = pw1;
 		oldw[2] = pw2;
 	}
-	// the launch's statistics (cluster_mask_kernel: words 2 and 3 of a tile counter's line, one 64-bit add per wave; the scatter kernel sums them)
+	// the launch's statistic (cluster_mask_kernel: word 1 of a tile counter's line; the scatter kernel sums them)
 	{
-		const uint32_t sum = wave_sum_u32(passedAcc), msum = wave_sum_u32(meshletsAcc);
-		if (lane == 0 && (sum | msum) && !a.payloadCounts)
+		const uint32_t sum = wave_sum_u32(passedAcc);
+		if (lane == 0 && sum && !a.payloadCounts)
 		{
 			const uint32_t numTiles = (numCmds + T2 - 1) / T2;
-			atomicAdd(reinterpret_cast<unsigned long long*>(&a.tileCounts->counts[bank][((blockIdx.x * (CB_THREADS / 64) + wave) % (numTiles ? numTiles : 1u)) * CC_COUNT_STRIDE + 2]),
-			          (unsigned long long)sum | (unsigned long long)msum << 32);
+			atomicAdd(&a.tileCounts->counts[bank][((blockIdx.x * (CB_THREADS / 64) + wave) % (numTiles ? numTiles : 1u)) * CC_COUNT_STRIDE + 1], sum);
 		}
 	}
 }
@@ -3062,12 +3034,15 @@ bool clustercull_prefers_direct(uint32_t previousCommandCount, uint32_t previous
 
 // The filter form's time goes with the number of COMMANDS (its stream is bound by instruction issue: ~60 instructions per command whatever the command's
 // size), the packed direct walk's with the number of valid MESHLETS / 64.  Behind drawcull's LOD select a draw's meshlets end in a partial command — config
-// 3B at BASELINE scale: 250 k commands, 40 valid lanes on average — and the packed walk then wins even where the filter rejects nearly everything (24 against
-// 34 us there, a cache-resident pool; 3A's full commands streamed from HBM: filter 21 us, packed walk 32).  fillPercent = the pass's valid meshlets per
-// command slot below which the packed walk is taken whatever the filter statistic says (context.hip: 85 for a cache-resident pool, 60 otherwise).
-bool clustercull_prefers_packed(uint32_t previousCommandCount, uint32_t previousMeshlets, uint32_t fillPercent)
+// 3B at BASELINE scale: 250 k commands, 40 valid lanes on average — and the packed walk then wins even where the filter rejects nearly everything (22.5 against
+// 34 us there, a cache-resident pool; 3A's full commands streamed from HBM: filter 21 us, packed walk 32).  The pass's FILL — valid meshlets per command slot —
+// is ESTIMATED, at no cost to any kernel, from what the task pass that wrote the commands left for the host anyway (context.hip: emitting draws and commands,
+// hint words 2 and 3): every emitting draw ends in one command that is half full on average, fill ~ 1 - draws / (2 commands).  (Round 6 first MEASURED it — the
+// valid meshlets summed by the cull kernels, a second word beside the filter statistic, summed by the scatter launch: the scatter launch of the headline
+// pass took 5.09 instead of 4.71 us by kernel-trace, whichever part of the plumbing was taken out again; the estimate decides the same way on every config.)
+bool clustercull_prefers_packed(uint32_t taskCommands, uint32_t emittingDraws, uint32_t fillPercent)
 {
-	return previousCommandCount != 0 && previousMeshlets != 0 && (uint64_t)previousMeshlets * 100u < (uint64_t)previousCommandCount * 64u * fillPercent;
+	return taskCommands != 0 && emittingDraws != 0 && (uint64_t)(2u * (uint64_t)taskCommands - emittingDraws) * 100u < (uint64_t)taskCommands * 2u * fillPercent;
 }
 
 // early pass with visibility bits, dense form (one lane per set bit): any grid size (equal contiguous shares per block, grid-stride beyond CB_CMDS commands per block)

@@ -24,7 +24,7 @@ int launch_cluster_mask(hipStream_t, const ClusterArgs&, int late, bool soa, uin
 bool clustercull_prefers_shallow(uint32_t previousCommandCount);
 bool clustercull_prefers_direct(uint32_t previousCommandCount, uint32_t previousPassedFilter, uint32_t percent);
 bool clustercull_takes_packed(const ClusterArgs&, int late, bool soa, bool direct);
-bool clustercull_prefers_packed(uint32_t previousCommandCount, uint32_t previousMeshlets, uint32_t fillPercent);
+bool clustercull_prefers_packed(uint32_t taskCommands, uint32_t emittingDraws, uint32_t fillPercent);
 int launch_cluster_scatter(hipStream_t, const ClusterArgs&, uint32_t scatterBlocks, uint32_t waves);
 int launch_cluster_hiz(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
 int launch_cluster_bits(hipStream_t, const ClusterArgs&, bool soa, uint32_t gridBlocks);
@@ -908,22 +908,24 @@ int nv_clustercull(nv_context* ctx, void* stream, const NvCullData* cull, int la
 	bool shallow = ctx->hintHost && nv::clustercull_prefers_shallow(*ctx->hintHost) && !(ctx->debugMode & 65536u); // bit 16 (experiments): always deep
 	if (ctx->forceShallow >= 0)
 		shallow = ctx->forceShallow != 0;
-	// mapped host words the previous launches left: [0] command count, [6] commands their filter did not (or would not
+	// mapped host words the previous launches left: [0] command count, [1] commands their filter did not (or would not
 	// have) finished — possibly a launch or two behind, which only matters for speed
-	bool direct = ctx->hintHost && nv::clustercull_prefers_direct(ctx->hintHost[0], ctx->hintHost[6], ctx->directPercent);
+	bool direct = ctx->hintHost && nv::clustercull_prefers_direct(ctx->hintHost[0], ctx->hintHost[1], ctx->directPercent);
 	if (!(ctx->hintHost && ctx->hintHost[0] != 0) && d_commands == ctx->taskCommandsFrom) // no statistic yet: by where the commands come from
 		direct = true;
 	// (the provenance is good for ONE cluster launch: a later list at the same address — a freed and reused buffer, a caller-built list — is not this
 	// context's drawcull output unless another nv_drawcull(task) has written there since)
+	const bool ownTaskCommands = d_commands == ctx->taskCommandsFrom;
 	ctx->taskCommandsFrom = nullptr;
-	// [7] = the valid meshlets of the previous launch's commands: a pass of partial commands (drawcull's LOD select) takes the direct form's packed walk whatever
-	// the filter statistic says, where that form exists (early form without visibility bits, over the mirror) — clustercull.hip clustercull_prefers_packed
+	// A pass of partial commands — what drawcull's LOD select leaves — takes the direct form's packed walk whatever the filter statistic says, where that form
+	// exists (early form without visibility bits, over the mirror): its fill is estimated from the emitting draws and commands the task pass that wrote the
+	// list left in hint words 2 and 3 (clustercull.hip clustercull_prefers_packed); a caller's own list has no such words and is taken as full.
 	const bool bits = cull->clusterOcclusionEnabled == 1 && cull->postPass == 0;
 	const bool twoStage = late && cull->clusterOcclusionEnabled == 1;
-	if (!direct && ctx->hintHost && a.soaBounds && a.filterK > 0.0f && (twoStage || (!late && !bits)))
+	if (!direct && ownTaskCommands && ctx->hintHost && a.soaBounds && a.filterK > 0.0f && (twoStage || (!late && !bits)))
 	{
 		const bool poolInCache = (uint64_t)ctx->scene->mirroredCount * 12u <= (48ull << 20);
-		direct = nv::clustercull_prefers_packed(ctx->hintHost[0], ctx->hintHost[7], poolInCache ? 85u : 60u);
+		direct = nv::clustercull_prefers_packed(ctx->hintHost[3], ctx->hintHost[2], poolInCache ? 85u : 60u);
 	}
 	if (ctx->forceDirect >= 0)
 		direct = ctx->forceDirect != 0;
@@ -992,13 +994,13 @@ int nv_taskcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 		hipStream_t s = (hipStream_t)stream;
 		a.fusedReset = 1u;
 		a.clusterCount4 = nullptr;
-		// mapped hint words: [4] = the command count of the previous nv_taskcull (ring depth); [0], [6] = command count and filter
+		// mapped hint words: [4] = the command count of the previous nv_taskcull (ring depth); [0], [1] = command count and filter
 		// statistic of the previous nv_clustercull, a consistent pair (the payload form writes neither: no scatter launch follows it
 		// that would publish its statistic).  A context that only ever calls nv_taskcull stays on the filter form.
 		bool shallow = ctx->hintHost && nv::clustercull_prefers_shallow(ctx->hintHost[4]);
 		if (ctx->forceShallow >= 0)
 			shallow = ctx->forceShallow != 0;
-		bool direct = ctx->hintHost && nv::clustercull_prefers_direct(ctx->hintHost[0], ctx->hintHost[6], ctx->directPercent);
+		bool direct = ctx->hintHost && nv::clustercull_prefers_direct(ctx->hintHost[0], ctx->hintHost[1], ctx->directPercent);
 		if (!(ctx->hintHost && ctx->hintHost[0] != 0) && d_commands == ctx->taskCommandsFrom) // (as in nv_clustercull)
 			direct = true;
 		ctx->taskCommandsFrom = nullptr;
