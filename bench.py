@@ -496,7 +496,7 @@ def contract_chain(device_index, n_draws=125000, iters=100):
     return {"what": "BASELINE configs[2] with LOD select: " + r["config"], "roofline": roof, "draws": r["draws"], "task_commands": r["task_commands"],
             "meshlets_tested": r["meshlets_tested"], "visible": r["visible"], "us_per_phase": r["step_us"], "meshlets_per_s": r["meshlets_per_s"],
             "drawcull_us": r["drawcull_us"], "cluster_cull_us": r["cluster_cull_us"], "cluster_scatter_us": r["cluster_scatter_us"],
-            "options": "NV_OPT_FUSED_COUNT_RESET + NV_OPT_FUSED_SUBMIT (4 launches per phase)", "regime": "one phase after the other on one stream, %d phases" % iters,
+            "options": "NV_OPT_FUSED_COUNT_RESET + NV_OPT_FUSED_SUBMIT (4 launches per phase)", "regime": "one phase after the other on one stream, the shortest of three loops of %d phases" % iters,
             "parity": r["parity"], "parity_checked": "task commands + count words, visible-ID list + count + submit padding, drawVisibility against the CPU oracle"}
 
 

@@ -21,7 +21,7 @@ for d in sorted(glob.glob("$out/pmc*")):
         for row in csv.DictReader(open(f)):
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, cs in acc.items():
-            short = k.split("(")[0][-60:]
+            short = k.split("(")[0][-100:]
             for c, v in cs.items():
                 res[short][c] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
 json.dump(res, open("$out/traffic_raw.json", "w"), indent=1)
