@@ -2463,14 +2463,28 @@ NV_DEV void bits_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint
 			u.scale = q0.w;
 			u.q = { q1.x, q1.y, q1.z };
 			u.qw = q1.w;
-			const FilterDraw f = make_filter(a.cd, u, a.filterK, a.viewRowNorm, a.viewTransNorm, a.viewSum, 0.0f, 0.0f); // (tK unused: the certified test keeps the per-meshlet margin)
+			// (SOA: the margin is the draw's tK over the registered pool's bounds, as in packed_walk — four multiply-adds and a 16-byte LDS read less per entry;
+			// records read in place have no pool bounds and keep the per-meshlet margin)
+			float vmax3 = 0.0f, rmax = 0.0f;
+			if (SOA)
+			{
+				k_f32p pb = (k_f32p)(uintptr_t)a.poolBounds;
+				vmax3 = pb[0];
+				rmax = pb[1];
+			}
+			const FilterDraw f = make_filter(a.cd, u, a.filterK, a.viewRowNorm, a.viewTransNorm, a.viewSum, vmax3, rmax);
 			s_draw[tid][0] = q0;
 			s_draw[tid][1] = q1;
 			s_cert[tid][0] = make_float4(f.m[0], f.m[1], f.m[2], f.b[0]);
 			s_cert[tid][1] = make_float4(f.m[3], f.m[4], f.m[5], f.b[1]);
 			s_cert[tid][2] = make_float4(f.m[6], f.m[7], f.m[8], f.b[2]);
-			s_cert[tid][3] = make_float4(f.aK, f.bK, f.aR, f.scale);
-			s_cert[tid][4] = make_float4(f.coneK, f.is127, 0.0f, 0.0f);
+			if (SOA)
+				s_cert[tid][3] = make_float4(f.tK, f.scale, f.tK * f.coneK, f.is127);
+			else
+			{
+				s_cert[tid][3] = make_float4(f.aK, f.bK, f.aR, f.scale);
+				s_cert[tid][4] = make_float4(f.coneK, f.is127, 0.0f, 0.0f);
+			}
 		}
 		NV_LDS_BARRIER();
 	}
@@ -2483,7 +2497,7 @@ NV_DEV void bits_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint
 		if (__ballot(s < total) == 0) // (uniform) nobody in this wave holds an entry in this slot
 			continue;
 		const uint32_t owner = e[k] >> 6, bit = e[k] & 63u;
-		const float4 r0 = s_cert[owner][0], r1 = s_cert[owner][1], r2 = s_cert[owner][2], r3 = s_cert[owner][3], r4 = s_cert[owner][4];
+		const float4 r0 = s_cert[owner][0], r1 = s_cert[owner][1], r2 = s_cert[owner][2], r3 = s_cert[owner][3];
 		const uint32_t b0 = b[k].x, b1 = b[k].y;
 		// certified_visible, one lane = one cluster
 		const float vx = half_bits_to_float(b0 & 0xffffu), vy = half_bits_to_float(b0 >> 16), vz = half_bits_to_float(b1 & 0xffffu);
@@ -2491,11 +2505,21 @@ NV_DEV void bits_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint
 		const float cx = __builtin_fmaf(r0.x, vx, __builtin_fmaf(r0.y, vy, __builtin_fmaf(r0.z, vz, r0.w)));
 		const float cy = __builtin_fmaf(r1.x, vx, __builtin_fmaf(r1.y, vy, __builtin_fmaf(r1.z, vz, r1.w)));
 		const float cz = __builtin_fmaf(r2.x, vx, __builtin_fmaf(r2.y, vy, __builtin_fmaf(r2.z, vz, r2.w)));
-		const float aK = r3.x, bK = r3.y, aR = r3.z, scale = r3.w, coneK = r4.x, is127 = r4.y;
-		float T = __builtin_fmaf(aK, __builtin_fabsf(vx), bK);
-		T = __builtin_fmaf(aK, __builtin_fabsf(vy), T);
-		T = __builtin_fmaf(aK, __builtin_fabsf(vz), T);
-		T = __builtin_fmaf(aR, __builtin_fabsf(rad), T);
+		float T, scale, Tc, is127;
+		if (SOA)
+			T = r3.x, scale = r3.y, Tc = r3.z, is127 = r3.w;
+		else
+		{
+			const float4 r4 = s_cert[owner][4];
+			const float aK = r3.x, bK = r3.y, aR = r3.z;
+			scale = r3.w;
+			is127 = r4.y;
+			T = __builtin_fmaf(aK, __builtin_fabsf(vx), bK);
+			T = __builtin_fmaf(aK, __builtin_fabsf(vy), T);
+			T = __builtin_fmaf(aK, __builtin_fabsf(vz), T);
+			T = __builtin_fmaf(aR, __builtin_fabsf(rad), T);
+			Tc = T * r4.x;
+		}
 		const float thrHi = __builtin_fmaf(scale, rad, T), thrLo = __builtin_fmaf(scale, rad, -T);
 		const float g1 = __builtin_fmaf(cz, cd.frustum[1], -(__builtin_fabsf(cx) * cd.frustum[0]));
 		const float g2 = __builtin_fmaf(cz, cd.frustum[3], -(__builtin_fabsf(cy) * cd.frustum[2]));
@@ -2515,7 +2539,6 @@ NV_DEV void bits_round(const ClusterArgs& a, uint32_t base, uint32_t total, uint
 			const float len = __builtin_amdgcn_sqrtf(__builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, cz * cz)));
 			const float rhs = __builtin_fmaf(kc * 0.00787401574803149606f, len, scale * rad);
 			const float D = lhs - rhs;
-			const float Tc = T * coneK;
 			const bool cull = D > Tc, keep = D < -Tc;
 			decided = decided && (out || cull || keep); // (a cluster outside the frustum is decided whatever its cone says)
 			visible = visible && keep;

@@ -49,10 +49,10 @@ while time.time() - t0 < budget:
     draws["position"] *= np.float32(rng.choice([0.1, 0.3, 1.0]))
     commands["lateDrawVisibility"][:n] = rng.integers(0, 2, n)
     # (round 6) half of the cases with ragged commands — any taskCount in 0 .. 64, empty ones included: what the direct form's packed walk packs — and every
-    # case with a random NV_OPT_CULL_FORM (0 = by the statistics the previous cases left .. 4 = one command per wave iteration)
+    # case with a random NV_OPT_CULL_FORM (0 = by the statistics the previous cases left .. 4 = one command per wave iteration, 5 = the packed walk also with visibility bits)
     if rng.random() < 0.5:
         commands["taskCount"][:n] = rng.integers(0, 65, n)
-    ctx.set_option(P.NV_OPT_CULL_FORM, int(rng.integers(0, 5)))
+    ctx.set_option(P.NV_OPT_CULL_FORM, int(rng.integers(0, 6)))
     cd = host.build_cull_data(draw_count=n_draws, cullingEnabled=1, clusterBackfaceEnabled=cbe, clusterOcclusionEnabled=coe, occlusionEnabled=1)
     cd["pyramidWidth"], cd["pyramidHeight"] = pyr.width, pyr.height
     mvb0 = rng.integers(0, 2 ** 32, n * 2 + 3, dtype=np.uint64).astype(np.uint32) if coe else None

@@ -36,7 +36,7 @@ while time.time() - t0 < budget:
     pyr = oracle.Pyramid(*scene["viewport"])
     oracle.depthreduce(scene["depth"], pyr)
     g.depthreduce(scene["depth"])
-    form = int(rng.integers(0, 5))
+    form = int(rng.integers(0, 6))
     ctx.set_option(P.NV_OPT_CULL_FORM, form)
     for late in (0, 1, 0):
         fl = tuple(int(x) for x in rng.integers(0, 2, 5)) if late == 0 else flags
