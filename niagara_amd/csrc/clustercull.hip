@@ -3012,10 +3012,11 @@ int launch_cluster_mask(hipStream_t stream, const ClusterArgs& args, int late, b
 {
 	ClusterArgs a = args;
 	// The dealing's delay compensation was calibrated on the filter form (a wave of config 3A lives ~11 us).  A wave of the packed walk lives 18-23 us and
-	// is bound by vector issue, so a later generation — the younger waves of every SIMD — falls behind by more than its start delay: 2.5 x the compensation
-	// (round 6 sweep 0 / 100 / 200 / 300 / 400 %: contract chain's cull launch 26.8 / 25.9 / 24.8 / 24.7 / 25.3 us, 3A dense 35.0 / 33.0 / 33.0 / 32.1 / 32.7)
+	// is bound by vector issue, so a later generation — the younger waves of every SIMD — falls behind by more than its start delay: the walk has a delay
+	// table of its own (dealing.h DEAL_PACKED_TABLE; round 6: 0 / 100 / 200 / 300 / 400 % of the filter form's — contract chain's cull launch 26.8 / 25.9 /
+	// 24.8 / 24.7 / 25.3 us — then the last generation's entry by the wave timeline)
 	if (clustercull_takes_packed(a, late, soa, direct))
-		a.dealScale = a.dealScale * 5u / 2u;
+		a.dealScale += DEAL_PACKED_TABLE;
 	a.plan = deal_plan(expectedCmds, late ? CC_CHUNK_LATE : CC_CHUNK, !late, maskBlocks * CC_WAVES, a.cullWavesMagic, a.generations, a.genBlocks, maskBlocks, a.dealScale,
 	                   a.scatterTiles, a.tilesMagic);
 	if (expectedCmds == 0)

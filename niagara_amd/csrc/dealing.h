@@ -40,6 +40,7 @@ struct DealPlan
 };
 
 constexpr uint32_t DEAL_WEIGHTED_WANTED = 1u;
+constexpr uint32_t DEAL_PACKED_TABLE = 1000u; // deal_plan's scalePercent from this value up: the packed walk's delay table
 constexpr uint32_t DEAL_TILE_THREADS = 256u; // = CC_THREADS: a scatter tile is a multiple of the cull workgroup's commands per step
 
 // q = n / d through the host's magic (host.cpp nv_division_magic: exact for n < 2^39 / d, 0 = not available)
@@ -95,8 +96,16 @@ NV_DP DealPlan deal_plan(uint32_t numCmds, uint32_t chunk, bool weightedWanted, 
 	if (!weightedWanted || generations != 6u || genBlocks * 6u != gridBlocks || p.perWaveChunks < 4u || p.perWaveChunks >= 60u)
 		return p;
 	const uint32_t genWaves = genBlocks * 4u;
-	// delays in 1/16 command: { 0, 0.5, 2.4, 4.2, 7.1, 13.1 }, mean 4.55
-	const int delay16[6] = { 0, 8, 38, 67, 114, 210 };
+	// delays in 1/16 command: { 0, 0.5, 2.4, 4.2, 7.1, 13.1 }, mean 4.55 — calibrated on the filter form (round 3).
+	// scalePercent >= DEAL_PACKED_TABLE: the packed walk's table at (scalePercent - DEAL_PACKED_TABLE) % (round 6: a wave of the walk lives 18-23 us and is bound
+	// by vector issue — the younger waves of a SIMD fall behind by more than their start delay.  2.5 x the filter form's delays balanced generations 0-4
+	// (ends 17.7-18.5 us) and starved the last one (12.4 us): its entry is 1.8 x instead — tools/wave_timeline.py with NV_DIRECT=1)
+	const bool packedTable = scalePercent >= DEAL_PACKED_TABLE;
+	if (packedTable)
+		scalePercent -= DEAL_PACKED_TABLE;
+	const int delayFilter16[6] = { 0, 8, 38, 67, 114, 210 }, delayPacked16[6] = { 0, 20, 95, 168, 285, 380 };
+	const int* delay16 = packedTable ? delayPacked16 : delayFilter16;
+	const int mean16 = packedTable ? 158 : 73;
 	// The dividend through the magic must stay below 2^39 / W (deal_div).  HERE perWaveChunks < 60, so numChunks < 61 W and the dividend is below
 	// 61 W x 16 chunk = 3904 W for the chunk of 4 both passes use; 3904 W < 2^39 / W for W < 11 866 — and deal_magic offers a magic up to W = 8192 only
 	// (tests/test_dealing.py holds host plan == wave-derived plan at that largest grid, at the largest counts that reach this line).
@@ -106,7 +115,7 @@ NV_DP DealPlan deal_plan(uint32_t numCmds, uint32_t chunk, bool weightedWanted, 
 	for (int k = 0; k < 6; ++k)
 	{
 		// (the nominal scale is a constant per generation; any other one divides)
-		const int adjust16 = scalePercent == 100u ? 73 - delay16[k] : ((int)scalePercent * (73 - delay16[k])) / 100;
+		const int adjust16 = scalePercent == 100u ? mean16 - delay16[k] : ((int)scalePercent * (mean16 - delay16[k])) / 100;
 		const int target16 = perWave16 + adjust16 - (int)(chunk * 16u); // keep one even round for the remainder
 		rounds[k] = target16 > 0 ? (uint32_t)target16 / (chunk * 16u) : 0u;
 		weightedTotal += rounds[k] * genWaves;

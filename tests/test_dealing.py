@@ -43,13 +43,13 @@ COUNTS = [0, 1, 3, 4, 5, 63, 64, 100, 6143, 6144 * 4, 6144 * 4 + 1, 24577, 10000
 def test_every_chunk_goes_to_exactly_one_wave(shim, grid):
     rng = np.random.default_rng(grid)
     for n in COUNTS + [int(x) for x in rng.integers(1, 3_000_000, 12)]:
-        for weighted in (1, 0):
-            plan = plan_of(shim, n, grid=grid, weighted=weighted)
+        for weighted, scale in ((1, 100), (0, 100), (1, 1100), (1, 1250)):  # (1000 + s: the packed walk's delay table at s %: dealing.h DEAL_PACKED_TABLE)
+            plan = plan_of(shim, n, grid=grid, weighted=weighted, scale=scale)
             chunks = (n + 3) // 4
             owner, per_wave = np.zeros(max(chunks, 1), np.uint32), np.zeros(grid * 4, np.uint32)
             bad = shim.shim_deal_all(plan.ctypes.data_as(C.c_void_p), C.c_uint32(grid), C.c_uint32(chunks), owner.ctypes.data_as(C.c_void_p), per_wave.ctypes.data_as(C.c_void_p))
-            assert bad == 0, (n, grid, weighted)
-            assert (owner[:chunks] != 0xFFFFFFFF).all(), (n, grid, weighted, int((owner[:chunks] == 0xFFFFFFFF).sum()))
+            assert bad == 0, (n, grid, weighted, scale)
+            assert (owner[:chunks] != 0xFFFFFFFF).all(), (n, grid, weighted, scale, int((owner[:chunks] == 0xFFFFFFFF).sum()))
             assert chunks <= int(per_wave.sum()) <= chunks + grid * 4  # at most one slot per wave past the end
             if field(plan, "weighted"):
                 assert per_wave.max() <= 64  # a wave's chunk table is one VGPR
@@ -60,6 +60,9 @@ def test_the_headline_shape_is_dealt_weighted_and_later_generations_take_fewer_r
     assert field(plan, "weighted") == 1 and field(plan, "waves") == 6144 and field(plan, "cmds") == 156250
     rounds = [field(plan, "r%d" % k) for k in range(6)]
     assert rounds == sorted(rounds, reverse=True) and rounds[0] > rounds[5]
+    packed = plan_of(shim, 156250, scale=1100)  # the packed walk's table: steeper, the last generation still takes part
+    rp = [field(packed, "r%d" % k) for k in range(6)]
+    assert field(packed, "weighted") == 1 and rp == sorted(rp, reverse=True) and rp[0] - rp[5] > rounds[0] - rounds[5]
     assert field(plan, "tileCmds") == 768 and field(plan, "numTiles") == 204
     # other grid shapes, tiny passes and passes of more than 64 chunks per wave fall back to plain round-robin
     assert field(plan_of(shim, 156250, grid=768, generations=3), "weighted") == 0
@@ -73,7 +76,7 @@ def test_the_hosts_plan_is_the_plan_a_wave_derives(shim):
     """the host divides through its prepared multipliers, a wave whose count word disagrees with the plan divides plainly: the same plan either way"""
     rng = np.random.default_rng(1)
     for n in COUNTS + [int(x) for x in rng.integers(1, 4_000_000, 200)]:
-        for scale in (100, 70, 0, 130):
+        for scale in (100, 70, 0, 130, 1100, 1070):
             a, b = plan_of(shim, n, scale=scale, magic=1), plan_of(shim, n, scale=scale, magic=0)
             assert (a == b).all(), (n, scale, a, b)
 
@@ -89,7 +92,7 @@ def test_the_largest_grid_the_magic_is_offered_for(shim):
     rng = np.random.default_rng(7)
     edge = [40 * W * 4, 59 * W * 4 - 1, 59 * W * 4, 60 * W * 4 - 4, 60 * W * 4 - 1, 60 * W * 4, 60 * W * 4 + 1, 61 * W * 4, 65535 * 64, 65535 * 64 - 1, 4 * W * 4, 4 * W * 4 - 1]
     for n in edge + [int(x) for x in rng.integers(1, 65535 * 64, 300)]:
-        for scale in (100, 70, 130):
+        for scale in (100, 70, 130, 1100):
             a, b = plan_of(shim, n, grid=grid, scale=scale, magic=1), plan_of(shim, n, grid=grid, scale=scale, magic=0)
             assert (a == b).all(), (n, scale)
     assert field(plan_of(shim, 40 * W * 4, grid=grid), "weighted") == 1  # (this shape does reach the weighted division)
