@@ -16,6 +16,9 @@ kernel in the file:
      as `; nv_ready all`).  Any other instruction that reads or writes an in-flight VGPR (a v_mov the allocator inserted
      to split a live range, a spill, a compiler-scheduled use) is reported, and so is an in-flight register at s_endpgm.
 
+  4. address spaces.  No flat_* instruction in any kernel of the file (an LDS pointer kept across a ring decays to a generic one: flat loads count on vmcnt
+     and hipcc then waits for the whole ring per iteration — slow, not wrong).
+
   3. counted waits.  `s_waitcnt vmcnt(N)` returns once at most N vector-memory operations are outstanding, and they complete in
      order, so a wait that names a slot is sufficient only if AT LEAST N younger VMEM operations (loads, stores and atomics: all
      of them count on gfx9) were issued after the slot's load on EVERY path to the wait — with fewer, the slot's load may be among
@@ -327,6 +330,18 @@ def main():
                 print("   +%d  %s    v%d: only %d younger VMEM operation(s) on some path, the wait allows %d outstanding" % (no, t, r, k, n))
         weak += len(found)
     bad += weak
+    # check 4 (round 6): no FLAT memory instruction in the file's kernels.  Every pointer here is global (kernel arguments) or LDS; an LDS pointer that is kept in a
+    # register across an asm ring decays to a generic one, hipcc then emits flat loads — which count on vmcnt AND lgkmcnt — and waits for the whole ring in front
+    # of every iteration (the packed walk lost a third of its speed that way before its table offsets were integers again); results stay right, so only this sees it
+    flat = 0
+    for name, lines in kernels(isa):
+        hits = [ln.strip() for ln in lines if re.match(r"\s*flat_(load|store|atomic)", ln)]
+        if hits:
+            print("%s: %d flat memory instruction(s) — an LDS or global pointer lost its address space (first: %s)" % (name, len(hits), hits[0]))
+        flat += len(hits)
+    bad += flat
+    if not flat:
+        print("address spaces: no flat memory instruction in any kernel")
     if not bad:
         print("in-flight scan: no instruction touches a ring register between its issue and its wait (%d kernels)" % len(kernels(isa)))
         print("counted waits: every vmcnt(N) that names a slot has at least N younger vector-memory operations behind the slot's load on every path (%d waits, no exemptions)" % waits)
