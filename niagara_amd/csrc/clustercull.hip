@@ -835,11 +835,7 @@ NV_DEV void packed_walk(const ClusterArgs& a, char* tabBytes, uint64_t* heads, u
 	auto map_next = [&]()
 	{
 		// (the heads word is the same in every lane: through the scalar unit, so that the running count of commands costs no vector instruction)
-#ifdef NV_WALK_VMAP
-		const uint32_t hlo = (uint32_t)H, hhi = (uint32_t)(H >> 32);
-#else
 		const uint32_t hlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)H), hhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(H >> 32));
-#endif
 		rkNext = __umul24(__builtin_amdgcn_mbcnt_hi(hhi, __builtin_amdgcn_mbcnt_lo(hlo, startsBefore)), CP_ENTRY);
 		startsBefore += (uint32_t)__builtin_popcount(hlo) + (uint32_t)__builtin_popcount(hhi);
 		const uint32_t e = ePos < eLast ? ePos : eLast; // the lanes past the list's end (and the ring's windows past its last) re-read the last entry: in range, unconditional
