@@ -460,7 +460,7 @@ def frame_field(device_index, iters):
         raise SystemExit("parity failure in the frame: " + str(r["parity"]))
     keep = ("frame_us", "frac", "achieved_GBs", "algorithmic_bytes", "algorithmic_bytes_by_pass", "sum_of_kernels_us", "kernel_variants", "early", "late", "frames_timed",
             "scene_copies_rotated", "meshlets_tested_per_frame", "meshlets_per_s", "draws_per_s", "oracle_frames_simulated", "parity", "roofline_valu")
-    f = {"what": r["config"], "regime": "one frame after the other on one stream; per-launch times = the library's HIP event pairs in separate frames"}
+    f = {"what": r["config"], "regime": "one frame after the other on one stream, the shortest of three loops of %d frames; per-launch times = the library's HIP event pairs in separate frames" % iters}
     f.update({k: r[k] for k in keep if k in r})
     f["launch_us"] = {k[:-3]: r[k] for k in r if k.endswith("_us") and k not in ("frame_us", "sum_of_kernels_us")}
     f["parity_checked"] = "task commands, count words, visible-ID lists + submit padding, drawVisibility, meshletVisibility of both phases and the pyramid of one frame after the same history"

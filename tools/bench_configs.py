@@ -426,12 +426,15 @@ def config_frame(ctx, iters, n_draws=1_000_000, lod0=2200, size=4096, copies=3, 
         frame(k)
         k += 1
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        frame(k)
-        k += 1
-    torch.cuda.synchronize()
-    frame_us = (time.perf_counter() - t0) / iters * 1e6
+    frame_us = None
+    for _ in range(3):  # (the shortest of three timed loops, as plain_wall: a loop of 30 frames is 6 ms of wall time and one scheduling hiccup of the launching thread is a tenth of it)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            frame(k)
+            k += 1
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / iters * 1e6
+        frame_us = t if frame_us is None or t < frame_us else frame_us
 
     # per-pass breakdown: the library's event pairs, read (and thereby synchronised) after every phase
     names = ("early_drawcull", "early_cluster_cull", "early_cluster_scatter", "pyramid", "late_drawcull", "late_cluster_cull", "late_cluster_hiz", "late_cluster_scatter")
