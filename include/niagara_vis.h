@@ -251,6 +251,11 @@ int nv_profile_variants(nv_context* ctx, uint32_t out_count[NV_VARIANT_SLOTS]);
  * writes its own draws' commands; fastest for meshes of one or two task groups), 2 = always the list form (one lane per output
  * command; fastest for meshes of many task groups).  Speed only. */
 #define NV_OPT_TASK_EMIT 7
+/* NV_OPT_DRAW_RECORDS (default 0): the order in which nv_drawcull's EARLY pass requests its inputs — 0 = by the statistic of the last
+ * task pass (visibility words first once it emitted from fewer than one draw in eight), 1 = always the records together with the
+ * visibility words, 2 = always the visibility words first and then only the records of last frame's visible draws (the others leave
+ * at drawcull.comp.glsl:66 whatever their record holds).  Speed only; the late pass decides every draw and reads every record. */
+#define NV_OPT_DRAW_RECORDS 8
 int nv_set_option(nv_context* ctx, int option, int value);
 
 /* ---- capacities ----

@@ -196,7 +196,7 @@ struct DrawArgs
 	uint32_t meshCount;  // > 0 when nv_upload_meshes registered `meshes`: the table may be staged in LDS
 	uint32_t* hostHint;  // mapped host words (context.hip): [2], [3] = emitting draws / commands of the last TASK pass, written by its scatter launch
 	uint32_t taskList;   // TASK scatter in the list form (one lane per output command) instead of the per-draw form
-	uint32_t stagedBase; // late pass: first texel (offset from the pyramid base) of the coarse levels the decide kernel stages in LDS; ~0u = none
+	uint32_t visFirst;   // early pass: request the visibility words ahead of the records and only the records of last frame's visible draws (a hint: results do not depend on it)
 #ifdef NV_EXPERIMENTS
 	uint32_t debugMode; // NV_DEBUG_MODE of the experiments build
 #endif

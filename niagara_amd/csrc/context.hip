@@ -105,11 +105,11 @@ struct nv_context
 	uint32_t scatterTilesPerCU;
 	uint32_t scatterWaves; // NV_OPT_SCATTER_WAVES: waves per workgroup of the cluster scatter launch (16; 4 / 8)
 	uint32_t scatterTilesAbs; // experiments: absolute number of scatter tiles (0 = per CU)
-	uint32_t hizLds; // stage the coarse pyramid levels in LDS for drawcull's late pass (experiments: measured slower)
 	uint32_t directPercent; // share of commands passing the filter above which the next launch skips the filter pass
 	uint32_t bitsBlocksPerCU; // cluster_bits_kernel: grid (blocks per CU)
 	uint32_t taskcullOneLaunch; // experiments: nv_taskcull's early pass as the one-command-per-wave kernel (the round-1 form)
 	int forceDirect;        // NV_OPT_CULL_FORM: -1 = by the previous launch's statistic, 0 / 1 = always filter / always direct, 2 = direct and never the bit-expanding early form
+	int forceVisFirst;      // NV_OPT_DRAW_RECORDS: -1 = by the statistic of the last TASK pass, 0 / 1 = records with / after the visibility words in drawcull's early pass
 	int forceTaskList;      // NV_OPT_TASK_EMIT: -1 = by the statistic of earlier TASK passes, 0 / 1 = per-draw / list form of drawcull's TASK scatter
 	int forceShallow;       // NV_OPT_CULL_RING: -1 = by the previous launch's command count, 0 / 1 = always the 8-deep / the 4-deep ring
 	// command count of the previous clustercull launch, written by its kernel into mapped host memory (tuning hint)
@@ -390,12 +390,11 @@ int nv_create(nv_context** out_ctx, int device)
 	ctx->taskcullOneLaunch = 0;
 	ctx->forceShallow = -1;
 	ctx->forceTaskList = -1;
+	ctx->forceVisFirst = -1;
 	ctx->listStride = nv::clustercull_list_stride();
 	ctx->listSharers = 4;
 	ctx->listMinPer = 8;
 #ifdef NV_EXPERIMENTS
-	if (const char* v = getenv("NV_HIZ_LDS"))
-		ctx->hizLds = (uint32_t)atoi(v);
 	if (const char* v = getenv("NV_DIRECT"))
 		ctx->forceDirect = atoi(v);
 	if (const char* v = getenv("NV_TASKCULL_ONE_LAUNCH"))
@@ -517,6 +516,11 @@ int nv_set_option(nv_context* ctx, int option, int value)
 		if (value < 0 || value > 2)
 			return NV_EINVAL;
 		ctx->forceTaskList = value - 1;
+		return NV_OK;
+	case NV_OPT_DRAW_RECORDS:
+		if (value < 0 || value > 2)
+			return NV_EINVAL;
+		ctx->forceVisFirst = value - 1;
 		return NV_OK;
 	case NV_OPT_CULL_RING:
 		if (value != 0 && value != 4 && value != 8)
@@ -777,18 +781,8 @@ int nv_drawcull(nv_context* ctx, void* stream, const NvCullData* cull, int late,
 	// TASK scatter form: the list form (one lane per output command) when an earlier TASK pass emitted more than 4 commands per
 	// emitting draw, the per-draw form otherwise (and until a pass has been seen); NV_OPT_TASK_EMIT pins it
 	a.taskList = ctx->forceTaskList >= 0 ? (uint32_t)ctx->forceTaskList : (ctx->hintHost && ctx->hintHost[3] > 4u * ctx->hintHost[2] ? 1u : 0u);
-	// LDS-staged coarse pyramid levels for the late pass's HiZ probes: measured slower than reading them through L2 (a
-	// workgroup of 512 draws stages 22 KiB to serve the ~20 probes of its visible draws; EXPERIMENTS.md (B) §4.3) — off unless asked for
-	a.stagedBase = ~0u;
-#ifdef NV_EXPERIMENTS
-	if (late && ctx->hizLds && pyramid && pyramid->levels)
-		for (uint32_t l = 0; l < pyramid->levels; ++l)
-			if (pyramid->totalTexels - pyramid->mipOffset[l] <= 5632u)
-			{
-				a.stagedBase = pyramid->mipOffset[l];
-				break;
-			}
-#endif
+	// early pass: visibility words first, and only the records of last frame's visible draws, when the last TASK pass emitted from fewer than one draw in eight
+	a.visFirst = late ? 0u : (ctx->forceVisFirst >= 0 ? (uint32_t)ctx->forceVisFirst : (ctx->hintHost && ctx->hintHost[2] != 0u && (uint64_t)ctx->hintHost[2] * 8u < cull->drawCount ? 1u : 0u));
 	if (task)
 	{
 		ctx->variants[a.taskList ? NV_VARIANT_TASK_LIST : NV_VARIANT_TASK_PER_DRAW] += 1u;

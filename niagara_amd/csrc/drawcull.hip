@@ -3,11 +3,11 @@
 // Replaces src/shaders/drawcull.comp.glsl:54-156 (4 pipelines LATE x TASK, src/niagara.cpp:724-727).
 //
 // Mapping to CDNA4 — two wait-free launches on the stream, the same scheme as clustercull.hip:
-//   K1 draw_decide_kernel   one lane per draw, 1024 draws per workgroup, all four 52-B records of a lane requested
-//                           before the first is used.  Decides visibility / LOD (reference arithmetic), writes one
-//                           result byte per draw (LOD | emit << 3 | old visibility << 4), the new drawVisibility word
-//                           (LATE), and adds each wave's command count to the count of the scatter tile it falls in
-//                           (one fire-and-forget atomic per wave that emits anything).
+//   K1 draw_decide_kernel   one lane per draw; a grid that does not grow with the draw count, each wave walking its own range of
+//                           64-draw units with the records of the next DS_DEPTH units in flight.  Decides visibility / LOD
+//                           (reference arithmetic), writes one result byte per draw (LOD | emit << 3 | old visibility << 4),
+//                           the new drawVisibility word (LATE), and adds its command counts to the counts of the scatter tiles
+//                           they fall in (one fire-and-forget atomic per wave and tile).
 //   K2 draw_scatter_kernel  one workgroup per CU owns a contiguous range of draws; its append base is the count word
 //                           plus the counts of the tiles before it, so no workgroup waits on another.  Each lane owns
 //                           16 consecutive draws (one 16-B load of result bytes); the append index of a draw is the
@@ -24,19 +24,6 @@ namespace nv
 
 constexpr int DC_WAVES = 4;
 constexpr int DC_THREADS = DC_WAVES * 64;
-constexpr int DC_BATCH = 2;                          // draws per lane of the decide kernel
-// (round 4, tools/build_variant.sh, config 2 with the fused reset / the frame's two drawcull passes: 2 draws per lane x 4 waves as built 14.4 / 21-22 + 24 us;
-//  4 x 4: 15.4-15.5 / 22 + 25; 1 x 4: 14.9 / 22-26 + 25; 8 x 4: 17.5 / 24 + 28; 2 x 8: 19.3 / 25.5 + 26; 4 x 8: 21.5 / 27 + 28; 2 x 2: 17.1 / 27 + 29)
-constexpr uint32_t DC_TILE = DC_THREADS * DC_BATCH;   // draws per workgroup of the decide kernel
-// LDS-staged coarse pyramid levels for the late pass's HiZ probes (north_star: "LDS-staged HiZ tiles"): implemented,
-// measured, and compiled into the experiments build only — 1 M draws with HiZ took 31.4 us with the tail of a 2048^2 pyramid
-// (levels 5..11, 5461 texels) staged per workgroup against 24.9 us reading the same texels through L2: a workgroup of 512
-// draws copies 22 KiB to serve the ~20 probes of its visible draws, and the LDS footprint costs a resident workgroup.
-#ifdef NV_EXPERIMENTS
-constexpr uint32_t DC_HIZ_TAIL = 5632; // texels a workgroup may stage (22 KiB)
-#else
-constexpr uint32_t DC_HIZ_TAIL = 1;
-#endif
 constexpr uint32_t DC_MESH_LDS = 64;  // meshes staged in LDS (13 KiB) when the table is registered and small enough
 
 
@@ -110,20 +97,14 @@ NV_DEV DrawPre decide_pre(const DrawArgs& a, const char* meshBase, const float4&
 	return pre;
 }
 
-// drawcull.comp.glsl:86-99.  Texels of the staged pyramid tail (experiments build: levels copied to LDS by the workgroup,
-// north_star's "LDS-staged HiZ tiles") come from LDS, the others from global memory.
-NV_DEV bool draw_probe(const DrawArgs& a, f3 c, float radius, const float* hizTail)
+// drawcull.comp.glsl:86-99
+NV_DEV bool draw_probe(const DrawArgs& a, f3 c, float radius)
 {
 	const HizProbe p = hiz_prepare(a.cd, a.pyr, c, radius, a.pyr.mipOffset);
 	if (!(p.use & 16u))
 		return true;
 	const float* base = a.pyr.d_base;
-	const uint32_t sb = DC_HIZ_TAIL > 1 ? a.stagedBase : ~0u; // ~0u: nothing staged
-	const float t00 = p.o00 >= sb ? hizTail[p.o00 - sb] : base[p.o00];
-	const float t10 = p.o10 >= sb ? hizTail[p.o10 - sb] : base[p.o10];
-	const float t01 = p.o01 >= sb ? hizTail[p.o01 - sb] : base[p.o01];
-	const float t11 = p.o11 >= sb ? hizTail[p.o11 - sb] : base[p.o11];
-	return hiz_finish(p, t00, t10, t01, t11);
+	return hiz_finish(p, base[p.o00], base[p.o10], base[p.o01], base[p.o11]);
 }
 
 template <bool LATE, bool TASK, bool COMPACT>
@@ -201,7 +182,7 @@ struct DrawLoad
 // SOA: the streams of the mirror (a wave reads 1 KiB + 512 B + 256 B contiguous); otherwise the 48-B record in place
 // (three 16-B loads at a 48-B stride)
 template <bool SOA>
-NV_DEV DrawLoad load_draw_record(const DrawArgs& a, uint32_t di)
+NV_DEV DrawLoad load_draw_fields(const DrawArgs& a, uint32_t di)
 {
 	DrawLoad l;
 	if (SOA)
@@ -218,6 +199,14 @@ NV_DEV DrawLoad load_draw_record(const DrawArgs& a, uint32_t di)
 		l.d1 = p[1];
 		l.d2 = *reinterpret_cast<const uint4*>(p + 2);
 	}
+	l.oldVis = 0u;
+	return l;
+}
+
+template <bool SOA>
+NV_DEV DrawLoad load_draw_record(const DrawArgs& a, uint32_t di)
+{
+	DrawLoad l = load_draw_fields<SOA>(a, di);
 	l.oldVis = a.dvb[di];
 	return l;
 }
@@ -318,16 +307,45 @@ NV_DEV const char* stage_lod_commit(const DrawArgs& a, const LodStage& st, uint3
 	return reinterpret_cast<const char*>(s_lodTable);
 }
 
-// K1
-template <bool LATE, bool TASK, bool MESH_LDS, bool SOA>
+// K1: a grid that does not grow with the draw count (at most DS_MAX_BLOCKS workgroups = two waves per SIMD), each wave walking its own
+// contiguous range of 64-draw units with the records of the next DS_DEPTH units requested ahead of the one it decides — for 1 M draws
+// the dispatcher starts 2 k waves instead of the 7.8 k of one workgroup per 512 draws (rounds 1-5), and no wave's loads wait behind
+// its own arithmetic.  The decision is split in decide_pre / draw_probe / decide_post: what follows the frustum test (the occlusion
+// probe, the LOD choice, the counts) runs on the wave's own queue of survivors, up to 64 at a time on consecutive lanes — the probe's
+// ~360 instructions are executed once per 64 survivors instead of once per wave that holds one (round 2 compacted them per workgroup
+// behind two barriers) and no workgroup barrier follows the staging of the Mesh table.  The survivors of a wave are queued in draw
+// order, so the scatter tiles their counts fall in are non-decreasing and a wave adds to each tile's counter once.
+#ifndef DS_MAX_BLOCKS
+#define DS_MAX_BLOCKS 512
+#endif
+#ifndef DS_DEPTH
+#define DS_DEPTH 4
+#endif
+constexpr uint32_t DS_QUEUE = 128; // survivors a wave may hold: a unit adds at most 64 to fewer than 64
+
+struct TileRun
+{
+	uint32_t tile, sum, emit;
+};
+
+template <bool TASK>
+NV_DEV void tile_run_flush(const DrawArgs& a, uint32_t bank, const TileRun& run, uint32_t lane)
+{
+	if (lane == 0 && !NV_DBG(a, 4u))
+	{
+		if (run.sum)
+			atomicAdd(&a.tileCounts->counts[bank][run.tile * CC_COUNT_STRIDE], run.sum);
+		if (TASK && run.emit)
+			atomicAdd(&a.tileCounts->counts[bank][run.tile * CC_COUNT_STRIDE + 1], run.emit);
+	}
+}
+
+template <bool LATE, bool TASK, bool MESH_LDS, bool SOA, bool VISFIRST>
 __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 {
-	// the Mesh table (center/radius, LOD errors, LOD ranges) is read by every draw: staged once per workgroup when
-	// nv_upload_meshes registered a table of at most DC_MESH_LDS meshes, otherwise gathered from global memory
 	__shared__ __attribute__((aligned(16))) uint32_t s_lodTable[MESH_LDS ? DC_MESH_LDS * DC_LOD_WORDS : 4];
-	// the coarse end of the depth pyramid (late pass, when the host asks for it): every level from a.stagedLevel up, at most
-	// DC_HIZ_TAIL texels (levels 5..11 of a 2048^2 pyramid = 5461)
-	__shared__ float s_hizTail[LATE ? DC_HIZ_TAIL : 1];
+	__shared__ float4 s_q0[DC_WAVES][DS_QUEUE]; // view-space centre, radius
+	__shared__ uint4 s_q1[DC_WAVES][DS_QUEUE];  // scale, meshIndex, draw, previous visibility
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
@@ -342,149 +360,173 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 		a.tileCounts->base = a.fusedReset ? 0u : a.count4[0];
 	}
 
-	const uint32_t first = blockIdx.x * DC_TILE;
-	if (first >= drawCount)
-		return;
-	const uint32_t n = drawCount - first < DC_TILE ? drawCount - first : DC_TILE;
+	// the wave's units: [u0, u1)
+	const uint32_t units = (drawCount + 63u) / 64u;
+	const uint32_t waves = gridDim.x * DC_WAVES;
+	const uint32_t per = (units + waves - 1u) / waves;
+	const uint32_t w = blockIdx.x * DC_WAVES + wave;
+	const uint32_t u0 = w * per < units ? w * per : units;
+	const uint32_t u1 = u0 + per < units ? u0 + per : units;
 
-	// Indices past the tile are clamped, not branched, so that the loads are unconditional and the compiler can count
-	// them (s_waitcnt vmcnt(N)) instead of draining after each one.
+	// Indices past the range are clamped, not branched: unconditional loads the compiler can count (s_waitcnt vmcnt(N)).
+	// VISFIRST (early pass, when few draws were visible last frame): the visibility words run DS_DEPTH units ahead of the records, and
+	// a lane whose draw was not visible — it leaves at drawcull.comp.glsl:66 whatever its record holds — requests the record of the
+	// unit's first draw instead of its own: the instruction stays unconditional, the lines it fetches are those of the visible draws.
+	static_assert(!(LATE && VISFIRST), "the late pass decides every draw");
+	const uint32_t lastDraw = drawCount ? drawCount - 1u : 0u;
+	auto draw_of = [&](uint32_t u, uint32_t l) {
+		const uint32_t uc = u < u1 ? u : (u1 ? u1 - 1u : 0u);
+		const uint32_t di = uc * 64u + l;
+		return di < lastDraw ? di : lastDraw;
+	};
+	auto request = [&](DrawLoad& slot, uint32_t u) { slot = load_draw_record<SOA>(a, draw_of(u, lane)); };
+	auto request_visible = [&](DrawLoad& slot, uint32_t u, uint32_t vis) {
+		slot = load_draw_fields<SOA>(a, draw_of(u, vis != 0 ? lane : 0u));
+		slot.oldVis = vis != 0 ? 1u : 0u; // (a value of its own: the register of the word just read is free for the next one)
+	};
 	const LodStage st = stage_lod_issue<MESH_LDS>(a);
-	DrawLoad ld[DC_BATCH];
+	DrawLoad ring[DS_DEPTH];
+	uint32_t visRing[DS_DEPTH]; // VISFIRST: visRing[k] = the visibility words of the unit DS_DEPTH after ring[k]'s
+	if (VISFIRST)
+	{
+		uint32_t first[DS_DEPTH];
 #pragma unroll
-	for (int j = 0; j < DC_BATCH; ++j)
-	{
-		const uint32_t c = j * DC_THREADS + tid;
-		ld[j] = load_draw_record<SOA>(a, first + (c < n ? c : n - 1));
+		for (uint32_t k = 0; k < DS_DEPTH; ++k)
+			first[k] = a.dvb[draw_of(u0 + k, lane)];
+#pragma unroll
+		for (uint32_t k = 0; k < DS_DEPTH; ++k)
+			visRing[k] = a.dvb[draw_of(u0 + DS_DEPTH + k, lane)];
+#pragma unroll
+		for (uint32_t k = 0; k < DS_DEPTH; ++k)
+			request_visible(ring[k], u0 + k, first[k]);
 	}
-	if (LATE && DC_HIZ_TAIL > 1 && a.stagedBase != ~0u)
+	else
 	{
-		const uint32_t n_tail = a.pyr.totalTexels - a.stagedBase;
-		for (uint32_t i = tid; i < n_tail && i < DC_HIZ_TAIL; i += DC_THREADS)
-			s_hizTail[i] = a.pyr.d_base[a.stagedBase + i];
-		if (!MESH_LDS)
-			__syncthreads();
+#pragma unroll
+		for (uint32_t k = 0; k < DS_DEPTH; ++k)
+			request(ring[k], u0 + k);
 	}
 	const char* meshBase = stage_lod_commit<MESH_LDS>(a, st, s_lodTable);
+	if (u0 >= u1 || drawCount == 0)
+		return;
 
-	// per wave-batch command counts -> LDS; merged per scatter tile below
-	__shared__ uint32_t s_waveCount[DC_BATCH * DC_WAVES];
-	__shared__ uint32_t s_waveEmit[DC_BATCH * DC_WAVES]; // TASK: draws of the wave-batch that emit commands (the host's statistic)
-	DrawPre pre[DC_BATCH];
-	bool visible[DC_BATCH];
-#pragma unroll
-	for (int j = 0; j < DC_BATCH; ++j)
-	{
-		const uint32_t c = j * DC_THREADS + tid;
-		pre[j] = decide_pre<LATE, MESH_LDS, SOA>(a, meshBase, ld[j].d0, ld[j].d1, ld[j].d2, ld[j].oldVis);
-		if (c >= n)
-			pre[j].skip = true;
-		visible[j] = !pre[j].skip && pre[j].visible;
-	}
-	// Late pass: the occlusion probe (~360 instructions, two dependent loads) is needed by the few per cent of the draws
-	// that pass the frustum test, i.e. by one or two lanes of nearly every wave — executed in place it costs every wave
-	// the full instruction stream (1 M draws: decide 16.5 us against 10.1 us without the probe).  The workgroup's
-	// requests are compacted through LDS instead and probed on consecutive lanes: once per workgroup in the sparse case,
-	// never more often than in place.
-	if (LATE && a.cd.occlusionEnabled == 1) // (uniform)
-	{
-		__shared__ float4 s_req[DC_TILE];
-		__shared__ uint16_t s_reqSlot[DC_TILE];
-		__shared__ uint32_t s_reqCount, s_seen[DC_TILE / 32];
-		if (tid == 0)
-			s_reqCount = 0;
-		if (tid < DC_TILE / 32)
-			s_seen[tid] = 0;
-		__syncthreads();
-#pragma unroll
-		for (int j = 0; j < DC_BATCH; ++j)
+	const bool probe = LATE && a.cd.occlusionEnabled == 1; // (uniform)
+	uint32_t queued = 0;
+	TileRun run = { u0 * 64u / T2, 0u, 0u };
+
+	// the queue's first `cnt` survivors on lanes 0..cnt-1: drawcull.comp.glsl:86-118 + :154-155
+	auto drain = [&](uint32_t cnt) {
+		const bool mine = lane < cnt;
+		uint32_t count = 0, di = 0;
+		if (mine)
 		{
-			const uint64_t want = __ballot(visible[j]);
-			if (want)
-			{
-				uint32_t slot = 0;
-				if (lane == 0)
-					slot = atomicAdd(&s_reqCount, (uint32_t)__builtin_popcountll(want));
-				slot = __builtin_amdgcn_readfirstlane(slot) + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
-				if (visible[j])
-				{
-					s_req[slot] = make_float4(pre[j].c.x, pre[j].c.y, pre[j].c.z, pre[j].radius);
-					s_reqSlot[slot] = (uint16_t)(j * DC_THREADS + tid);
-				}
-			}
-		}
-		__syncthreads();
-		const uint32_t requests = s_reqCount;
-		for (uint32_t r = tid; r < requests; r += DC_THREADS)
-		{
-			const float4 q = s_req[r];
-			if (draw_probe(a, f3{ q.x, q.y, q.z }, q.w, s_hizTail))
-			{
-				const uint32_t slot = s_reqSlot[r];
-				atomicOr(&s_seen[slot >> 5], 1u << (slot & 31u));
-			}
-		}
-		__syncthreads();
-#pragma unroll
-		for (int j = 0; j < DC_BATCH; ++j)
-		{
-			const uint32_t slot = j * DC_THREADS + tid;
-			visible[j] = visible[j] && (s_seen[slot >> 5] >> (slot & 31u) & 1u) != 0;
-		}
-	}
-#pragma unroll
-	for (int j = 0; j < DC_BATCH; ++j)
-	{
-		const uint32_t c = j * DC_THREADS + tid;
-		uint32_t count = 0;
-		if (c < n)
-		{
-			DrawResult res = { 0, 0, 0 };
-			if (NV_DBG(a, 1u)) // experiments: loads only
-				res.lodWord = __float_as_uint(ld[j].d0.x + ld[j].d1.x) + ld[j].d2.x + ld[j].oldVis == 12345u ? 0x100u : 0u;
-			else
-				res = decide_post<LATE, TASK, MESH_LDS>(a, pre[j], visible[j], first + c, ld[j].oldVis);
-			a.results[first + c] = (uint8_t)((res.lodWord & 7u) | ((res.lodWord >> 8 & 1u) << 3) | ((ld[j].oldVis != 0 ? 1u : 0u) << 4));
+			const float4 q0 = s_q0[wave][lane];
+			const uint4 q1 = s_q1[wave][lane];
+			di = q1.z;
+			DrawPre pre;
+			pre.c = f3{ q0.x, q0.y, q0.z };
+			pre.radius = q0.w;
+			pre.scale = __uint_as_float(q1.x);
+			pre.mesh = meshBase + (size_t)q1.y * (MESH_LDS ? DC_LOD_WORDS * 4u : sizeof(NvMesh));
+			pre.skip = false;
+			pre.visible = true;
+			const bool seen = probe ? draw_probe(a, pre.c, pre.radius) : true;
+			const DrawResult res = decide_post<LATE, TASK, MESH_LDS>(a, pre, seen, di, q1.w);
+			a.results[di] = (uint8_t)((res.lodWord & 7u) | ((res.lodWord >> 8 & 1u) << 3) | ((q1.w != 0 ? 1u : 0u) << 4));
 			count = res.count;
 		}
-		const uint32_t waveCount = wave_sum_u32(count);
-		const uint32_t waveEmit = TASK ? (uint32_t)__builtin_popcountll(__ballot(count != 0)) : 0u;
-		if (lane == 0)
+		// counts -> the wave's run of scatter tiles (draws ascend along the queue, so do their tiles)
+		uint64_t rest = __ballot(mine);
+		while (rest)
 		{
-			s_waveCount[j * DC_WAVES + wave] = waveCount;
-			s_waveEmit[j * DC_WAVES + wave] = waveEmit;
-		}
-	}
-	__syncthreads();
-	// One thread adds the workgroup's counts to the scatter tiles they fall in (tiles are whole multiples of 64 draws, so
-	// a wave-batch never straddles; a workgroup's 1024 draws usually span one or two tiles): ~1.3 atomics per
-	// workgroup instead of one per wave-batch — atomics into one line serialise in its L2 channel (args.h).
-	if (tid == 0 && !NV_DBG(a, 4u))
-	{
-		// (TASK: the tile's emitting draws go into word 1 of the same line — the scatter launch's last tile sums them for the host)
-		uint32_t runTile = first / T2, runSum = 0, runEmit = 0;
-#pragma unroll
-		for (uint32_t i = 0; i < DC_BATCH * DC_WAVES; ++i)
-		{
-			const uint32_t t = (first + i * 64u) / T2;
-			if (t != runTile)
+			const uint32_t head = (uint32_t)__builtin_ctzll(rest);
+			const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)di, (int)head) / T2;
+			const bool in = (rest >> lane & 1u) != 0 && di < (t + 1u) * T2;
+			const uint32_t sum = wave_sum_u32(in ? count : 0u);
+			const uint32_t emit = (uint32_t)__builtin_popcountll(__ballot(in && count != 0));
+			if (t != run.tile)
 			{
-				if (runSum)
-					atomicAdd(&a.tileCounts->counts[bank][runTile * CC_COUNT_STRIDE], runSum);
-				if (TASK && runEmit)
-					atomicAdd(&a.tileCounts->counts[bank][runTile * CC_COUNT_STRIDE + 1], runEmit);
-				runTile = t;
-				runSum = 0;
-				runEmit = 0;
+				tile_run_flush<TASK>(a, bank, run, lane);
+				run = TileRun{ t, 0u, 0u };
 			}
-			runSum += s_waveCount[i];
-			runEmit += s_waveEmit[i];
+			run.sum += sum;
+			run.emit += emit;
+			rest &= ~__ballot(in);
 		}
-		if (runSum)
-			atomicAdd(&a.tileCounts->counts[bank][runTile * CC_COUNT_STRIDE], runSum);
-		if (TASK && runEmit)
-			atomicAdd(&a.tileCounts->counts[bank][runTile * CC_COUNT_STRIDE + 1], runEmit);
+		// what is left moves to the front
+		if (queued > cnt)
+		{
+			float4 m0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			uint4 m1 = make_uint4(0u, 0u, 0u, 0u);
+			const bool moves = lane < queued - cnt;
+			if (moves)
+			{
+				m0 = s_q0[wave][cnt + lane];
+				m1 = s_q1[wave][cnt + lane];
+			}
+			if (moves)
+			{
+				s_q0[wave][lane] = m0;
+				s_q1[wave][lane] = m1;
+			}
+		}
+		queued -= cnt;
+	};
+
+	auto decide = [&](const DrawLoad& ld, uint32_t u) {
+		const uint32_t di = u * 64u + lane;
+		const bool valid = u < u1 && di < drawCount;
+		DrawPre pre = decide_pre<LATE, MESH_LDS, SOA>(a, meshBase, ld.d0, ld.d1, ld.d2, ld.oldVis);
+		const bool survives = valid && !pre.skip && pre.visible;
+		// a draw that is not part of the pass or fails the frustum test ends here: no command, LATE: drawVisibility 0 (decide_post with visible = false)
+		if (valid && !survives)
+		{
+			a.results[di] = (uint8_t)((ld.oldVis != 0 ? 1u : 0u) << 4);
+			if (LATE && !pre.skip)
+				a.dvb[di] = 0u;
+		}
+		const uint64_t want = __ballot(survives);
+		if (want)
+		{
+			const uint32_t slot = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+			if (survives)
+			{
+				s_q0[wave][slot] = make_float4(pre.c.x, pre.c.y, pre.c.z, pre.radius);
+				s_q1[wave][slot] = make_uint4(__float_as_uint(pre.scale), ld.d2.x, di, ld.oldVis);
+			}
+			queued += (uint32_t)__builtin_popcountll(want);
+		}
+	};
+
+	// Every slot of the ring is decided and requested again in every round (units past the wave's range: clamped loads, nothing
+	// written), and a slot's new loads are issued only after the last use of its old values — so that the loop carries the ring in
+	// the same registers and the back edge holds no copy of a register with a load in flight (hipcc waits for a load before it
+	// moves its destination: with the request ahead of the decision the ring drained to vmcnt(0) once per round).
+	const uint32_t rounds = (u1 - u0 + DS_DEPTH - 1u) / DS_DEPTH;
+	for (uint32_t r = 0, u = u0; r < rounds; ++r, u += DS_DEPTH)
+	{
+#pragma unroll
+		for (uint32_t k = 0; k < DS_DEPTH; ++k)
+		{
+			if (u + k < u1) // (uniform; a pass of few draws has one unit per wave and DS_DEPTH - 1 idle slots)
+				decide(ring[k], u + k);
+			asm volatile("" ::: "memory");
+			if (VISFIRST)
+			{
+				request_visible(ring[k], u + k + DS_DEPTH, visRing[k]);
+				asm volatile("" ::: "memory");
+				visRing[k] = a.dvb[draw_of(u + k + 2u * DS_DEPTH, lane)];
+			}
+			else
+				request(ring[k], u + k + DS_DEPTH);
+			asm volatile("" ::: "memory");
+			if (queued >= 64u)
+				drain(64u);
+		}
 	}
+	if (queued)
+		drain(queued);
+	tile_run_flush<TASK>(a, bank, run, lane);
 }
 
 // result bytes of PER consecutive draws, packed little-endian into words
@@ -865,33 +907,45 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 }
 
 template <bool MESH_LDS, bool SOA>
-static void launch_decide(hipStream_t stream, const DrawArgs& a, int late, int task, uint32_t decideBlocks)
+static void launch_decide(hipStream_t stream, const DrawArgs& a, int late, int task)
 {
-	dim3 grid(decideBlocks), block(DC_THREADS);
+	const uint32_t units = (a.cd.drawCount + 63u) / 64u, want = (units + DC_WAVES - 1u) / DC_WAVES;
+	const dim3 grid(want < 1u ? 1u : (want < DS_MAX_BLOCKS ? want : DS_MAX_BLOCKS)), block(DC_THREADS);
 	if (late)
 	{
 		if (task)
-			hipLaunchKernelGGL((draw_decide_kernel<true, true, MESH_LDS, SOA>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((draw_decide_kernel<true, true, MESH_LDS, SOA, false>), grid, block, 0, stream, a);
 		else
-			hipLaunchKernelGGL((draw_decide_kernel<true, false, MESH_LDS, SOA>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((draw_decide_kernel<true, false, MESH_LDS, SOA, false>), grid, block, 0, stream, a);
+	}
+#ifdef DS_FORCE_VISFIRST // (tools/build_variant.sh: A/B of the two early forms)
+	else if (DS_FORCE_VISFIRST)
+#else
+	else if (a.visFirst)
+#endif
+	{
+		if (task)
+			hipLaunchKernelGGL((draw_decide_kernel<false, true, MESH_LDS, SOA, true>), grid, block, 0, stream, a);
+		else
+			hipLaunchKernelGGL((draw_decide_kernel<false, false, MESH_LDS, SOA, true>), grid, block, 0, stream, a);
 	}
 	else
 	{
 		if (task)
-			hipLaunchKernelGGL((draw_decide_kernel<false, true, MESH_LDS, SOA>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((draw_decide_kernel<false, true, MESH_LDS, SOA, false>), grid, block, 0, stream, a);
 		else
-			hipLaunchKernelGGL((draw_decide_kernel<false, false, MESH_LDS, SOA>), grid, block, 0, stream, a);
+			hipLaunchKernelGGL((draw_decide_kernel<false, false, MESH_LDS, SOA, false>), grid, block, 0, stream, a);
 	}
 }
 
 template <bool MESH_LDS>
-static void launch_dc(hipStream_t stream, const DrawArgs& a, int late, int task, uint32_t decideBlocks)
+static void launch_dc(hipStream_t stream, const DrawArgs& a, int late, int task)
 {
 	dim3 block(DC_THREADS);
 	if (a.soaWorld)
-		launch_decide<MESH_LDS, true>(stream, a, late, task, decideBlocks);
+		launch_decide<MESH_LDS, true>(stream, a, late, task);
 	else
-		launch_decide<MESH_LDS, false>(stream, a, late, task, decideBlocks);
+		launch_decide<MESH_LDS, false>(stream, a, late, task);
 	const uint32_t t = (a.cd.drawCount + a.scatterTiles - 1) / a.scatterTiles; // scatter_tile_draws, before rounding
 	const dim3 sgrid(a.scatterTiles);
 #define LAUNCH_TASK_SCATTER(PER)                                                                                      \
@@ -924,11 +978,10 @@ static void launch_dc(hipStream_t stream, const DrawArgs& a, int late, int task,
 
 int launch_drawcull(hipStream_t stream, const DrawArgs& a, int late, int task)
 {
-	const uint32_t decideBlocks = (a.cd.drawCount + DC_TILE - 1) / DC_TILE;
 	if (a.meshCount && a.meshCount <= DC_MESH_LDS)
-		launch_dc<true>(stream, a, late, task, decideBlocks ? decideBlocks : 1u);
+		launch_dc<true>(stream, a, late, task);
 	else
-		launch_dc<false>(stream, a, late, task, decideBlocks ? decideBlocks : 1u);
+		launch_dc<false>(stream, a, late, task);
 	return (int)hipGetLastError();
 }
 

@@ -42,6 +42,7 @@ NV_OPT_SCATTER_WAVES = 4
 NV_OPT_CULL_FORM = 5
 NV_OPT_CULL_RING = 6
 NV_OPT_TASK_EMIT = 7
+NV_OPT_DRAW_RECORDS = 8
 
 
 class Context:

@@ -91,6 +91,42 @@ def test_drawcull_flag_matrix(ctx, late, task):
     ctx.status()
 
 
+@pytest.mark.parametrize("n_draws", [1, 63, 64, 65, 257, 4097, 70_001, 300_000])
+def test_drawcull_ring_and_queue_shapes(ctx, n_draws):
+    """The decide launch walks 64-draw units per wave behind a ring of requests and queues the frustum's survivors per wave (round 6):
+    draw counts that leave partial units, partial rounds of the ring and waves without a unit; every draw surviving (culling off: the queue
+    drains inside the walk and its remainder moves to the front), a few, none; early and late; the early pass with the records requested
+    together with the visibility words and after them (NV_OPT_DRAW_RECORDS 1 / 2), mirror and records in place: the oracle's commands,
+    count and drawVisibility."""
+    scene = make_scene(seed=77 + n_draws % 13, n_draws=n_draws, post_pass_fraction=0.05)
+    pyr = oracle.Pyramid(*scene["viewport"])
+    oracle.depthreduce(scene["depth"], pyr)
+    rng = np.random.default_rng(n_draws)
+    try:
+        for use_soa in ((True, False) if n_draws <= 70_001 else (True,)):
+            g = G.GpuScene(ctx, scene, use_soa)
+            g.depthreduce(scene["depth"])
+            for flags in ((0, 1, 0, 0, 1), (1, 1, 1, 1, 1)):
+                cd = passes.set_flags(scene["cull"], flags)
+                for fraction in (1.0, 0.03, 0.0):
+                    dvb0 = (rng.random(n_draws) < fraction).astype(np.uint32)
+                    for late, task, records in ((0, 0, 1), (0, 1, 2), (0, 0, 2), (1, 1, 0), (1, 0, 0)):
+                        ctx.set_option(P.NV_OPT_DRAW_RECORDS, records)
+                        dvb_o = dvb0.copy()
+                        co, c4o = passes.run_drawcull(oracle, scene, cd, late, task, dvb_o, pyr)
+                        dcb, dccb, dvb = g.drawcull(cd, late, task, dvb0)
+                        n = int(c4o[0])
+                        what = (use_soa, flags, fraction, late, task, records)
+                        assert G.host_u32(dccb)[0] == n, what
+                        assert P.from_device(dcb, L.TASKCMD if task else L.DRAWCMD)[:n].tobytes() == co[:n].tobytes(), what
+                        assert (G.host_u32(dvb) == dvb_o).all(), what
+    finally:
+        ctx.set_option(P.NV_OPT_DRAW_RECORDS, 0)
+    with pytest.raises(P.NvError):
+        ctx.set_option(P.NV_OPT_DRAW_RECORDS, 3)
+    ctx.status()
+
+
 def test_drawcull_counter_base_and_empty_input(ctx):
     """append indices start at the value already in the count word (atomicAdd semantics); drawCount 0 is a no-op"""
     scene = make_scene(seed=40, n_draws=700)
