@@ -196,6 +196,14 @@ struct DrawArgs
 	uint32_t meshCount;  // > 0 when nv_upload_meshes registered `meshes`: the table may be staged in LDS
 	uint32_t* hostHint;  // mapped host words (context.hip): [2], [3] = emitting draws / commands of the last TASK pass, written by its scatter launch
 	uint32_t taskList;   // TASK scatter in the list form (one lane per output command) instead of the per-draw form
+	// TASK passes in the list form: the decide launch leaves one 16-byte record per EMITTING draw — {LOD's meshletOffset, meshletCount, meshletVisibilityOffset, draw | previous
+	// visibility << 31} — compacted per wave at the front of the wave's own draw range, and the number of them per wave; the scatter launch reads those instead of the result bytes,
+	// the draw records and the Mesh table.  tileDraws is then a whole number of waves' ranges.
+	uint4* records;
+	uint32_t* recordCounts;
+	uint32_t recordsOn;
+	uint32_t tileDraws;    // draws per scatter tile (scatter_tile_draws(), rounded up to whole waves of the decide launch when records are on)
+	uint32_t unitsPerWave; // 64-draw units per wave of the decide launch
 	uint32_t visFirst;   // early pass: request the visibility words ahead of the records and only the records of last frame's visible draws (a hint: results do not depend on it)
 #ifdef NV_EXPERIMENTS
 	uint32_t debugMode; // NV_DEBUG_MODE of the experiments build

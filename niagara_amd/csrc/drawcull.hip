@@ -42,12 +42,12 @@ NV_DEV uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
 
 // drawcull.comp.glsl:56-118 + :154-155 for one draw
 // What a decision needs of a Mesh, 20 words (the decide kernel's LDS table when the Mesh table is registered):
-//   [0..3] center.xyz, radius   [4] lodCount   [5..11] lods[1..7].error   [12..19] lods[0..7].meshletCount
-constexpr uint32_t DC_LOD_WORDS = 20;
+//   [0..3] center.xyz, radius   [4] lodCount   [5..11] lods[1..7].error   [12..19] lods[0..7].meshletCount   [20..27] lods[0..7].meshletOffset
+constexpr uint32_t DC_LOD_WORDS = 28;
 // word k of that record = word lod_table_source(k) of the 52-word NvMesh
 NV_DEV uint32_t lod_table_source(uint32_t k)
 {
-	return k < 4u ? k : (k == 4u ? 8u : (k < 12u ? 12u + 5u * (k - 4u) + 4u : 12u + 5u * (k - 12u) + 3u));
+	return k < 4u ? k : (k == 4u ? 8u : (k < 12u ? 12u + 5u * (k - 4u) + 4u : (k < 20u ? 12u + 5u * (k - 12u) + 3u : 12u + 5u * (k - 20u) + 2u)));
 }
 
 // drawcull.comp.glsl:56-118 + :154-155 for one draw.  COMPACT: meshBase is the LDS table above, else the NvMesh array.
@@ -212,7 +212,7 @@ NV_DEV DrawLoad load_draw_record(const DrawArgs& a, uint32_t di)
 }
 
 // draws per scatter tile: an even split over the scatter grid, rounded up to whole waves of the decide kernel
-NV_DEV uint32_t scatter_tile_draws(uint32_t drawCount, uint32_t tiles)
+static uint32_t scatter_tile_draws(uint32_t drawCount, uint32_t tiles)
 {
 	const uint32_t t = (drawCount + tiles - 1) / tiles;
 	return t < 64u ? 64u : (t + 63u) / 64u * 64u;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
 	const uint32_t drawCount = a.cd.drawCount;
-	const uint32_t T2 = scatter_tile_draws(drawCount, a.scatterTiles);
+	const uint32_t T2 = a.tileDraws;
 	const uint32_t bank = load_uniform_u32(&a.tileCounts->parity) & 1u;
 	if (blockIdx.x == 0 && tid == 0)
 	{
@@ -362,9 +362,10 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 
 	// the wave's units: [u0, u1)
 	const uint32_t units = (drawCount + 63u) / 64u;
-	const uint32_t waves = gridDim.x * DC_WAVES;
-	const uint32_t per = (units + waves - 1u) / waves;
+	const uint32_t per = a.unitsPerWave;
 	const uint32_t w = blockIdx.x * DC_WAVES + wave;
+	const bool records = TASK && a.recordsOn != 0; // (uniform)
+	uint32_t recorded = 0;
 	const uint32_t u0 = w * per < units ? w * per : units;
 	const uint32_t u1 = u0 + per < units ? u0 + per : units;
 
@@ -408,7 +409,11 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 	}
 	const char* meshBase = stage_lod_commit<MESH_LDS>(a, st, s_lodTable);
 	if (u0 >= u1 || drawCount == 0)
+	{
+		if (records && lane == 0)
+			a.recordCounts[w] = 0u;
 		return;
+	}
 
 	const bool probe = LATE && a.cd.occlusionEnabled == 1; // (uniform)
 	uint32_t queued = 0;
@@ -418,6 +423,10 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 	auto drain = [&](uint32_t cnt) {
 		const bool mine = lane < cnt;
 		uint32_t count = 0, di = 0;
+		uint32_t mvo = 0, lodRange = 0; // records: the draw's meshletVisibilityOffset (requested ahead of the probe), the LOD's {meshletOffset, meshletCount} at mesh + lodRange
+		const char* recMesh = meshBase;
+		if (records && mine)
+			mvo = a.draws[s_q1[wave][lane].z].meshletVisibilityOffset;
 		if (mine)
 		{
 			const float4 q0 = s_q0[wave][lane];
@@ -434,6 +443,32 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 			const DrawResult res = decide_post<LATE, TASK, MESH_LDS>(a, pre, seen, di, q1.w);
 			a.results[di] = (uint8_t)((res.lodWord & 7u) | ((res.lodWord >> 8 & 1u) << 3) | ((q1.w != 0 ? 1u : 0u) << 4));
 			count = res.count;
+			recMesh = pre.mesh;
+			lodRange = res.lodWord & 7u;
+			di |= records && q1.w != 0 ? 0x80000000u : 0u; // (stripped again below)
+		}
+		if (records)
+		{
+			// one record per emitting draw, in draw order, at the front of the wave's own range of the record array
+			const uint64_t emits = __ballot(count != 0);
+			if (count != 0)
+			{
+				uint32_t meshletOffset, meshletCount;
+				if (MESH_LDS)
+				{
+					meshletOffset = reinterpret_cast<const uint32_t*>(recMesh)[20u + lodRange];
+					meshletCount = reinterpret_cast<const uint32_t*>(recMesh)[12u + lodRange];
+				}
+				else
+				{
+					meshletOffset = *reinterpret_cast<const uint32_t*>(recMesh + 48 + 20 * lodRange + 8);
+					meshletCount = *reinterpret_cast<const uint32_t*>(recMesh + 48 + 20 * lodRange + 12);
+				}
+				const uint32_t at = recorded + __builtin_amdgcn_mbcnt_hi((uint32_t)(emits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)emits, 0u));
+				a.records[(size_t)u0 * 64u + at] = make_uint4(meshletOffset, meshletCount, mvo, di);
+			}
+			recorded += (uint32_t)__builtin_popcountll(emits);
+			di &= 0x7fffffffu;
 		}
 		// counts -> the wave's run of scatter tiles (draws ascend along the queue, so do their tiles)
 		uint64_t rest = __ballot(mine);
@@ -527,6 +562,8 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 	if (queued)
 		drain(queued);
 	tile_run_flush<TASK>(a, bank, run, lane);
+	if (records && lane == 0)
+		a.recordCounts[w] = recorded;
 }
 
 // result bytes of PER consecutive draws, packed little-endian into words
@@ -550,24 +587,31 @@ NV_DEV void load_result_bytes(const uint8_t* p, uint32_t (&w)[4])
 
 // K2.  DC_PER_LANE = consecutive draws per lane (1, 4 or 16, chosen by the launcher so that a tile is one step and all
 // lanes have work: 16 for >= 1 M draws, 1 for the few thousand draws of a small scene).
-template <bool TASK, bool MESH_LDS, uint32_t DC_PER_LANE, bool LIST = false>
+// RECORDS (TASK, list form): the decide launch left a 16-byte record per emitting draw (args.h) — no result bytes, no draw words and no
+// Mesh table are read here; the records of a tile's waves are requested together with the tile counts (DC_THREADS / waves-per-tile of
+// each wave's, which holds them all unless a wave emitted from more draws than that: then the tile's records are walked in order).
+template <bool TASK, bool MESH_LDS, uint32_t DC_PER_LANE, bool LIST = false, bool RECORDS = false>
 __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 {
+	static_assert(!RECORDS || (TASK && LIST), "records feed the list form");
 	constexpr uint32_t DC_STEP = DC_THREADS * DC_PER_LANE;
-	__shared__ __attribute__((aligned(16))) uint32_t s_meshTable[MESH_LDS ? DC_MESH_LDS * sizeof(NvMesh) / 4 : 4];
+	__shared__ __attribute__((aligned(16))) uint32_t s_meshTable[MESH_LDS && !RECORDS ? DC_MESH_LDS * sizeof(NvMesh) / 4 : 4];
 	__shared__ uint32_t s_part[DC_WAVES];
 	__shared__ uint32_t s_sum[DC_WAVES];
 	// TASK: the step's emitting draws in draw order, {first command of the draw relative to the step's first command,
 	// draw within the step | lod << 12 | previous visibility << 15}, + one sentinel (round 3: one LANE per output command)
-	__shared__ uint2 s_emit[TASK && LIST ? DC_STEP + 1 : 1];
+	__shared__ uint2 s_emit[TASK && LIST && !RECORDS ? DC_STEP + 1 : 1];
 	__shared__ uint32_t s_partE[DC_WAVES];
+	__shared__ uint4 s_rec[RECORDS ? DC_THREADS : 1];           // RECORDS: the step's records in draw order ...
+	__shared__ uint32_t s_recFirst[RECORDS ? DC_THREADS + 1 : 1]; // ... and each one's first command relative to the step's, + one sentinel
+	__shared__ uint32_t s_recCount[RECORDS ? DC_THREADS + 1 : 1]; // records per wave of the tile; then their exclusive prefix
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
 	const uint32_t drawCount = a.cd.drawCount;
-	const uint32_t T = scatter_tile_draws(drawCount, a.scatterTiles);
+	const uint32_t T = a.tileDraws;
 	const uint32_t numTiles = (drawCount + T - 1) / T; // <= gridDim.x
 	const uint32_t tile = blockIdx.x;
 
@@ -595,8 +639,22 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 	const uint32_t first = tile * T;
 	const uint32_t n = tile < numTiles ? (drawCount - first < T ? drawCount - first : T) : 0u;
 	uint32_t bw[4] = { 0, 0, 0, 0 }; // first step's result bytes (usually the only step)
-	if (tid * DC_PER_LANE < n)
+	if (!RECORDS && tid * DC_PER_LANE < n)
 		load_result_bytes<DC_PER_LANE>(a.results + first + tid * DC_PER_LANE, bw);
+	// RECORDS: the tile is wavesPerTile whole ranges of the decide launch; thread tid holds record tid % share of wave tid / share
+	const uint32_t waveDraws = a.unitsPerWave * 64u;
+	const uint32_t wavesPerTile = RECORDS ? T / waveDraws : 1u;
+	const uint32_t share = RECORDS ? DC_THREADS / wavesPerTile : 1u; // >= 1 (the host takes this form for at most DC_THREADS waves per tile)
+	uint4 myRec = make_uint4(0u, 0u, 0u, 0u);
+	uint32_t myWaveRecords = 0;
+	if (RECORDS && tile < numTiles)
+	{
+		const uint32_t j = tid / share, i = tid - j * share;
+		if (j < wavesPerTile && i < waveDraws && (size_t)first + (size_t)j * waveDraws < drawCount)
+			myRec = a.records[(size_t)first + (size_t)j * waveDraws + i];
+		if (tid < wavesPerTile && (size_t)first + (size_t)tid * waveDraws < drawCount)
+			myWaveRecords = a.recordCounts[first / waveDraws + tid];
+	}
 
 	const uint32_t bank = k2parity & 1u;
 	// every workgroup clears its entries of the other bank for the next pass; one thread flips the parity the next
@@ -626,7 +684,9 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 	if (tile >= numTiles)
 		return;
 
-	const char* meshBase = stage_mesh_commit<MESH_LDS>(a, stage_mesh_issue<MESH_LDS>(a), s_meshTable);
+	const char* meshBase = RECORDS ? nullptr : stage_mesh_commit<MESH_LDS>(a, stage_mesh_issue<MESH_LDS && !RECORDS>(a), s_meshTable);
+	if (RECORDS)
+		s_recCount[tid] = myWaveRecords; // (0 past the tile's waves; ordered by the barrier below)
 
 	uint32_t before = 0, all = 0;
 #pragma unroll
@@ -685,6 +745,114 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 		const uint32_t boundary = (count + 63u) & ~63u;
 		if (tid < 64u && count + tid < boundary)
 			static_cast<NvMeshTaskCommand*>(a.commands)[count + tid] = NvMeshTaskCommand{ 0, 0, 0, 0, 0 };
+	}
+
+	if constexpr (RECORDS)
+	{
+		NvMeshTaskCommand* tc = static_cast<NvMeshTaskCommand*>(a.commands);
+		// <= DC_THREADS records in draw order, one per thread: drawcull.comp.glsl:120-139 with one LANE per output command (as the list form below)
+		auto emit_records = [&](bool valid, const uint4& rec) {
+			const uint32_t mine = valid ? (rec.y + NV_TASK_WGSIZE - 1) / NV_TASK_WGSIZE : 0u;
+			const uint32_t incl = wave_inclusive_scan(mine, lane);
+			const uint32_t mineE = valid ? 1u : 0u; // (an emitting draw has >= 1 command: the decide launch recorded only those)
+			const uint32_t inclE = wave_inclusive_scan(mineE, lane);
+			__syncthreads(); // s_part and the lists are free
+			if (lane == 63)
+			{
+				s_part[wave] = incl;
+				s_partE[wave] = inclE;
+			}
+			__syncthreads();
+			const uint32_t stepBase = running;
+			uint32_t dci = running + incl - mine, eIdx = inclE - mineE, stepEmitters = 0;
+#pragma unroll
+			for (int w = 0; w < DC_WAVES; ++w)
+			{
+				const uint32_t p = s_part[w], pe = s_partE[w];
+				dci += w < (int)wave ? p : 0u;
+				eIdx += w < (int)wave ? pe : 0u;
+				running += p;
+				stepEmitters += pe;
+			}
+			const uint32_t stepTotal = running - stepBase;
+			if (valid)
+			{
+				s_rec[eIdx] = rec;
+				s_recFirst[eIdx] = dci - stepBase;
+			}
+			if (tid == 0)
+				s_recFirst[stepEmitters] = stepTotal;
+			__syncthreads();
+			for (uint32_t k = tid; k < stepTotal; k += DC_THREADS)
+			{
+				uint32_t lo = 0, hi = stepEmitters; // invariant: s_recFirst[lo] <= k < s_recFirst[hi]
+				while (hi - lo > 1u)
+				{
+					const uint32_t mid = (lo + hi) >> 1;
+					if (s_recFirst[mid] <= k)
+						lo = mid;
+					else
+						hi = mid;
+				}
+				const uint32_t e = s_recFirst[lo];
+				const uint32_t groups = s_recFirst[lo + 1u] - e;
+				const uint32_t i = k - e;
+				const uint4 r = s_rec[lo];
+				if (stepBase + e + groups <= NV_TASK_WGLIMIT) // drop the whole draw on overflow (:128)
+				{
+					NvMeshTaskCommand cmd;
+					cmd.drawId = r.w & 0x7fffffffu;
+					cmd.taskOffset = r.x + i * NV_TASK_WGSIZE;
+					const uint32_t rest = r.y - i * NV_TASK_WGSIZE;
+					cmd.taskCount = rest < NV_TASK_WGSIZE ? rest : NV_TASK_WGSIZE;
+					cmd.lateDrawVisibility = r.w >> 31;
+					cmd.meshletVisibilityOffset = r.z + i * NV_TASK_WGSIZE;
+					tc[stepBase + k] = cmd;
+				}
+			}
+		};
+		// (s_recCount was written before the barriers of the base reduction)
+		const uint32_t j = tid / share, i = tid - j * share;
+		const bool held = !__syncthreads_or(tid < wavesPerTile && myWaveRecords > share ? 1 : 0);
+		if (held)
+			emit_records(j < wavesPerTile && i < s_recCount[j], myRec);
+		else
+		{
+			// a wave emitted from more draws than the tile's threads hold of it: the tile's records in order, DC_THREADS at a time
+			__syncthreads();
+			if (tid == 0)
+			{
+				uint32_t sum = 0;
+				for (uint32_t w = 0; w <= wavesPerTile && w <= DC_THREADS; ++w)
+				{
+					const uint32_t c = w < wavesPerTile ? s_recCount[w] : 0u;
+					s_recCount[w] = sum;
+					sum += c;
+				}
+			}
+			__syncthreads();
+			const uint32_t all = s_recCount[wavesPerTile];
+			for (uint32_t k0 = 0; k0 < all; k0 += DC_THREADS)
+			{
+				const uint32_t k = k0 + tid;
+				uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+				if (k < all)
+				{
+					uint32_t lo = 0, hi = wavesPerTile; // invariant: s_recCount[lo] <= k < s_recCount[hi]
+					while (hi - lo > 1u)
+					{
+						const uint32_t mid = (lo + hi) >> 1;
+						if (s_recCount[mid] <= k)
+							lo = mid;
+						else
+							hi = mid;
+					}
+					rec = a.records[(size_t)first + (size_t)lo * waveDraws + (k - s_recCount[lo])];
+				}
+				emit_records(k < all, rec);
+			}
+		}
+		return;
 	}
 
 	for (uint32_t c0 = 0; c0 < n; c0 += DC_STEP)
@@ -906,11 +1074,17 @@ __global__ __launch_bounds__(DC_THREADS) void draw_scatter_kernel(DrawArgs a)
 	}
 }
 
+// workgroups of the decide launch: one 64-draw unit per wave until DS_MAX_BLOCKS workgroups are out, more units per wave beyond
+static uint32_t decide_blocks(uint32_t drawCount)
+{
+	const uint32_t units = (drawCount + 63u) / 64u, want = (units + DC_WAVES - 1u) / DC_WAVES;
+	return want < 1u ? 1u : (want < DS_MAX_BLOCKS ? want : DS_MAX_BLOCKS);
+}
+
 template <bool MESH_LDS, bool SOA>
 static void launch_decide(hipStream_t stream, const DrawArgs& a, int late, int task)
 {
-	const uint32_t units = (a.cd.drawCount + 63u) / 64u, want = (units + DC_WAVES - 1u) / DC_WAVES;
-	const dim3 grid(want < 1u ? 1u : (want < DS_MAX_BLOCKS ? want : DS_MAX_BLOCKS)), block(DC_THREADS);
+	const dim3 grid(decide_blocks(a.cd.drawCount)), block(DC_THREADS);
 	if (late)
 	{
 		if (task)
@@ -951,7 +1125,9 @@ static void launch_dc(hipStream_t stream, const DrawArgs& a, int late, int task)
 #define LAUNCH_TASK_SCATTER(PER)                                                                                      \
 	do                                                                                                                 \
 	{                                                                                                                  \
-		if (a.taskList)                                                                                                \
+		if (a.recordsOn)                                                                                               \
+			hipLaunchKernelGGL((draw_scatter_kernel<true, MESH_LDS, 1, true, true>), sgrid, block, 0, stream, a);      \
+		else if (a.taskList)                                                                                                \
 			hipLaunchKernelGGL((draw_scatter_kernel<true, MESH_LDS, PER, true>), sgrid, block, 0, stream, a);          \
 		else                                                                                                           \
 			hipLaunchKernelGGL((draw_scatter_kernel<true, MESH_LDS, PER, false>), sgrid, block, 0, stream, a);         \
@@ -976,8 +1152,24 @@ static void launch_dc(hipStream_t stream, const DrawArgs& a, int late, int task)
 	}
 }
 
-int launch_drawcull(hipStream_t stream, const DrawArgs& a, int late, int task)
+int launch_drawcull(hipStream_t stream, const DrawArgs& a0, int late, int task)
 {
+	DrawArgs a = a0;
+	const uint32_t units = (a.cd.drawCount + 63u) / 64u, waves = decide_blocks(a.cd.drawCount) * DC_WAVES;
+	a.unitsPerWave = units ? (units + waves - 1u) / waves : 1u;
+	a.tileDraws = scatter_tile_draws(a.cd.drawCount, a.scatterTiles);
+	// the list form of a TASK pass reads the decide launch's records of the emitting draws: tiles of whole waves' ranges, at most one wave per thread of a tile
+	const uint32_t waveDraws = a.unitsPerWave * 64u, wavesPerTile = (a.tileDraws + waveDraws - 1u) / waveDraws;
+#ifdef DC_NO_RECORDS // (tools/build_variant.sh: A/B against the list form that reads result bytes, draw words and the Mesh table)
+	a.recordsOn = 0u;
+#else
+	a.recordsOn = task && a.taskList && a.cd.drawCount && a.cd.drawCount < 0x80000000u && wavesPerTile <= (uint32_t)DC_THREADS ? 1u : 0u;
+#endif
+	if (a.recordsOn)
+		a.tileDraws = wavesPerTile * waveDraws;
+	const size_t bytes = ((size_t)a.cd.drawCount + 64u + 255u) & ~(size_t)255u;
+	a.recordCounts = reinterpret_cast<uint32_t*>(a.results + bytes);
+	a.records = reinterpret_cast<uint4*>(a.results + bytes + (size_t)DS_MAX_BLOCKS * DC_WAVES * sizeof(uint32_t));
 	if (a.meshCount && a.meshCount <= DC_MESH_LDS)
 		launch_dc<true>(stream, a, late, task);
 	else
@@ -1018,6 +1210,11 @@ int launch_draw_split(hipStream_t stream, const NvMeshDraw* draws, const NvMesh*
 }
 
 // bytes of the per-draw result scratch (padded so that the scatter kernel's 16-B loads stay in range)
-size_t drawcull_result_bytes(uint32_t drawCount) { return (size_t)drawCount + 64; }
+// + the record counts of the decide launch's waves and one 16-byte record per draw (the TASK list form; a wave's records lie at the front of its own range)
+size_t drawcull_result_bytes(uint32_t drawCount)
+{
+	const size_t bytes = ((size_t)drawCount + 64u + 255u) & ~(size_t)255u;
+	return bytes + (size_t)DS_MAX_BLOCKS * DC_WAVES * sizeof(uint32_t) + ((size_t)drawCount + 64u) * sizeof(uint4);
+}
 
 } // namespace nv

@@ -110,18 +110,20 @@ def test_drawcull_ring_and_queue_shapes(ctx, n_draws):
                 cd = passes.set_flags(scene["cull"], flags)
                 for fraction in (1.0, 0.03, 0.0):
                     dvb0 = (rng.random(n_draws) < fraction).astype(np.uint32)
-                    for late, task, records in ((0, 0, 1), (0, 1, 2), (0, 0, 2), (1, 1, 0), (1, 0, 0)):
+                    for late, task, records, emit in ((0, 0, 1, 0), (0, 1, 2, 1), (0, 1, 1, 2), (0, 0, 2, 0), (1, 1, 0, 2), (1, 1, 0, 1), (1, 0, 0, 0)):
                         ctx.set_option(P.NV_OPT_DRAW_RECORDS, records)
+                        ctx.set_option(P.NV_OPT_TASK_EMIT, emit)  # 2: the list form, fed by the decide launch's records of the emitting draws
                         dvb_o = dvb0.copy()
                         co, c4o = passes.run_drawcull(oracle, scene, cd, late, task, dvb_o, pyr)
                         dcb, dccb, dvb = g.drawcull(cd, late, task, dvb0)
                         n = int(c4o[0])
-                        what = (use_soa, flags, fraction, late, task, records)
+                        what = (use_soa, flags, fraction, late, task, records, emit)
                         assert G.host_u32(dccb)[0] == n, what
                         assert P.from_device(dcb, L.TASKCMD if task else L.DRAWCMD)[:n].tobytes() == co[:n].tobytes(), what
                         assert (G.host_u32(dvb) == dvb_o).all(), what
     finally:
         ctx.set_option(P.NV_OPT_DRAW_RECORDS, 0)
+        ctx.set_option(P.NV_OPT_TASK_EMIT, 0)
     with pytest.raises(P.NvError):
         ctx.set_option(P.NV_OPT_DRAW_RECORDS, 3)
     ctx.status()
