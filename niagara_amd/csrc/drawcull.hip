@@ -425,8 +425,8 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 		uint32_t count = 0, di = 0;
 		uint32_t mvo = 0, lodRange = 0; // records: the draw's meshletVisibilityOffset (requested ahead of the probe), the LOD's {meshletOffset, meshletCount} at mesh + lodRange
 		const char* recMesh = meshBase;
-		if (records && mine)
-			mvo = a.draws[s_q1[wave][lane].z].meshletVisibilityOffset;
+		if (TASK)
+			mvo = a.draws[s_q1[wave][mine ? lane : 0u].z].meshletVisibilityOffset;
 		if (mine)
 		{
 			const float4 q0 = s_q0[wave][lane];
@@ -470,6 +470,11 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 			recorded += (uint32_t)__builtin_popcountll(emits);
 			di &= 0x7fffffffu;
 		}
+		// (The request of `mvo` is issued and used on every path of a TASK kernel's drain, whether records are on or not: a request that is
+		// consumed only under a condition hipcc must assume still in flight when the walk goes on, and it then waits for nearly the whole
+		// ring — vmcnt(1) — before the next unit's code overwrites the register: +1 us per decide launch at 1 M draws.)
+		if (TASK)
+			asm volatile("" ::"v"(mvo));
 		// counts -> the wave's run of scatter tiles (draws ascend along the queue, so do their tiles)
 		uint64_t rest = __ballot(mine);
 		while (rest)

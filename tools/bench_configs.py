@@ -696,11 +696,15 @@ def verdict(same):
 
 
 # NV_BENCH_CULL_FORM=n (A/B runs only): every context this module — or bench.contract_chain through it — creates pins NV_OPT_CULL_FORM to n
-if os.environ.get("NV_BENCH_CULL_FORM"):
+# NV_BENCH_TASK_EMIT=n likewise NV_OPT_TASK_EMIT (1 = per draw, 2 = the list form)
+if os.environ.get("NV_BENCH_CULL_FORM") or os.environ.get("NV_BENCH_TASK_EMIT"):
     class _PinnedContext(P.Context):
         def __init__(self, *args, **kw):
             super().__init__(*args, **kw)
-            self.set_option(P.NV_OPT_CULL_FORM, int(os.environ["NV_BENCH_CULL_FORM"]))
+            if os.environ.get("NV_BENCH_CULL_FORM"):
+                self.set_option(P.NV_OPT_CULL_FORM, int(os.environ["NV_BENCH_CULL_FORM"]))
+            if os.environ.get("NV_BENCH_TASK_EMIT"):
+                self.set_option(P.NV_OPT_TASK_EMIT, int(os.environ["NV_BENCH_TASK_EMIT"]))
     P.Context = _PinnedContext
 
 

@@ -32,6 +32,8 @@ while time.time() - t0 < budget:
     if os.environ.get("FUZZ_VERBOSE"):
         print("seed", seed, kw, flags, use_soa, fused, flush=True)
     scene = make_scene(**kw)
+    ctx.set_option(P.NV_OPT_DRAW_RECORDS, seed % 3)      # drawcull: the early pass's request order ...
+    ctx.set_option(P.NV_OPT_TASK_EMIT, seed // 3 % 3)    # ... and the task pass's emission form (2: the list form, fed by the decide launch's records)
     fo = passes.run_frames(oracle, scene, flags, frames=3)
     fg = G.run_frames(ctx, scene, flags, frames=3, use_soa=use_soa, fused=fused)
     ok = True

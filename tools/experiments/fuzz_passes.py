@@ -41,19 +41,38 @@ while time.time() - t0 < budget:
     oracle.depthreduce(scene["depth"], pyr)
     if g.depthreduce(scene["depth"]).tobytes() != pyr.data.tobytes():
         bad.append(("scene pyramid", seed, kw))
-    for late in (0, 1):
-        for task in (0, 1):
-            post = int(rng.integers(0, 2))
-            cd = passes.set_flags(scene["cull"], flags)
-            dvb0 = (rng.random(len(scene["draws"])) < rng.random()).astype(np.uint32)
-            dvb_o = dvb0.copy()
-            co, c4o = passes.run_drawcull(oracle, scene, cd, late, task, dvb_o, pyr, post)
-            dcb, dccb, dvb = g.drawcull(cd, late, task, dvb0, post)
-            n = int(c4o[0])
-            dt = L.TASKCMD if task else L.DRAWCMD
-            if G.host_u32(dccb)[0] != n or P.from_device(dcb, dt)[:n].tobytes() != co[:n].tobytes() or not (G.host_u32(dvb) == dvb_o).all():
-                bad.append(("drawcull", seed, kw, flags, late, task, post))
-            counts["drawcull"] += 1
+    def drawcull_passes(scene, g, pyr, flags, what):
+        for late in (0, 1):
+            for task in (0, 1):
+                post = int(rng.integers(0, 2))
+                # the early pass's request order and the task pass's emission form (round 6: the list form reads the decide launch's records)
+                opts = (int(rng.integers(0, 3)), int(rng.integers(0, 3)))
+                ctx.set_option(P.NV_OPT_DRAW_RECORDS, opts[0])
+                ctx.set_option(P.NV_OPT_TASK_EMIT, opts[1])
+                cd = passes.set_flags(scene["cull"], flags)
+                dvb0 = (rng.random(len(scene["draws"])) < rng.random() ** 2).astype(np.uint32)
+                dvb_o = dvb0.copy()
+                co, c4o = passes.run_drawcull(oracle, scene, cd, late, task, dvb_o, pyr, post)
+                dcb, dccb, dvb = g.drawcull(cd, late, task, dvb0, post)
+                n = int(c4o[0])
+                dt = L.TASKCMD if task else L.DRAWCMD
+                if G.host_u32(dccb)[0] != n or P.from_device(dcb, dt)[:n].tobytes() != co[:n].tobytes() or not (G.host_u32(dvb) == dvb_o).all():
+                    bad.append(("drawcull", seed, what, flags, late, task, post, opts))
+                counts["drawcull"] += 1
+        ctx.set_option(P.NV_OPT_DRAW_RECORDS, 0)
+        ctx.set_option(P.NV_OPT_TASK_EMIT, 0)
+
+    drawcull_passes(scene, g, pyr, flags, kw)
+    # ---- and over enough draws that a wave of the decide launch walks several 64-draw units (more than 131 072)
+    big = dict(seed=seed, n_draws=int(rng.integers(131_073, 600_000)), n_meshes=int(rng.integers(1, 9)), lods=int(rng.integers(1, 9)), meshlets_lod0=int(rng.integers(1, 400)),
+               scene_radius=float(rng.uniform(5, 60)), post_pass_fraction=float(rng.choice([0.0, 0.1])))
+    scene = make_scene(**big)
+    g = G.GpuScene(ctx, scene, bool(rng.integers(0, 2)))
+    pyr = oracle.Pyramid(*scene["viewport"])
+    oracle.depthreduce(scene["depth"], pyr)
+    g.depthreduce(scene["depth"])
+    drawcull_passes(scene, g, pyr, tuple(int(x) for x in rng.integers(0, 2, 5)), big)
+    del g, scene
     # ---- pyramid of a random size
     w, h = (int(rng.integers(1, 1200)), int(rng.integers(1, 900))) if rng.random() < 0.8 else (int(2 ** rng.integers(0, 12)), int(2 ** rng.integers(0, 12)))
     depth = rng.random((h, w), dtype=np.float32)
