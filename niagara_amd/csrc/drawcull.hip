@@ -340,7 +340,7 @@ NV_DEV void tile_run_flush(const DrawArgs& a, uint32_t bank, const TileRun& run,
 	}
 }
 
-template <bool LATE, bool TASK, bool MESH_LDS, bool SOA, bool VISFIRST>
+template <bool LATE, bool TASK, bool MESH_LDS, bool SOA, bool VISFIRST, bool RECORDS>
 __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t s_lodTable[MESH_LDS ? DC_MESH_LDS * DC_LOD_WORDS : 4];
@@ -364,7 +364,8 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 	const uint32_t units = (drawCount + 63u) / 64u;
 	const uint32_t per = a.unitsPerWave;
 	const uint32_t w = blockIdx.x * DC_WAVES + wave;
-	const bool records = TASK && a.recordsOn != 0; // (uniform)
+	static_assert(!RECORDS || TASK, "records feed the TASK scatter's list form");
+	constexpr bool records = RECORDS;
 	uint32_t recorded = 0;
 	const uint32_t u0 = w * per < units ? w * per : units;
 	const uint32_t u1 = u0 + per < units ? u0 + per : units;
@@ -385,36 +386,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 		slot = load_draw_fields<SOA>(a, draw_of(u, vis != 0 ? lane : 0u));
 		slot.oldVis = vis != 0 ? 1u : 0u; // (a value of its own: the register of the word just read is free for the next one)
 	};
-	const LodStage st = stage_lod_issue<MESH_LDS>(a);
-	DrawLoad ring[DS_DEPTH];
-	uint32_t visRing[DS_DEPTH]; // VISFIRST: visRing[k] = the visibility words of the unit DS_DEPTH after ring[k]'s
-	if (VISFIRST)
-	{
-		uint32_t first[DS_DEPTH];
-#pragma unroll
-		for (uint32_t k = 0; k < DS_DEPTH; ++k)
-			first[k] = a.dvb[draw_of(u0 + k, lane)];
-#pragma unroll
-		for (uint32_t k = 0; k < DS_DEPTH; ++k)
-			visRing[k] = a.dvb[draw_of(u0 + DS_DEPTH + k, lane)];
-#pragma unroll
-		for (uint32_t k = 0; k < DS_DEPTH; ++k)
-			request_visible(ring[k], u0 + k, first[k]);
-	}
-	else
-	{
-#pragma unroll
-		for (uint32_t k = 0; k < DS_DEPTH; ++k)
-			request(ring[k], u0 + k);
-	}
-	const char* meshBase = stage_lod_commit<MESH_LDS>(a, st, s_lodTable);
-	if (u0 >= u1 || drawCount == 0)
-	{
-		if (records && lane == 0)
-			a.recordCounts[w] = 0u;
-		return;
-	}
-
+	const char* meshBase = nullptr; // (set once the Mesh table is staged; the functions below are called after that)
 	const bool probe = LATE && a.cd.occlusionEnabled == 1; // (uniform)
 	uint32_t queued = 0;
 	TileRun run = { u0 * 64u / T2, 0u, 0u };
@@ -425,7 +397,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 		uint32_t count = 0, di = 0;
 		uint32_t mvo = 0, lodRange = 0; // records: the draw's meshletVisibilityOffset (requested ahead of the probe), the LOD's {meshletOffset, meshletCount} at mesh + lodRange
 		const char* recMesh = meshBase;
-		if (TASK)
+		if (RECORDS)
 			mvo = a.draws[s_q1[wave][mine ? lane : 0u].z].meshletVisibilityOffset;
 		if (mine)
 		{
@@ -470,10 +442,10 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 			recorded += (uint32_t)__builtin_popcountll(emits);
 			di &= 0x7fffffffu;
 		}
-		// (The request of `mvo` is issued and used on every path of a TASK kernel's drain, whether records are on or not: a request that is
+		// (The request of `mvo` is issued and used on every path of the drain — RECORDS is a template parameter for that: a request that is
 		// consumed only under a condition hipcc must assume still in flight when the walk goes on, and it then waits for nearly the whole
 		// ring — vmcnt(1) — before the next unit's code overwrites the register: +1 us per decide launch at 1 M draws.)
-		if (TASK)
+		if (RECORDS)
 			asm volatile("" ::"v"(mvo));
 		// counts -> the wave's run of scatter tiles (draws ascend along the queue, so do their tiles)
 		uint64_t rest = __ballot(mine);
@@ -537,6 +509,58 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 			queued += (uint32_t)__builtin_popcountll(want);
 		}
 	};
+
+	const LodStage st = stage_lod_issue<MESH_LDS>(a);
+	// A pass of at most DS_MAX_BLOCKS * DC_WAVES units has one unit per wave and nothing to run ahead of: request, decide, finish — in a
+	// block of its own that ends the kernel, so that the ring below has one definition in front of the walk (a value requested under a
+	// condition and used under a later one is "maybe in flight" for hipcc on the other path, and the walk then waits for it in every round).
+	if (per == 1u) // (uniform over the grid)
+	{
+		DrawLoad one;
+		if (VISFIRST)
+			request_visible(one, u0, a.dvb[draw_of(u0, lane)]);
+		else
+			request(one, u0);
+		meshBase = stage_lod_commit<MESH_LDS>(a, st, s_lodTable);
+		if (u0 < u1)
+		{
+			decide(one, u0);
+			if (queued)
+				drain(queued);
+			tile_run_flush<TASK>(a, bank, run, lane);
+		}
+		if (records && lane == 0)
+			a.recordCounts[w] = recorded;
+		return;
+	}
+	DrawLoad ring[DS_DEPTH];
+	uint32_t visRing[DS_DEPTH]; // VISFIRST: visRing[k] = the visibility words of the unit DS_DEPTH after ring[k]'s
+	if (VISFIRST)
+	{
+		uint32_t first[DS_DEPTH];
+#pragma unroll
+		for (uint32_t k = 0; k < DS_DEPTH; ++k)
+			first[k] = a.dvb[draw_of(u0 + k, lane)];
+#pragma unroll
+		for (uint32_t k = 0; k < DS_DEPTH; ++k)
+			visRing[k] = a.dvb[draw_of(u0 + DS_DEPTH + k, lane)];
+#pragma unroll
+		for (uint32_t k = 0; k < DS_DEPTH; ++k)
+			request_visible(ring[k], u0 + k, first[k]);
+	}
+	else
+	{
+#pragma unroll
+		for (uint32_t k = 0; k < DS_DEPTH; ++k)
+			request(ring[k], u0 + k);
+	}
+	meshBase = stage_lod_commit<MESH_LDS>(a, st, s_lodTable);
+	if (u0 >= u1)
+	{
+		if (records && lane == 0)
+			a.recordCounts[w] = 0u;
+		return;
+	}
 
 	// Every slot of the ring is decided and requested again in every round (units past the wave's range: clamped loads, nothing
 	// written), and a slot's new loads are issued only after the last use of its old values — so that the loop carries the ring in
@@ -1090,31 +1114,40 @@ template <bool MESH_LDS, bool SOA>
 static void launch_decide(hipStream_t stream, const DrawArgs& a, int late, int task)
 {
 	const dim3 grid(decide_blocks(a.cd.drawCount)), block(DC_THREADS);
+#ifdef DS_FORCE_VISFIRST // (tools/build_variant.sh: A/B of the two early forms)
+	const bool visFirst = DS_FORCE_VISFIRST;
+#else
+	const bool visFirst = a.visFirst != 0;
+#endif
+#define LAUNCH_DECIDE(L, T, V, R) hipLaunchKernelGGL((draw_decide_kernel<L, T, MESH_LDS, SOA, V, R>), grid, block, 0, stream, a)
 	if (late)
 	{
-		if (task)
-			hipLaunchKernelGGL((draw_decide_kernel<true, true, MESH_LDS, SOA, false>), grid, block, 0, stream, a);
+		if (!task)
+			LAUNCH_DECIDE(true, false, false, false);
+		else if (a.recordsOn)
+			LAUNCH_DECIDE(true, true, false, true);
 		else
-			hipLaunchKernelGGL((draw_decide_kernel<true, false, MESH_LDS, SOA, false>), grid, block, 0, stream, a);
+			LAUNCH_DECIDE(true, true, false, false);
 	}
-#ifdef DS_FORCE_VISFIRST // (tools/build_variant.sh: A/B of the two early forms)
-	else if (DS_FORCE_VISFIRST)
-#else
-	else if (a.visFirst)
-#endif
+	else if (visFirst)
 	{
-		if (task)
-			hipLaunchKernelGGL((draw_decide_kernel<false, true, MESH_LDS, SOA, true>), grid, block, 0, stream, a);
+		if (!task)
+			LAUNCH_DECIDE(false, false, true, false);
+		else if (a.recordsOn)
+			LAUNCH_DECIDE(false, true, true, true);
 		else
-			hipLaunchKernelGGL((draw_decide_kernel<false, false, MESH_LDS, SOA, true>), grid, block, 0, stream, a);
+			LAUNCH_DECIDE(false, true, true, false);
 	}
 	else
 	{
-		if (task)
-			hipLaunchKernelGGL((draw_decide_kernel<false, true, MESH_LDS, SOA, false>), grid, block, 0, stream, a);
+		if (!task)
+			LAUNCH_DECIDE(false, false, false, false);
+		else if (a.recordsOn)
+			LAUNCH_DECIDE(false, true, false, true);
 		else
-			hipLaunchKernelGGL((draw_decide_kernel<false, false, MESH_LDS, SOA, false>), grid, block, 0, stream, a);
+			LAUNCH_DECIDE(false, true, false, false);
 	}
+#undef LAUNCH_DECIDE
 }
 
 template <bool MESH_LDS>

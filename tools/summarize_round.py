@@ -224,7 +224,9 @@ for n_, c, a, mi, ma in rows:
 md += """
 The sum of the averages is the frame: the launches are back to back.  What changed against round 5: the late cull launch (frustum / cone ballots of 174 760 commands, `DEFER`) walks packed
 windows of 64 valid meshlets (`cluster_mask_kernel<false, true, false, 8, true, true, true>`: 28-29 us against 37.6-38.2); the early cull launch (one lane per set bit) tests with the draw's
-margin `tK`.  The occlusion stage (58 us, 0.77 of its vector-issue floor) reads 209 MB per launch for 6.1 M probes; a group test in front of it was measured on the CPU and not built
+margin `tK`; `drawcull`'s decide launch is a fixed grid of waves walking 64-draw units behind a ring of requests (late: 12.1-12.2 us against 12.8-13.3; early, visibility words ahead
+of the records and only last frame's visible draws' records fetched: 8.3 against 9.2-10.4, 20.7 MB per launch instead of 33) and hands 16-byte records of the emitting draws to the TASK
+scatter launch (`draw_scatter_kernel<true, true, 1u, true, true>`: 6.2-6.5 us against 8.5-8.8).  The occlusion stage (58 us, 0.77 of its vector-issue floor) reads 209 MB per launch for 6.1 M probes; a group test in front of it was measured on the CPU and not built
 (`tools/experiments/hiz_group_fraction.py`: 26 % of the listed commands end all-occluded, a conservative test certifies 0.1 % of them).
 """
 open(OUT + "frame.md", "w").write(md)
