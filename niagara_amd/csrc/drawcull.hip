@@ -399,6 +399,10 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 		const char* recMesh = meshBase;
 		if (RECORDS)
 			mvo = a.draws[s_q1[wave][mine ? lane : 0u].z].meshletVisibilityOffset;
+		// late pass over the mirror: {scale, meshIndex} of the survivors only, requested here beside the probe's texels (the walk leaves them out: 8 of 32 B per draw)
+		uint2 lateSm = make_uint2(0u, 0u);
+		if (LATE && SOA)
+			lateSm = a.soaScaleMesh[s_q1[wave][mine ? lane : 0u].z];
 		if (mine)
 		{
 			const float4 q0 = s_q0[wave][lane];
@@ -407,8 +411,8 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 			DrawPre pre;
 			pre.c = f3{ q0.x, q0.y, q0.z };
 			pre.radius = q0.w;
-			pre.scale = __uint_as_float(q1.x);
-			pre.mesh = meshBase + (size_t)q1.y * (MESH_LDS ? DC_LOD_WORDS * 4u : sizeof(NvMesh));
+			pre.scale = __uint_as_float(LATE && SOA ? lateSm.x : q1.x);
+			pre.mesh = meshBase + (size_t)(LATE && SOA ? lateSm.y : q1.y) * (MESH_LDS ? DC_LOD_WORDS * 4u : sizeof(NvMesh));
 			pre.skip = false;
 			pre.visible = true;
 			const bool seen = probe ? draw_probe(a, pre.c, pre.radius) : true;
@@ -447,6 +451,8 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 		// ring — vmcnt(1) — before the next unit's code overwrites the register: +1 us per decide launch at 1 M draws.)
 		if (RECORDS)
 			asm volatile("" ::"v"(mvo));
+		if (LATE && SOA)
+			asm volatile("" ::"v"(lateSm.x), "v"(lateSm.y)); // (likewise)
 		// counts -> the wave's run of scatter tiles (draws ascend along the queue, so do their tiles)
 		uint64_t rest = __ballot(mine);
 		while (rest)
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 			if (survives)
 			{
 				s_q0[wave][slot] = make_float4(pre.c.x, pre.c.y, pre.c.z, pre.radius);
-				s_q1[wave][slot] = make_uint4(__float_as_uint(pre.scale), ld.d2.x, di, ld.oldVis);
+				s_q1[wave][slot] = LATE && SOA ? make_uint4(0u, 0u, di, ld.oldVis) : make_uint4(__float_as_uint(pre.scale), ld.d2.x, di, ld.oldVis);
 			}
 			queued += (uint32_t)__builtin_popcountll(want);
 		}
