@@ -13,9 +13,12 @@
 //                           16 consecutive draws (one 16-B load of result bytes); the append index of a draw is the
 //                           exclusive prefix sum of the emit counts in draw order — one valid serialisation of the
 //                           reference's atomicAdd (drawcull.comp.glsl:123,143), and bit-reproducible.
-//                           TASK mode expands a draw's commands wave-cooperatively: the owning lane's (draw, LOD range,
-//                           dci) is broadcast with readlane and all 64 lanes write consecutive 20-B MeshTaskCommands,
-//                           instead of one lane looping over up to hundreds of commands (drawcull.comp.glsl:131-138).
+//                           TASK mode, per-draw form (draws of one or two task groups): a draw's commands are written by its
+//                           own lane or, beyond four, wave-cooperatively (the owning lane's draw, LOD range and dci broadcast
+//                           with readlane, 64 lanes writing consecutive 20-B MeshTaskCommands) instead of one lane looping over
+//                           up to hundreds of commands (drawcull.comp.glsl:131-138).  TASK mode, list form (many task groups per
+//                           draw): one LANE per output command; since round 6 fed by 16-byte records of the emitting draws that
+//                           K1 leaves per wave, so that K2 reads neither result bytes nor draw words nor the Mesh table.
 #include "cullmath.h"
 #include "args.h"
 

@@ -89,3 +89,30 @@ def test_dpp_scans_refuse_a_non_gfx9_target(tmp_path):
     assert "args.h: the DPP scans are written for GFX9-family wave64 targets (gfx950)" in bad.stderr
     good = subprocess.run(["hipcc", "--offload-arch=gfx950", "-std=c++17", "-c", str(src), "-o", str(tmp_path / "good.o")], capture_output=True, text=True, timeout=300)
     assert good.returncode == 0, good.stderr[-2000:]
+
+
+def test_decide_ring_stays_in_flight():
+    """drawcull.hip's decide kernel keeps four units of requests in flight behind waits the COMPILER counts; twice in round 6 hipcc placed them so that
+    the ring drained (results right, kernel 1 us slower): tools/check_decide_ring.py finds a wait with a small count inside the walk outside the
+    queue's drains.  On the real file with the validated compiler, and on the two regressions it was written after."""
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    tool = os.path.join(ROOT, "tools", "check_decide_ring.py")
+    src = os.path.join(ROOT, "niagara_amd", "csrc", "drawcull.hip")
+    r = subprocess.run([sys.executable, tool, "--hipcc", hipcc], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    text = open(src).read()
+    gather = "\t\tif (RECORDS)\n\t\t\tmvo = a.draws[s_q1[wave][mine ? lane : 0u].z].meshletVisibilityOffset;"
+    use = "\t\tif (RECORDS)\n\t\t\tasm volatile(\"\" ::\"v\"(mvo));"
+    assert gather in text and use in text
+    bad = text.replace(gather, "\t\tif (RECORDS && mine)\n\t\t\tmvo = a.draws[s_q1[wave][lane].z].meshletVisibilityOffset;").replace(use, "")
+    copy = os.path.join(os.path.dirname(src), "_ring_regression.hip")
+    try:
+        open(copy, "w").write(bad)
+        r = subprocess.run([sys.executable, tool, "--hipcc", hipcc, "--src", copy], capture_output=True, text=True)
+        assert r.returncode == 1 and "vmcnt(1)" in r.stdout, r.stdout
+    finally:
+        os.remove(copy)
