@@ -324,6 +324,9 @@ NV_DEV const char* stage_lod_commit(const DrawArgs& a, const LodStage& st, uint3
 #ifndef DS_DEPTH
 #define DS_DEPTH 4
 #endif
+#ifndef DS_DEFER_SM
+#define DS_DEFER_SM 1 // (0: tools/build_variant.sh A/B — the early pass's walk requests {scale, meshIndex} of every draw with the other streams)
+#endif
 constexpr uint32_t DS_QUEUE = 128; // survivors a wave may hold: a unit adds at most 64 to fewer than 64
 
 struct TileRun
@@ -347,8 +350,10 @@ template <bool LATE, bool TASK, bool MESH_LDS, bool SOA, bool VISFIRST, bool REC
 __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t s_lodTable[MESH_LDS ? DC_MESH_LDS * DC_LOD_WORDS : 4];
-	__shared__ float4 s_q0[DC_WAVES][DS_QUEUE]; // view-space centre, radius
-	__shared__ uint4 s_q1[DC_WAVES][DS_QUEUE];  // scale, meshIndex, draw, previous visibility
+	// (DS_DEFER_SM: the survivors of the last DS_DEPTH + 1 units may wait for their {scale, meshIndex} behind fewer than 64 whole entries)
+	constexpr uint32_t QUEUE = DS_DEFER_SM && SOA && !LATE && !(VISFIRST && DS_DEFER_SM == 1) ? 64u * (DS_DEPTH + 2u) : DS_QUEUE;
+	__shared__ float4 s_q0[DC_WAVES][QUEUE]; // view-space centre, radius
+	__shared__ uint4 s_q1[DC_WAVES][QUEUE];  // scale, meshIndex, draw, previous visibility
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
@@ -474,27 +479,54 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 			run.emit += emit;
 			rest &= ~__ballot(in);
 		}
-		// what is left moves to the front
-		if (queued > cnt)
+		// what is left moves to the front (64 entries at a time, lowest first: a destination is never ahead of a source not yet read)
+		for (uint32_t base = 0; cnt + base < queued; base += 64u)
 		{
 			float4 m0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 			uint4 m1 = make_uint4(0u, 0u, 0u, 0u);
-			const bool moves = lane < queued - cnt;
+			const bool moves = cnt + base + lane < queued;
 			if (moves)
 			{
-				m0 = s_q0[wave][cnt + lane];
-				m1 = s_q1[wave][cnt + lane];
+				m0 = s_q0[wave][cnt + base + lane];
+				m1 = s_q1[wave][cnt + base + lane];
 			}
 			if (moves)
 			{
-				s_q0[wave][lane] = m0;
-				s_q1[wave][lane] = m1;
+				s_q0[wave][base + lane] = m0;
+				s_q1[wave][base + lane] = m1;
 			}
 		}
 		queued -= cnt;
 	};
 
-	auto decide = [&](const DrawLoad& ld, uint32_t u) {
+	// The early pass's walk over the mirror leaves {scale, meshIndex} out like the late pass's (only the LOD select reads them: 8 of 32 B per draw, 24 of 33 MB
+	// at 1 M draws).  With no probe to hide the request behind, a unit's survivors request theirs right after the frustum test and the words are put into the
+	// queue entries when the slot comes round again (commit_pending); only whole entries drain.
+	constexpr bool deferSm = DS_DEFER_SM && SOA && !LATE && !(VISFIRST && DS_DEFER_SM == 1); // (DS_DEFER_SM=2: also in the visibility-first form, where the records are fetched for last frame's visible draws only anyway)
+	// one pending request per ring slot: issued when the slot's unit is decided, put into the queue when the slot comes round again (DS_DEPTH units later:
+	// consumed any earlier, the in-order return of the loads would make it a wait for every request of the ring issued before it)
+	uint2 pendSm[DS_DEPTH];
+	uint32_t pendSlot[DS_DEPTH], pendCount[DS_DEPTH], uncommitted = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < DS_DEPTH; ++k)
+	{
+		pendSm[k] = make_uint2(0u, 0u);
+		pendSlot[k] = ~0u;
+		pendCount[k] = 0u;
+	}
+	auto commit_pending = [&](uint32_t k) {
+		if (deferSm)
+		{
+			asm volatile("" ::"v"(pendSm[k].x), "v"(pendSm[k].y)); // (used on every path: see the drain's `mvo`)
+			if (pendSlot[k] != ~0u)
+				*reinterpret_cast<uint2*>(&s_q1[wave][pendSlot[k]]) = pendSm[k];
+			pendSlot[k] = ~0u;
+			uncommitted -= pendCount[k];
+			pendCount[k] = 0u;
+		}
+	};
+	auto decide = [&](const DrawLoad& ld, uint32_t u, auto ringed, uint32_t k) {
+		constexpr bool deferred = deferSm && decltype(ringed)::value;
 		const uint32_t di = u * 64u + lane;
 		const bool valid = u < u1 && di < drawCount;
 		DrawPre pre = decide_pre<LATE, MESH_LDS, SOA>(a, meshBase, ld.d0, ld.d1, ld.d2, ld.oldVis);
@@ -507,15 +539,24 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 				a.dvb[di] = 0u;
 		}
 		const uint64_t want = __ballot(survives);
+		if (deferred)
+			pendSm[k] = a.soaScaleMesh[survives ? di : (u < u1 ? u : u0) * 64u]; // (every lane, the others the unit's first draw: one unconditional instruction)
 		if (want)
 		{
 			const uint32_t slot = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
 			if (survives)
 			{
 				s_q0[wave][slot] = make_float4(pre.c.x, pre.c.y, pre.c.z, pre.radius);
-				s_q1[wave][slot] = LATE && SOA ? make_uint4(0u, 0u, di, ld.oldVis) : make_uint4(__float_as_uint(pre.scale), ld.d2.x, di, ld.oldVis);
+				s_q1[wave][slot] = (LATE && SOA) || deferred ? make_uint4(0u, 0u, di, ld.oldVis) : make_uint4(__float_as_uint(pre.scale), ld.d2.x, di, ld.oldVis);
+				if (deferred)
+					pendSlot[k] = slot;
 			}
 			queued += (uint32_t)__builtin_popcountll(want);
+			if (deferred)
+			{
+				pendCount[k] = (uint32_t)__builtin_popcountll(want);
+				uncommitted += pendCount[k];
+			}
 		}
 	};
 
@@ -533,7 +574,7 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 		meshBase = stage_lod_commit<MESH_LDS>(a, st, s_lodTable);
 		if (u0 < u1)
 		{
-			decide(one, u0);
+			decide(one, u0, std::false_type{}, 0u);
 			if (queued)
 				drain(queued);
 			tile_run_flush<TASK>(a, bank, run, lane);
@@ -581,8 +622,19 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 #pragma unroll
 		for (uint32_t k = 0; k < DS_DEPTH; ++k)
 		{
+			if (deferSm)
+			{
+				commit_pending(k); // the survivors of this slot's last unit are whole now ...
+				if (queued - uncommitted >= 64u) // ... and only whole entries drain (the queue is in draw order: the whole ones are at its front)
+				{
+					drain(64u);
+#pragma unroll
+					for (uint32_t j = 0; j < DS_DEPTH; ++j)
+						pendSlot[j] = pendSlot[j] != ~0u ? pendSlot[j] - 64u : ~0u; // (what was left moved to the front)
+				}
+			}
 			if (u + k < u1) // (uniform; a pass of few draws has one unit per wave and DS_DEPTH - 1 idle slots)
-				decide(ring[k], u + k);
+				decide(ring[k], u + k, std::true_type{}, k);
 			asm volatile("" ::: "memory");
 			if (VISFIRST)
 			{
@@ -593,10 +645,15 @@ __global__ __launch_bounds__(DC_THREADS) void draw_decide_kernel(DrawArgs a)
 			else
 				request(ring[k], u + k + DS_DEPTH);
 			asm volatile("" ::: "memory");
-			if (queued >= 64u)
+			if (!deferSm && queued >= 64u)
 				drain(64u);
 		}
 	}
+#pragma unroll
+	for (uint32_t k = 0; k < DS_DEPTH; ++k)
+		commit_pending(k);
+	while (deferSm && queued > 64u)
+		drain(64u);
 	if (queued)
 		drain(queued);
 	tile_run_flush<TASK>(a, bank, run, lane);
